@@ -1,0 +1,237 @@
+/*
+ * mi355_nanovllm.h — C ABI of libmi355_nanovllm.so
+ *
+ * MI355X (gfx950 / CDNA4) replacement for the device-operator surface that the
+ * reference (linzm1007/nano-vllm-ascend) reaches through torch_npu / torchair:
+ * the paged-KV Qwen3 decode path and the prefill that feeds it.
+ *
+ * The reference has no FFI of its own: its seam is the Python class surface of
+ * nanovllm/layers.  Every entry point below names the reference
+ * call site it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points)
+ *   - plain pointers + sizes; no torch types.  `mi_bf16` is a raw 16-bit
+ *     bfloat16 pattern.  All device pointers must be 16-byte aligned.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), allocates
+ *     nothing, never synchronises, safe to call while the stream is being
+ *     captured into a hipGraph.
+ *   - the caller owns every buffer, including the workspace.
+ *   - returns MI_OK (0) or a negative MI_E* code; never throws.  Argument
+ *     validation happens on the host before anything is enqueued.
+ *   - indices (block ids, slots) are NOT range-checked on the device, matching
+ *     the reference ops (op_docs/_op_plugin_docs.py:9656-9657, :7123); negative
+ *     slots / block ids are skipped.
+ *
+ * Paged KV cache layout ("fragment-native")
+ *   One layer's K (or V) cache is   [num_blocks][n_kv_heads][block_size/16][2048] bf16,
+ *   i.e. one 4 KiB tile per (16 consecutive slots of a block, kv head); head_dim = 128.
+ *   Element (t = slot%16, d) of a K tile sits at  (d/32)*512 + (((d%32)/8)*16 + t)*8 + d%8,
+ *   element (t, d) of a V tile at                 (d/32)*512 + ((t/4)*16 + d%16)*8 + ((d%32)/16)*4 + t%4
+ *   (offsets in bf16 elements).  A wavefront's 1 KiB coalesced load of a tile
+ *   quarter is then exactly one MFMA 16x16x32 operand fragment.  Only block ids
+ *   and slot indices are part of the parity contract with the reference
+ *   (model_runner.py:218 stores [nblk, block, Hkv*D]); `mi_kv_cache_gather`
+ *   converts back to that logical view for bit-exact content checks.
+ */
+#ifndef MI355_NANOVLLM_H
+#define MI355_NANOVLLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t mi_bf16;
+typedef void*    mi_stream; /* hipStream_t */
+
+enum {
+  MI_OK            = 0,
+  MI_EINVAL        = -1, /* bad argument (null pointer, negative size, misaligned) */
+  MI_EUNSUPPORTED  = -2, /* shape outside what the kernels are built for          */
+  MI_EWORKSPACE    = -3, /* workspace too small                                   */
+  MI_ELAUNCH       = -4  /* hipLaunchKernel reported an error                     */
+};
+
+#define MI_HEAD_DIM        128  /* the only head_dim compiled (all Qwen3 sizes)   */
+#define MI_KV_TILE_TOKENS  16
+#define MI_KV_TILE_ELEMS   2048
+
+/* ---- library info -------------------------------------------------------- */
+const char* mi_strerror(int code);
+/* "mi355_nanovllm <semver> gfx950" */
+const char* mi_version(void);
+/* hipGetLastError() text of the most recent MI_ELAUNCH on this thread. */
+const char* mi_last_launch_error(void);
+
+/* ---- KV cache: layout helpers ------------------------------------------- */
+/* Element offset of logical (slot_in_block, head, d) inside one block of the
+ * K (is_v=0) or V (is_v=1) cache.  Host-side helper used by tests. */
+int64_t mi_kv_elem_offset(int is_v, int slot_in_block, int kv_head, int d,
+                          int n_kv_heads, int block_size);
+
+/* ---- KV scatter (reference: layers/attention.py:22-35) ------------------- */
+/* Prefill scatter, stands in for torch_npu._npu_reshape_and_cache
+ * (attention.py:25-30): cache[slot_flat[t]] = k[t], v[t] for every token t.
+ * k/v are [n_tokens, n_kv_heads, 128] with row strides given in elements
+ * (v is a strided view of the fused qkv output, qwen3.py:79).
+ * slot_flat[t] = block_id*block_size + offset (model_runner.py:263-270); <0 skips. */
+int mi_reshape_and_cache(const mi_bf16* k, const mi_bf16* v,
+                         int64_t k_row_stride, int64_t v_row_stride,
+                         mi_bf16* k_cache, mi_bf16* v_cache,
+                         const int32_t* slot_flat, int n_tokens,
+                         int n_kv_heads, int head_dim, int block_size,
+                         mi_stream stream);
+
+/* Decode scatter, stands in for the two torch_npu.scatter_update_ calls
+ * (attention.py:32-35): cache[idx[b][0], idx[b][1]] = k[b], v[b].
+ * slot_2d is [batch][2] int32 = {block_id, offset} (model_runner.py:301,353). */
+int mi_scatter_update_kv(const mi_bf16* k, const mi_bf16* v,
+                         int64_t k_row_stride, int64_t v_row_stride,
+                         mi_bf16* k_cache, mi_bf16* v_cache,
+                         const int32_t* slot_2d, int batch,
+                         int n_kv_heads, int head_dim, int block_size,
+                         mi_stream stream);
+
+/* Test/debug helper: read rows back from the fragment-native cache into the
+ * reference's logical [n, n_kv_heads*128] layout (one row per flat slot). */
+int mi_kv_cache_gather(const mi_bf16* cache, int is_v,
+                       const int32_t* slot_flat, int n,
+                       mi_bf16* out, int n_kv_heads, int head_dim, int block_size,
+                       mi_stream stream);
+
+/* ---- paged attention ------------------------------------------------------ */
+/* Bytes of workspace mi_paged_attn_decode needs for (batch, n_q_heads). */
+size_t mi_paged_attn_decode_workspace(int batch, int n_q_heads);
+
+/* Decode attention, stands in for npu_fused_infer_attention_score_v2 "BNSD"
+ * with block_table (attention.py:63-76) and its torchair twin (:79-93).
+ * q [batch, n_q_heads, 128] (row stride q_row_stride elements per token),
+ * block_table [batch][table_stride] int32 (-1 padded, model_runner.py:231-236),
+ * context_lens [batch] int32, includes the token just written (:351);
+ * rows with context_len <= 0 (graph padding, :305) produce zeros.
+ * out [batch, n_q_heads*128] bf16. */
+int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride,
+                         const mi_bf16* k_cache, const mi_bf16* v_cache,
+                         const int32_t* block_table, int table_stride,
+                         const int32_t* context_lens,
+                         mi_bf16* out, void* workspace, size_t ws_bytes,
+                         int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                         int block_size, float scale, mi_stream stream);
+
+/* Prefill attention, stands in for npu_fused_infer_attention_score_v2 "TND"
+ * sparse_mode=3 (attention.py:47-59): per-sequence causal GQA attention.
+ * K/V are read back from the paged cache that mi_reshape_and_cache has just
+ * filled for this step (bit-identical to the step's k,v, since the scatter is a
+ * pure copy), through block_table [n_seqs][table_stride].
+ * q [T, n_q_heads, 128]; cu_seqlens_q [n_seqs+1] int32 (model_runner.py:254-258);
+ * kv_lens [n_seqs] int32 = tokens of each sequence present in the cache
+ * (== query length in the reference, which recomputes everything :248-249;
+ *  larger when a cached prefix is skipped).  Query token i of a sequence sits
+ * at position kv_len - q_len + i.  out [T, n_q_heads*128]. */
+int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride,
+                          const mi_bf16* k_cache, const mi_bf16* v_cache,
+                          const int32_t* block_table, int table_stride,
+                          const int32_t* cu_seqlens_q, const int32_t* kv_lens,
+                          int n_seqs, int max_seqlen_q,
+                          mi_bf16* out,
+                          int n_q_heads, int n_kv_heads, int head_dim,
+                          int block_size, float scale, mi_stream stream);
+
+/* ---- normalisation (reference: layers/layernorm.py) ----------------------- */
+/* RMSNorm.rms_forward (layernorm.py:16-25):
+ *   y = bf16( bf16(x32 * rsqrt(mean(x32^2)+eps)) * w )   — two roundings.
+ * x is [outer][inner][cols]; row (o,i) starts at x + o*x_outer_stride + i*cols
+ * (so the per-head q/k norm of qwen3.py:83-85 runs on strided views of qkv).
+ * y is contiguous [outer*inner][cols].  cols % 8 == 0, cols <= 8192. */
+int mi_rmsnorm(const mi_bf16* x, int64_t x_outer_stride, const mi_bf16* w,
+               mi_bf16* y, int outer, int inner, int cols, float eps,
+               mi_stream stream);
+
+/* RMSNorm.add_rms_forward (layernorm.py:27-38):
+ *   s = x32 + r32; residual_out = bf16(s); y = norm(s) as above (variance from
+ *   the un-rounded s).  x, residual, y, residual_out are contiguous [rows][cols];
+ *   y may alias x and residual_out may alias residual. */
+int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* w,
+                   mi_bf16* y, mi_bf16* residual_out, int rows, int cols,
+                   float eps, mi_stream stream);
+
+/* ---- rotary embedding (reference: layers/rotary_embedding.py) ------------- */
+/* RotaryEmbedding.forward (rotary_embedding.py:37-47), NeoX halves, fp32 math:
+ *   y1 = x1*cos - x2*sin ; y2 = x2*cos + x1*sin ; cast to bf16 (:6-14).
+ * cos_sin [max_pos][128] fp32 = cat(cos[64], sin[64]) (:29-35).
+ * positions [n_tokens] int64.  q/k rows: [n_tokens][n_heads][128], token stride
+ * given in elements; outputs are contiguous [n_tokens][n_heads][128]. */
+int mi_rope(const int64_t* positions, const float* cos_sin,
+            const mi_bf16* q, int64_t q_row_stride, int n_q_heads,
+            const mi_bf16* k, int64_t k_row_stride, int n_kv_heads,
+            mi_bf16* q_out, mi_bf16* k_out, int n_tokens, int head_dim,
+            mi_stream stream);
+
+/* Fused q_norm + k_norm + RoPE + KV scatter for one step (qwen3.py:79-88 +
+ * attention.py:22-35), reading the packed qkv row [q | k | v] of
+ * QKVParallelLinear (linear.py:117-126).  Rounding points are exactly those of
+ * the unfused sequence mi_rmsnorm -> mi_rope -> mi_reshape_and_cache /
+ * mi_scatter_update_kv, so results are bit-identical to it.
+ * q_w/k_w may be NULL (attention_bias=true models skip the norms, qwen3.py:70).
+ * slots: flat [n_tokens] if slot_is_2d == 0, else [n_tokens][2]. */
+int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride,
+                         const mi_bf16* q_w, const mi_bf16* k_w, float eps,
+                         const int64_t* positions, const float* cos_sin,
+                         mi_bf16* q_out, mi_bf16* k_cache, mi_bf16* v_cache,
+                         const int32_t* slots, int slot_is_2d,
+                         int n_tokens, int n_q_heads, int n_kv_heads,
+                         int head_dim, int block_size, mi_stream stream);
+
+/* ---- activation (reference: layers/activation.py:10-12) ------------------- */
+/* SiluAndMul: out[t][i] = bf16( bf16(silu(x[t][i])) * x[t][inter+i] ). */
+int mi_silu_mul(const mi_bf16* x, mi_bf16* out, int rows, int inter,
+                mi_stream stream);
+
+/* ---- linear (reference: layers/linear.py:51,73,150; embed_head.py:61) ----- */
+/* y[M][N] = x[M][K] @ w[N][K]^T (+ bias[N]); bf16 in, fp32 accumulate, one
+ * rounding to bf16.  Weight-streaming MFMA kernel for the decode regime:
+ * 1 <= M <= 64, K % 32 == 0 (K % 256 == 0 fastest), N % 16 == 0.
+ * x row stride = K, y row stride = N. */
+int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_bf16* bias,
+                        mi_bf16* y, int M, int N, int K, mi_stream stream);
+
+/* ---- embedding / head (reference: layers/embed_head.py) ------------------- */
+/* VocabParallelEmbedding.forward (embed_head.py:34-42): out[t] = w[ids[t]-vocab_start]
+ * if vocab_start <= ids[t] < vocab_start+vocab_local else 0 (TP mask). */
+int mi_embedding(const int64_t* ids, const mi_bf16* w, mi_bf16* out,
+                 int n_tokens, int hidden, int64_t vocab_start, int64_t vocab_local,
+                 mi_stream stream);
+
+/* ParallelLMHead last-token select in prefill (embed_head.py:58-60):
+ * out[s] = x[cu_seqlens_q[s+1]-1]. */
+int mi_gather_last_tokens(const mi_bf16* x, const int32_t* cu_seqlens_q,
+                          mi_bf16* out, int n_seqs, int hidden, mi_stream stream);
+
+/* ---- sampling (reference: layers/sampler.py:9-17) ------------------------- */
+/* Greedy token = lowest index of the row maximum of logits[rows][vocab] (the
+ * deterministic path BASELINE config 1 needs; the reference itself only has
+ * multinomial sampling).  out [rows] int64. */
+int mi_argmax(const mi_bf16* logits, int64_t row_stride, int64_t* out,
+              int rows, int vocab, mi_stream stream);
+
+/* Sampler.forward: sample from softmax(logits.float()/temperature) per row via
+ * the Gumbel-max identity with a counter-based generator keyed by
+ * (seed, step, row, column).  temperatures [rows] fp32; rows whose temperature
+ * is <= 0 are greedy.  out [rows] int64. */
+int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatures,
+              int64_t* out, int rows, int vocab, uint64_t seed, uint64_t step,
+              mi_stream stream);
+
+/* ---- host-side hashing (reference: engine/block_manager.py:38-44) --------- */
+/* xxh64 of `len` bytes with seed 0, optionally prefixed by the 8 little-endian
+ * bytes of `prefix` (has_prefix != 0) — the chained block hash of
+ * BlockManager.compute_hash.  The reference calls the third-party `xxhash`
+ * package (pyproject.toml:17, unpinned); this is XXH64 as published. */
+uint64_t mi_xxh64_chain(const void* data, size_t len, int has_prefix, uint64_t prefix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_NANOVLLM_H */

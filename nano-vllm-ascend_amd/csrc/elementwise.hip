@@ -1,0 +1,593 @@
+// Elementwise / gather / scatter kernels of the decode path for gfx950.
+// All of them are HBM- or latency-bound: 16-byte vector accesses, one rounding
+// point per reference rounding point (compiled with -ffp-contract=off so the
+// fp32 sequences match the reference's unfused torch ops bit for bit).
+#include "mi_common.hpp"
+
+namespace mi {
+
+// ---------------------------------------------------------------------------
+// RMSNorm / add+RMSNorm   (reference: layers/layernorm.py:16-38)
+//   LPR lanes cooperate on one row, each holding VPL vectors of 8 bf16.
+// ---------------------------------------------------------------------------
+template <int LPR, int VPL, bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(
+    const uint16_t* __restrict__ x, int64_t x_outer_stride, int inner,
+    const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
+    uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out,
+    int rows, int cols, float eps) {
+  constexpr int ROWS_PER_WAVE = WAVE / LPR;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int row = wave * ROWS_PER_WAVE + lane / LPR;
+  const int sub = lane % LPR;
+  const bool active = row < rows;
+  const int nvec = cols >> 3;
+
+  const int64_t xoff = active ? (int64_t)(row / inner) * x_outer_stride + (int64_t)(row % inner) * cols : 0;
+  const int64_t yoff = (int64_t)row * cols;
+
+  float v[VPL][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vec = sub + i * LPR;
+    if (active && vec < nvec) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + xoff + vec * 8);
+      u32x4 rr = {0, 0, 0, 0};
+      if (ADD) rr = *reinterpret_cast<const u32x4*>(residual + yoff + vec * 8);
+      u32x4 ro;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = lo_bf(raw[j]), b = hi_bf(raw[j]);
+        if (ADD) {
+          a = a + lo_bf(rr[j]);
+          b = b + hi_bf(rr[j]);
+          ro[j] = pack_bf(a, b);
+        }
+        v[i][2 * j] = a;
+        v[i][2 * j + 1] = b;
+        ss += a * a;
+        ss += b * b;
+      }
+      if (ADD) *reinterpret_cast<u32x4*>(residual_out + yoff + vec * 8) = ro;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rs = 1.0f / sqrtf(ss / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vec = sub + i * LPR;
+    if (active && vec < nvec) {
+      const u32x4 wr = *reinterpret_cast<const u32x4*>(w + vec * 8);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = rbf(v[i][2 * j] * rs) * lo_bf(wr[j]);
+        const float b = rbf(v[i][2 * j + 1] * rs) * hi_bf(wr[j]);
+        o[j] = pack_bf(a, b);
+      }
+      *reinterpret_cast<u32x4*>(y + yoff + vec * 8) = o;
+    }
+  }
+}
+
+template <bool ADD>
+static int launch_rmsnorm(const uint16_t* x, int64_t xs, int inner, const uint16_t* r,
+                          const uint16_t* w, uint16_t* y, uint16_t* ro, int rows, int cols,
+                          float eps, hipStream_t st) {
+  const int nvec = cols / 8;
+  auto go = [&](auto lpr_c, auto vpl_c) {
+    constexpr int LPR = decltype(lpr_c)::value, VPL = decltype(vpl_c)::value;
+    const int rows_per_block = (256 / 64) * (64 / LPR);
+    const int grid = (rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL((rmsnorm_kernel<LPR, VPL, ADD>), dim3(grid), dim3(256), 0, st, x, xs, inner, r, w,
+                       y, ro, rows, cols, eps);
+  };
+  using std::integral_constant;
+  if (nvec <= 8) go(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+  else if (nvec <= 16) go(integral_constant<int, 16>{}, integral_constant<int, 1>{});
+  else if (nvec <= 32) go(integral_constant<int, 32>{}, integral_constant<int, 1>{});
+  else if (nvec <= 64) go(integral_constant<int, 64>{}, integral_constant<int, 1>{});
+  else if (nvec <= 128) go(integral_constant<int, 64>{}, integral_constant<int, 2>{});
+  else if (nvec <= 256) go(integral_constant<int, 64>{}, integral_constant<int, 4>{});
+  else if (nvec <= 512) go(integral_constant<int, 64>{}, integral_constant<int, 8>{});
+  else if (nvec <= 1024) go(integral_constant<int, 64>{}, integral_constant<int, 16>{});
+  else return MI_EUNSUPPORTED;
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// q/k norm + RoPE + KV scatter: 8 lanes per (token, head); lane j owns
+// d = 8j..8j+7 and d = 64+8j..64+8j+7, i.e. the NeoX rotation pairs are in-lane
+// and each half is one 16-byte chunk of the fragment-native K tile.
+// ---------------------------------------------------------------------------
+struct HeadSlot {
+  int token, head, kind;  // kind 0 = q, 1 = k, 2 = v
+};
+
+__device__ __forceinline__ void load16(const uint16_t* p, float (&f)[8]) {
+  const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = lo_bf(raw[j]);
+    f[2 * j + 1] = hi_bf(raw[j]);
+  }
+}
+__device__ __forceinline__ u32x4 pack16(const float (&f)[8]) {
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack_bf(f[2 * j], f[2 * j + 1]);
+  return o;
+}
+
+// rms-normalise the 128 values held by 8 lanes (16 each) with weight w
+__device__ __forceinline__ void head_rmsnorm(float (&a)[8], float (&b)[8], const uint16_t* w, int j,
+                                             float eps) {
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss += b[i] * b[i];
+  ss += __shfl_xor(ss, 1, 64);
+  ss += __shfl_xor(ss, 2, 64);
+  ss += __shfl_xor(ss, 4, 64);
+  const float rs = 1.0f / sqrtf(ss / 128.0f + eps);
+  float wa[8], wb[8];
+  load16(w + 8 * j, wa);
+  load16(w + 64 + 8 * j, wb);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = rbf(rbf(a[i] * rs) * wa[i]);
+    b[i] = rbf(rbf(b[i] * rs) * wb[i]);
+  }
+}
+
+// NeoX rotation in fp32 (rotary_embedding.py:6-14): separate mul / sub / add
+__device__ __forceinline__ void head_rope(float (&a)[8], float (&b)[8], const float* cs, int j) {
+  const float4 c0 = *reinterpret_cast<const float4*>(cs + 8 * j);
+  const float4 c1 = *reinterpret_cast<const float4*>(cs + 8 * j + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(cs + 64 + 8 * j);
+  const float4 s1 = *reinterpret_cast<const float4*>(cs + 64 + 8 * j + 4);
+  const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x1 = a[i], x2 = b[i];
+    a[i] = rbf(x1 * c[i] - x2 * s[i]);
+    b[i] = rbf(x2 * c[i] + x1 * s[i]);
+  }
+}
+
+__device__ __forceinline__ bool resolve_slot(const int32_t* slots, int slot_is_2d, int token,
+                                             int block_size, int64_t& blk, int& off) {
+  if (slot_is_2d) {
+    blk = slots[2 * token];
+    off = slots[2 * token + 1];
+    return blk >= 0 && off >= 0;
+  }
+  const int32_t s = slots[token];
+  if (s < 0) return false;
+  blk = s / block_size;
+  off = s % block_size;
+  return true;
+}
+
+__device__ __forceinline__ void store_k_head(uint16_t* k_cache, int64_t blk, int off, int h, int j,
+                                             const float (&a)[8], const float (&b)[8], int n_kv_heads,
+                                             int tpb) {
+  uint16_t* tile = k_cache + kv_tile_base(blk, h, off, n_kv_heads, tpb);
+  const int t = off & 15;
+  // chunk j: d = 8j ; chunk j+8: d = 64 + 8j
+  *reinterpret_cast<u32x4*>(tile + k_tile_off(t, 8 * j)) = pack16(a);
+  *reinterpret_cast<u32x4*>(tile + k_tile_off(t, 64 + 8 * j)) = pack16(b);
+}
+__device__ __forceinline__ void store_v_head(uint16_t* v_cache, int64_t blk, int off, int h, int j,
+                                             const float (&a)[8], const float (&b)[8], int n_kv_heads,
+                                             int tpb) {
+  uint16_t* tile = v_cache + kv_tile_base(blk, h, off, n_kv_heads, tpb);
+  const int t = off & 15;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    tile[v_tile_off(t, 8 * j + i)] = f2bf(a[i]);
+    tile[v_tile_off(t, 64 + 8 * j + i)] = f2bf(b[i]);
+  }
+}
+
+// MODE 0: fused norm+rope+store from packed qkv
+// MODE 1: rope only (q,k separate inputs -> contiguous outputs)
+// MODE 2: store only (k,v separate inputs -> caches)
+template <int MODE>
+__global__ __launch_bounds__(256) void qk_rope_store_kernel(
+    const uint16_t* __restrict__ qsrc, int64_t q_stride, const uint16_t* __restrict__ ksrc,
+    int64_t k_stride, const uint16_t* __restrict__ vsrc, int64_t v_stride,
+    const uint16_t* __restrict__ q_w, const uint16_t* __restrict__ k_w, float eps,
+    const int64_t* __restrict__ positions, const float* __restrict__ cos_sin,
+    uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_out, uint16_t* __restrict__ k_cache,
+    uint16_t* __restrict__ v_cache, const int32_t* __restrict__ slots, int slot_is_2d, int n_tokens,
+    int n_q_heads, int n_kv_heads, int block_size) {
+  const int heads_per_token = MODE == 0 ? n_q_heads + 2 * n_kv_heads
+                              : MODE == 1 ? n_q_heads + n_kv_heads
+                                          : 2 * n_kv_heads;
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;  // (token, head) slot
+  const int j = threadIdx.x & 7;
+  const bool active = gid < (int64_t)n_tokens * heads_per_token;
+  const int token = active ? (int)(gid / heads_per_token) : 0;
+  int hh = active ? (int)(gid % heads_per_token) : 0;
+  int kind;  // 0 q, 1 k, 2 v
+  if (MODE == 2) {
+    kind = hh < n_kv_heads ? 1 : 2;
+    if (kind == 2) hh -= n_kv_heads;
+  } else {
+    kind = hh < n_q_heads ? 0 : (hh < n_q_heads + n_kv_heads ? 1 : 2);
+    if (kind == 1) hh -= n_q_heads;
+    if (kind == 2) hh -= n_q_heads + n_kv_heads;
+  }
+  const uint16_t* src = kind == 0 ? qsrc + token * q_stride
+                        : kind == 1 ? ksrc + token * k_stride
+                                    : vsrc + token * v_stride;
+  src += hh * 128;
+  float a[8], b[8];
+  if (active) {
+    load16(src + 8 * j, a);
+    load16(src + 64 + 8 * j, b);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = b[i] = 0.f;
+  }
+  if (MODE == 0 && kind != 2) {
+    const uint16_t* w = kind == 0 ? q_w : k_w;
+    if (w != nullptr) head_rmsnorm(a, b, w, j, eps);  // shuffles: all 8 lanes of the group run it
+  }
+  if (MODE != 2 && kind != 2 && active) {
+    const int64_t pos = positions[token];
+    head_rope(a, b, cos_sin + pos * 128, j);
+  }
+  if (!active) return;
+  if (MODE != 2 && kind == 0) {
+    uint16_t* dst = q_out + ((int64_t)token * n_q_heads + hh) * 128;
+    *reinterpret_cast<u32x4*>(dst + 8 * j) = pack16(a);
+    *reinterpret_cast<u32x4*>(dst + 64 + 8 * j) = pack16(b);
+    return;
+  }
+  if (MODE == 1) {  // k -> contiguous output
+    uint16_t* dst = k_out + ((int64_t)token * n_kv_heads + hh) * 128;
+    *reinterpret_cast<u32x4*>(dst + 8 * j) = pack16(a);
+    *reinterpret_cast<u32x4*>(dst + 64 + 8 * j) = pack16(b);
+    return;
+  }
+  int64_t blk;
+  int off;
+  if (!resolve_slot(slots, slot_is_2d, token, block_size, blk, off)) return;
+  const int tpb = block_size >> 4;
+  if (kind == 1) store_k_head(k_cache, blk, off, hh, j, a, b, n_kv_heads, tpb);
+  else store_v_head(v_cache, blk, off, hh, j, a, b, n_kv_heads, tpb);
+}
+
+// inverse of the scatter, for content checks: out[i][h*128+d] = cache[slot_flat[i]][h][d]
+__global__ __launch_bounds__(256) void kv_gather_kernel(const uint16_t* __restrict__ cache, int is_v,
+                                                        const int32_t* __restrict__ slot_flat, int n,
+                                                        uint16_t* __restrict__ out, int n_kv_heads,
+                                                        int block_size) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n * n_kv_heads * 128;
+  if (idx >= total) return;
+  const int d = idx & 127;
+  const int h = (idx >> 7) % n_kv_heads;
+  const int i = idx / (128 * n_kv_heads);
+  const int32_t s = slot_flat[i];
+  if (s < 0) {
+    out[idx] = 0;
+    return;
+  }
+  const int64_t blk = s / block_size;
+  const int off = s % block_size;
+  const uint16_t* tile = cache + kv_tile_base(blk, h, off, n_kv_heads, block_size >> 4);
+  out[idx] = tile[is_v ? v_tile_off(off & 15, d) : k_tile_off(off & 15, d)];
+}
+
+// ---------------------------------------------------------------------------
+// SiluAndMul (activation.py:10-12): bf16(bf16(silu(x)) * y)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x,
+                                                       uint16_t* __restrict__ out, int rows, int inter) {
+  const int64_t vec = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int vpr = inter >> 3;
+  if (vec >= (int64_t)rows * vpr) return;
+  const int r = vec / vpr, c = (vec % vpr) * 8;
+  float g[8], u[8];
+  load16(x + (int64_t)r * 2 * inter + c, g);
+  load16(x + (int64_t)r * 2 * inter + inter + c, u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float s = g[i] / (1.0f + expf(-g[i]));
+    g[i] = rbf(s) * u[i];
+  }
+  *reinterpret_cast<u32x4*>(out + (int64_t)r * inter + c) = pack16(g);
+}
+
+// ---------------------------------------------------------------------------
+// Row gathers: embedding (embed_head.py:34-42) and last-token select (:58-60)
+// ---------------------------------------------------------------------------
+template <bool FROM_CU>
+__global__ __launch_bounds__(256) void row_gather_kernel(const int64_t* __restrict__ ids,
+                                                         const int32_t* __restrict__ cu,
+                                                         const uint16_t* __restrict__ w,
+                                                         uint16_t* __restrict__ out, int n, int hidden,
+                                                         int64_t vocab_start, int64_t vocab_local) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= n) return;
+  int64_t src;
+  bool valid = true;
+  if (FROM_CU) {
+    src = (int64_t)cu[row + 1] - 1;
+  } else {
+    src = ids[row] - vocab_start;
+    valid = src >= 0 && src < vocab_local;
+  }
+  const int nvec = hidden >> 3;
+  for (int v = lane; v < nvec; v += 64) {
+    u32x4 val = {0, 0, 0, 0};
+    if (valid) val = *reinterpret_cast<const u32x4*>(w + src * hidden + v * 8);
+    *reinterpret_cast<u32x4*>(out + (int64_t)row * hidden + v * 8) = val;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// argmax / Gumbel-max sampling over [rows][vocab] bf16 logits (sampler.py:9-17)
+// one 1024-thread workgroup per row; key = (value, lowest index)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(1024) void pick_kernel(const uint16_t* __restrict__ logits,
+                                                    int64_t row_stride,
+                                                    const float* __restrict__ temperatures,
+                                                    int64_t* __restrict__ out, int vocab, uint64_t seed,
+                                                    uint64_t step) {
+  const int row = blockIdx.x;
+  const uint16_t* p = logits + (int64_t)row * row_stride;
+  float inv_t = 1.0f;
+  bool noisy = false;
+  if (SAMPLE) {
+    const float t = temperatures[row];
+    noisy = t > 0.f;
+    inv_t = noisy ? 1.0f / t : 1.0f;
+  }
+  const uint64_t rkey = seed * 0x9e3779b97f4a7c15ull + step * 0xd1342543de82ef95ull + (uint64_t)row * 0x2545f4914f6cdd1dull;
+  float best = -INFINITY;
+  int best_i = 0x7fffffff;
+  const int nvec = vocab >> 3;
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+    float f[8];
+    load16(p + v * 8, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float key = f[i];
+      const int col = v * 8 + i;
+      if (SAMPLE && noisy) {
+        // u in (0,1): 24 random bits, never 0 or 1
+        const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        key = key * inv_t - logf(-logf(u));
+      }
+      if (key > best || (key == best && col < best_i)) {
+        best = key;
+        best_i = col;
+      }
+    }
+  }
+  for (int col = (nvec << 3) + threadIdx.x; col < vocab; col += blockDim.x) {  // tail
+    float key = bf2f(p[col]);
+    if (SAMPLE && noisy) {
+      const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      key = key * inv_t - logf(-logf(u));
+    }
+    if (key > best || (key == best && col < best_i)) {
+      best = key;
+      best_i = col;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (ob > best || (ob == best && oi < best_i)) {
+      best = ob;
+      best_i = oi;
+    }
+  }
+  __shared__ float sb[16];
+  __shared__ int si[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sb[wave] = best;
+    si[wave] = best_i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    for (int wv = 1; wv < nw; ++wv)
+      if (sb[wv] > best || (sb[wv] == best && si[wv] < best_i)) {
+        best = sb[wv];
+        best_i = si[wv];
+      }
+    out[row] = best_i == 0x7fffffff ? 0 : best_i;
+  }
+}
+
+}  // namespace mi
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace mi;
+
+extern "C" int mi_rmsnorm(const mi_bf16* x, int64_t x_outer_stride, const mi_bf16* w, mi_bf16* y,
+                          int outer, int inner, int cols, float eps, mi_stream stream) {
+  if (!x || !w || !y || outer < 0 || inner <= 0 || cols <= 0) return MI_EINVAL;
+  if (cols % 8 != 0 || x_outer_stride % 8 != 0) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return MI_EINVAL;
+  if (outer == 0) return MI_OK;
+  return launch_rmsnorm<false>(x, x_outer_stride, inner, nullptr, w, y, nullptr, outer * inner, cols, eps,
+                               S(stream));
+}
+
+extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* w, mi_bf16* y,
+                              mi_bf16* residual_out, int rows, int cols, float eps, mi_stream stream) {
+  if (!x || !residual || !w || !y || !residual_out || rows < 0 || cols <= 0) return MI_EINVAL;
+  if (cols % 8 != 0) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
+    return MI_EINVAL;
+  if (rows == 0) return MI_OK;
+  return launch_rmsnorm<true>(x, (int64_t)cols, 1, residual, w, y, residual_out, rows, cols, eps, S(stream));
+}
+
+static int heads_grid(int64_t head_slots) { return (int)((head_slots * 8 + 255) / 256); }
+
+extern "C" int mi_rope(const int64_t* positions, const float* cos_sin, const mi_bf16* q,
+                       int64_t q_row_stride, int n_q_heads, const mi_bf16* k, int64_t k_row_stride,
+                       int n_kv_heads, mi_bf16* q_out, mi_bf16* k_out, int n_tokens, int head_dim,
+                       mi_stream stream) {
+  if (!positions || !cos_sin || !q || !k || !q_out || !k_out || n_tokens < 0) return MI_EINVAL;
+  if (head_dim != MI_HEAD_DIM || q_row_stride % 8 || k_row_stride % 8) return MI_EUNSUPPORTED;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(q_out) || !aligned16(k_out) || !aligned16(cos_sin))
+    return MI_EINVAL;
+  if (n_tokens == 0) return MI_OK;
+  const int64_t slots = (int64_t)n_tokens * (n_q_heads + n_kv_heads);
+  hipLaunchKernelGGL((qk_rope_store_kernel<1>), dim3(heads_grid(slots)), dim3(256), 0, S(stream), q,
+                     q_row_stride, k, k_row_stride, nullptr, (int64_t)0, nullptr, nullptr, 0.f, positions,
+                     cos_sin, q_out, k_out, nullptr, nullptr, nullptr, 0, n_tokens, n_q_heads, n_kv_heads,
+                     16);
+  return check_launch();
+}
+
+static int store_common(const mi_bf16* k, const mi_bf16* v, int64_t ks, int64_t vs, mi_bf16* kc,
+                        mi_bf16* vc, const int32_t* slots, int is2d, int n, int n_kv_heads, int head_dim,
+                        int block_size, mi_stream stream) {
+  if (!k || !v || !kc || !vc || !slots || n < 0 || n_kv_heads <= 0) return MI_EINVAL;
+  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16 || ks % 8 || vs % 8)
+    return MI_EUNSUPPORTED;
+  if (!aligned16(k) || !aligned16(v) || !aligned16(kc) || !aligned16(vc)) return MI_EINVAL;
+  if (n == 0) return MI_OK;
+  const int64_t hs = (int64_t)n * 2 * n_kv_heads;
+  hipLaunchKernelGGL((qk_rope_store_kernel<2>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), nullptr,
+                     (int64_t)0, k, ks, v, vs, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, kc,
+                     vc, slots, is2d, n, 0, n_kv_heads, block_size);
+  return check_launch();
+}
+
+extern "C" int mi_reshape_and_cache(const mi_bf16* k, const mi_bf16* v, int64_t k_row_stride,
+                                    int64_t v_row_stride, mi_bf16* k_cache, mi_bf16* v_cache,
+                                    const int32_t* slot_flat, int n_tokens, int n_kv_heads, int head_dim,
+                                    int block_size, mi_stream stream) {
+  return store_common(k, v, k_row_stride, v_row_stride, k_cache, v_cache, slot_flat, 0, n_tokens, n_kv_heads,
+                      head_dim, block_size, stream);
+}
+
+extern "C" int mi_scatter_update_kv(const mi_bf16* k, const mi_bf16* v, int64_t k_row_stride,
+                                    int64_t v_row_stride, mi_bf16* k_cache, mi_bf16* v_cache,
+                                    const int32_t* slot_2d, int batch, int n_kv_heads, int head_dim,
+                                    int block_size, mi_stream stream) {
+  return store_common(k, v, k_row_stride, v_row_stride, k_cache, v_cache, slot_2d, 1, batch, n_kv_heads,
+                      head_dim, block_size, stream);
+}
+
+extern "C" int mi_kv_cache_gather(const mi_bf16* cache, int is_v, const int32_t* slot_flat, int n,
+                                  mi_bf16* out, int n_kv_heads, int head_dim, int block_size,
+                                  mi_stream stream) {
+  if (!cache || !slot_flat || !out || n < 0 || n_kv_heads <= 0) return MI_EINVAL;
+  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16) return MI_EUNSUPPORTED;
+  if (n == 0) return MI_OK;
+  const int64_t total = (int64_t)n * n_kv_heads * 128;
+  hipLaunchKernelGGL(kv_gather_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, S(stream), cache, is_v,
+                     slot_flat, n, out, n_kv_heads, block_size);
+  return check_launch();
+}
+
+extern "C" int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w,
+                                    const mi_bf16* k_w, float eps, const int64_t* positions,
+                                    const float* cos_sin, mi_bf16* q_out, mi_bf16* k_cache, mi_bf16* v_cache,
+                                    const int32_t* slots, int slot_is_2d, int n_tokens, int n_q_heads,
+                                    int n_kv_heads, int head_dim, int block_size, mi_stream stream) {
+  if (!qkv || !positions || !cos_sin || !q_out || !k_cache || !v_cache || !slots || n_tokens < 0)
+    return MI_EINVAL;
+  if ((q_w == nullptr) != (k_w == nullptr)) return MI_EINVAL;
+  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16 || qkv_row_stride % 8)
+    return MI_EUNSUPPORTED;
+  if (!aligned16(qkv) || !aligned16(q_out) || !aligned16(k_cache) || !aligned16(v_cache) ||
+      !aligned16(cos_sin) || (q_w && (!aligned16(q_w) || !aligned16(k_w))))
+    return MI_EINVAL;
+  if (n_tokens == 0) return MI_OK;
+  const int64_t hs = (int64_t)n_tokens * (n_q_heads + 2 * n_kv_heads);
+  const mi_bf16* ksrc = qkv + (int64_t)n_q_heads * 128;
+  const mi_bf16* vsrc = ksrc + (int64_t)n_kv_heads * 128;
+  hipLaunchKernelGGL((qk_rope_store_kernel<0>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), qkv,
+                     qkv_row_stride, ksrc, qkv_row_stride, vsrc, qkv_row_stride, q_w, k_w, eps, positions,
+                     cos_sin, q_out, nullptr, k_cache, v_cache, slots, slot_is_2d, n_tokens, n_q_heads,
+                     n_kv_heads, block_size);
+  return check_launch();
+}
+
+extern "C" int mi_silu_mul(const mi_bf16* x, mi_bf16* out, int rows, int inter, mi_stream stream) {
+  if (!x || !out || rows < 0 || inter <= 0) return MI_EINVAL;
+  if (inter % 8) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(out)) return MI_EINVAL;
+  if (rows == 0) return MI_OK;
+  const int64_t nvec = (int64_t)rows * (inter / 8);
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((int)((nvec + 255) / 256)), dim3(256), 0, S(stream), x, out, rows,
+                     inter);
+  return check_launch();
+}
+
+extern "C" int mi_embedding(const int64_t* ids, const mi_bf16* w, mi_bf16* out, int n_tokens, int hidden,
+                            int64_t vocab_start, int64_t vocab_local, mi_stream stream) {
+  if (!ids || !w || !out || n_tokens < 0 || hidden <= 0) return MI_EINVAL;
+  if (hidden % 8) return MI_EUNSUPPORTED;
+  if (!aligned16(w) || !aligned16(out)) return MI_EINVAL;
+  if (n_tokens == 0) return MI_OK;
+  hipLaunchKernelGGL((row_gather_kernel<false>), dim3((n_tokens + 3) / 4), dim3(256), 0, S(stream), ids,
+                     nullptr, w, out, n_tokens, hidden, vocab_start, vocab_local);
+  return check_launch();
+}
+
+extern "C" int mi_gather_last_tokens(const mi_bf16* x, const int32_t* cu_seqlens_q, mi_bf16* out, int n_seqs,
+                                     int hidden, mi_stream stream) {
+  if (!x || !cu_seqlens_q || !out || n_seqs < 0 || hidden <= 0) return MI_EINVAL;
+  if (hidden % 8) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(out)) return MI_EINVAL;
+  if (n_seqs == 0) return MI_OK;
+  hipLaunchKernelGGL((row_gather_kernel<true>), dim3((n_seqs + 3) / 4), dim3(256), 0, S(stream), nullptr,
+                     cu_seqlens_q, x, out, n_seqs, hidden, (int64_t)0, (int64_t)0);
+  return check_launch();
+}
+
+extern "C" int mi_argmax(const mi_bf16* logits, int64_t row_stride, int64_t* out, int rows, int vocab,
+                         mi_stream stream) {
+  if (!logits || !out || rows < 0 || vocab <= 0) return MI_EINVAL;
+  if (row_stride % 8 || !aligned16(logits)) return MI_EUNSUPPORTED;
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL((pick_kernel<false>), dim3(rows), dim3(1024), 0, S(stream), logits, row_stride, nullptr,
+                     out, vocab, 0ull, 0ull);
+  return check_launch();
+}
+
+extern "C" int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatures, int64_t* out,
+                         int rows, int vocab, uint64_t seed, uint64_t step, mi_stream stream) {
+  if (!logits || !temperatures || !out || rows < 0 || vocab <= 0) return MI_EINVAL;
+  if (row_stride % 8 || !aligned16(logits)) return MI_EUNSUPPORTED;
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL((pick_kernel<true>), dim3(rows), dim3(1024), 0, S(stream), logits, row_stride,
+                     temperatures, out, vocab, seed, step);
+  return check_launch();
+}

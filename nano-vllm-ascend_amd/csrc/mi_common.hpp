@@ -1,0 +1,68 @@
+// Shared device/host helpers for the gfx950 kernels of libmi355_nanovllm.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mi355_nanovllm.h"
+
+namespace mi {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA 16x16x32 A/B fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // one MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> f32, round-to-nearest-even (same rule as c10::BFloat16) ------
+__device__ __forceinline__ float bf2f(uint16_t h) {
+  return __uint_as_float(static_cast<uint32_t>(h) << 16);
+}
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
+  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+}
+// round a float to the nearest bf16 and return it as float
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ---- wave-level reductions (64 lanes) --------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- fragment-native KV tile addressing (see include/mi355_nanovllm.h) -----
+// element offset of (t, d) inside a 16-token x 128-dim K tile
+__host__ __device__ __forceinline__ int k_tile_off(int t, int d) {
+  return (d >> 5) * 512 + ((((d >> 3) & 3) * 16 + t) << 3) + (d & 7);
+}
+// element offset of (t, d) inside a V tile (token-transposed)
+__host__ __device__ __forceinline__ int v_tile_off(int t, int d) {
+  return (d >> 5) * 512 + ((((t >> 2) * 16) + (d & 15)) << 3) + (((d >> 4) & 1) << 2) + (t & 3);
+}
+// element offset of the tile holding `slot_in_block` of kv head `h` in block `blk`
+__host__ __device__ __forceinline__ int64_t kv_tile_base(int64_t blk, int h, int slot_in_block,
+                                                         int n_kv_heads, int tiles_per_block) {
+  return ((blk * n_kv_heads + h) * tiles_per_block + (slot_in_block >> 4)) * (int64_t)MI_KV_TILE_ELEMS;
+}
+
+// ---- host-side launch bookkeeping ------------------------------------------
+int check_launch();          // returns MI_OK or MI_ELAUNCH (records hipGetLastError text)
+inline hipStream_t S(mi_stream s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace mi

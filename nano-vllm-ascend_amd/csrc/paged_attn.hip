@@ -1,0 +1,360 @@
+// Paged GQA attention for gfx950 over the fragment-native KV cache.
+//
+// One wavefront attends one 32-token chunk (two 16-token cache tiles) at a time:
+//   * 16 fully coalesced 1 KiB loads bring the chunk's K and V tiles straight
+//     into VGPRs as MFMA operand fragments (the cache layout is the fragment
+//     layout, include/mi355_nanovllm.h) - no LDS staging, no transposes;
+//   * S^T = K . Q^T on v_mfma_f32_16x16x32_bf16 with tokens on the M axis and the
+//     16 "query columns" of the wave on the N axis (decode: the G q-heads of one
+//     kv head; prefill: 16/G consecutive query tokens x G heads), fp32 scores;
+//   * wavefront-level online softmax in fp32: a column's 32 scores live in 8
+//     registers of 4 lanes, so max/sum need two cross-lane steps;
+//   * O^T += V^T . P on the same MFMA shape; the contraction index is a token
+//     slot, and because any slot order is legal as long as V and P agree, the
+//     score registers feed the P operand without moving between lanes.  P is
+//     split into bf16 hi + lo parts (two MFMAs) so the probabilities keep ~16
+//     significant bits - the matrix cores are >90 % idle in this HBM-bound
+//     kernel, the extra MFMA is free and keeps the result within fp32-softmax
+//     accuracy of the oracle.
+// Decode splits each sequence's context over `nsplit` workgroups (flash-decoding)
+// whose ranges are derived on the device from context_lens, so the launch
+// geometry is static and hipGraph-capturable; a second kernel merges the splits.
+#include "mi_common.hpp"
+
+namespace mi {
+
+__device__ __forceinline__ void load_tile(const uint16_t* __restrict__ tile, int lane, u32x4 (&f)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4*>(tile + i * 512 + lane * 8);
+}
+__device__ __forceinline__ void zero_tile(u32x4 (&f)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = u32x4{0, 0, 0, 0};
+}
+
+// Attend one chunk.  `limit`: tokens with index < limit are visible to this lane's column.
+__device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
+                                             const u32x4 (&V0)[4], const u32x4 (&V1)[4],
+                                             const bf16x8 (&Q)[4], int tok0, int limit, float scale_log2e,
+                                             int g, float& m, float& l, f32x4 (&acc)[8]) {
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K0[kk]), Q[kk], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K1[kk]), Q[kk], s1, 0, 0, 0);
+  }
+  float p[8];
+  const int t0 = tok0 + 4 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p[r] = (t0 + r < limit) ? s0[r] * scale_log2e : -INFINITY;
+    p[4 + r] = (t0 + 16 + r < limit) ? s1[r] * scale_log2e : -INFINITY;
+  }
+  float mc = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+  mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+  mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+  const float mn = fmaxf(m, mc);
+  const bool dead = mn == -INFINITY;  // nothing visible for this column yet
+  const float alpha = dead ? 1.0f : exp2f(m - mn);
+  const float ms = dead ? 0.0f : mn;
+  float ps = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    p[i] = exp2f(p[i] - ms);
+    ps += p[i];
+  }
+  l = l * alpha + ps;
+  m = mn;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+  u32x4 ph, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float h0 = rbf(p[2 * i]), h1 = rbf(p[2 * i + 1]);
+    ph[i] = (__float_as_uint(h0) >> 16) | (__float_as_uint(h1) & 0xffff0000u);
+    pl[i] = pack_bf(p[2 * i] - h0, p[2 * i + 1] - h1);
+  }
+  const bf16x8 Ph = as_frag(ph), Pl = as_frag(pl);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int jp = j >> 1, hf = (j & 1) * 2;
+    const u32x4 a = {V0[jp][hf], V0[jp][hf + 1], V1[jp][hf], V1[jp][hf + 1]};
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Ph, acc[j], 0, 0, 0);
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Pl, acc[j], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void load_chunk(const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+                                           const int32_t* __restrict__ table_row, int c, int n_tiles, int h,
+                                           int n_kv_heads, int tpb, int lane, u32x4 (&K0)[4], u32x4 (&K1)[4],
+                                           u32x4 (&V0)[4], u32x4 (&V1)[4]) {
+  const int tile0 = 2 * c, tile1 = 2 * c + 1;
+  const int blk0 = __builtin_amdgcn_readfirstlane(table_row[tile0 / tpb]);
+  const int64_t base0 = (((int64_t)blk0 * n_kv_heads + h) * tpb + (tile0 % tpb)) * MI_KV_TILE_ELEMS;
+  load_tile(kc + base0, lane, K0);
+  load_tile(vc + base0, lane, V0);
+  if (tile1 < n_tiles) {
+    const int blk1 = __builtin_amdgcn_readfirstlane(table_row[tile1 / tpb]);
+    const int64_t base1 = (((int64_t)blk1 * n_kv_heads + h) * tpb + (tile1 % tpb)) * MI_KV_TILE_ELEMS;
+    load_tile(kc + base1, lane, K1);
+    load_tile(vc + base1, lane, V1);
+  } else {
+    zero_tile(K1);
+    zero_tile(V1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// decode: grid (nsplit, n_kv_heads, batch), 4 waves
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void paged_attn_decode_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
+    const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
+    const int32_t* __restrict__ ctx_lens, float* __restrict__ part_o, float* __restrict__ part_ml,
+    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) float sm_o[4][G][128];
+  __shared__ float sm_m[4][16];
+  __shared__ float sm_l[4][16];
+
+  const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int ctx = max(ctx_lens[b], 0);
+  const int n_chunks = (ctx + 31) >> 5, n_tiles = (ctx + 15) >> 4;
+  const int cps = (n_chunks + nsplit - 1) / nsplit;
+  const int c0 = split * cps, c1 = min(n_chunks, c0 + cps);
+
+  bf16x8 Q[4];
+  {
+    const uint16_t* qp = q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 v = {0, 0, 0, 0};
+      if (n < G && c0 < c1) v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);
+      Q[kk] = as_frag(v);
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* table_row = block_table + (int64_t)b * table_stride;
+  for (int c = c0 + wave; c < c1; c += 4) {
+    u32x4 K0[4], K1[4], V0[4], V1[4];
+    load_chunk(kc, vc, table_row, c, n_tiles, h, n_kv_heads, tpb, lane, K0, K1, V0, V1);
+    attend_chunk(K0, K1, V0, V1, Q, c * 32, ctx, scale_log2e, g, m, l, acc);
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+
+  if (n < G) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(&sm_o[wave][n][j * 16 + 4 * g]) = acc[j];
+    if (g == 0) {
+      sm_m[wave][n] = m;
+      sm_l[wave][n] = l;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * 128; idx += 256) {
+    const int hn = idx >> 7, d = idx & 127;
+    const float m0 = sm_m[0][hn], m1 = sm_m[1][hn], m2 = sm_m[2][hn], m3 = sm_m[3][hn];
+    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    float o = 0.f, L = 0.f;
+    if (M != -INFINITY) {
+      const float e0 = exp2f(m0 - M), e1 = exp2f(m1 - M), e2 = exp2f(m2 - M), e3 = exp2f(m3 - M);
+      o = e0 * sm_o[0][hn][d] + e1 * sm_o[1][hn][d] + e2 * sm_o[2][hn][d] + e3 * sm_o[3][hn][d];
+      L = e0 * sm_l[0][hn] + e1 * sm_l[1][hn] + e2 * sm_l[2][hn] + e3 * sm_l[3][hn];
+    }
+    const int64_t slot = ((int64_t)b * n_q_heads + h * G + hn) * nsplit + split;
+    part_o[slot * 128 + d] = o;
+    if (d == 0) {
+      part_ml[slot * 2] = M;
+      part_ml[slot * 2 + 1] = L;
+    }
+  }
+}
+
+// merge the splits: grid (batch * n_q_heads), 128 threads
+__global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __restrict__ part_o,
+                                                               const float* __restrict__ part_ml,
+                                                               uint16_t* __restrict__ out, int nsplit) {
+  const int64_t row = blockIdx.x;
+  const int d = threadIdx.x;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(row * nsplit + s) * 2]);
+  float num = 0.f, den = 0.f;
+  if (M != -INFINITY) {
+    for (int s = 0; s < nsplit; ++s) {
+      const float ms = part_ml[(row * nsplit + s) * 2];
+      const float e = exp2f(ms - M);
+      num += e * part_o[(row * nsplit + s) * 128 + d];
+      den += e * part_ml[(row * nsplit + s) * 2 + 1];
+    }
+  }
+  out[row * 128 + d] = f2bf(den > 0.f ? num / den : 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// prefill: grid (ceil(max_q_blocks / 4), n_kv_heads, n_seqs), 4 independent waves
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
+    const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
+    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ kv_lens, uint16_t* __restrict__ out,
+    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e) {
+  constexpr int TQ = 16 / G;
+  const int seq = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int q_start = cu_q[seq];
+  const int q_len = cu_q[seq + 1] - q_start;
+  const int kv_len = kv_lens[seq];
+  // heaviest (latest) query blocks are dispatched first
+  const int qblk = ((int)gridDim.x - 1 - (int)blockIdx.x) * 4 + wave;
+  const int qt0 = qblk * TQ;
+  if (qt0 >= q_len) return;
+  const int my_qt = qt0 + n / G, hn = n % G;
+  const bool valid = my_qt < q_len;
+  const int shift = kv_len - q_len;
+  const int limit = valid ? shift + my_qt + 1 : 1;
+  const int last_pos = shift + min(qt0 + TQ, q_len) - 1;
+  const int n_chunks = (last_pos + 32) >> 5;
+  const int n_tiles = (last_pos + 16) >> 4;
+
+  bf16x8 Q[4];
+  {
+    const uint16_t* qp = q + (int64_t)(q_start + (valid ? my_qt : qt0)) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 v = {0, 0, 0, 0};
+      if (valid) v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);
+      Q[kk] = as_frag(v);
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* table_row = block_table + (int64_t)seq * table_stride;
+  for (int c = 0; c < n_chunks; ++c) {
+    u32x4 K0[4], K1[4], V0[4], V1[4];
+    load_chunk(kc, vc, table_row, c, n_tiles, h, n_kv_heads, tpb, lane, K0, K1, V0, V1);
+    attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, scale_log2e, g, m, l, acc);
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (!valid) return;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  uint16_t* op = out + ((int64_t)(q_start + my_qt) * n_q_heads + h * G + hn) * 128 + 4 * g;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u32x2 o;
+    o[0] = pack_bf(acc[j][0] * inv, acc[j][1] * inv);
+    o[1] = pack_bf(acc[j][2] * inv, acc[j][3] * inv);
+    *reinterpret_cast<u32x2*>(op + 16 * j) = o;
+  }
+}
+
+static int decode_nsplit(int batch, int n_kv_heads) {
+  const int base = batch * n_kv_heads;
+  int ns = 2048 / (base > 0 ? base : 1);
+  if (ns < 1) ns = 1;
+  if (ns > 16) ns = 16;
+  return ns;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" size_t mi_paged_attn_decode_workspace(int batch, int n_q_heads) {
+  if (batch <= 0 || n_q_heads <= 0) return 0;
+  return (size_t)batch * n_q_heads * 16 * (128 + 2) * sizeof(float);
+}
+
+static int check_attn_common(const void* q, const void* kc, const void* vc, const void* bt, int n_q_heads,
+                             int n_kv_heads, int head_dim, int block_size, int64_t q_stride) {
+  if (!q || !kc || !vc || !bt || n_q_heads <= 0 || n_kv_heads <= 0) return MI_EINVAL;
+  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16 || q_stride % 8) return MI_EUNSUPPORTED;
+  if (n_q_heads % n_kv_heads) return MI_EUNSUPPORTED;
+  const int G = n_q_heads / n_kv_heads;
+  if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) return MI_EUNSUPPORTED;
+  if (!aligned16(q) || !aligned16(kc) || !aligned16(vc)) return MI_EINVAL;
+  return MI_OK;
+}
+
+extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                                    const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                    const int32_t* context_lens, mi_bf16* out, void* workspace,
+                                    size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                                    int block_size, float scale, mi_stream stream) {
+  int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
+                             q_row_stride);
+  if (rc != MI_OK) return rc;
+  if (!context_lens || !out || !workspace || batch < 0 || table_stride <= 0) return MI_EINVAL;
+  if (!aligned16(out) || !aligned16(workspace)) return MI_EINVAL;
+  if (batch == 0) return MI_OK;
+  if (ws_bytes < mi_paged_attn_decode_workspace(batch, n_q_heads)) return MI_EWORKSPACE;
+  const int G = n_q_heads / n_kv_heads;
+  const int nsplit = decode_nsplit(batch, n_kv_heads);
+  float* part_o = static_cast<float*>(workspace);
+  float* part_ml = part_o + (size_t)batch * n_q_heads * 16 * 128;
+  const float sl2 = scale * 1.4426950408889634f;
+  const dim3 grid(nsplit, n_kv_heads, batch);
+  hipStream_t st = S(stream);
+#define LAUNCH_DEC(GG)                                                                                       \
+  hipLaunchKernelGGL((paged_attn_decode_kernel<GG>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,       \
+                     v_cache, block_table, table_stride, context_lens, part_o, part_ml, n_q_heads,          \
+                     n_kv_heads, block_size / 16, sl2)
+  switch (G) {
+    case 1: LAUNCH_DEC(1); break;
+    case 2: LAUNCH_DEC(2); break;
+    case 4: LAUNCH_DEC(4); break;
+    case 8: LAUNCH_DEC(8); break;
+    default: LAUNCH_DEC(16); break;
+  }
+#undef LAUNCH_DEC
+  rc = check_launch();
+  if (rc != MI_OK) return rc;
+  hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(batch * n_q_heads), dim3(128), 0, st, part_o, part_ml, out,
+                     nsplit);
+  return check_launch();
+}
+
+extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                                     const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                     const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                     int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
+                                     int head_dim, int block_size, float scale, mi_stream stream) {
+  int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
+                             q_row_stride);
+  if (rc != MI_OK) return rc;
+  if (!cu_seqlens_q || !kv_lens || !out || n_seqs < 0 || max_seqlen_q < 0 || table_stride <= 0)
+    return MI_EINVAL;
+  if (!aligned16(out)) return MI_EINVAL;
+  if (n_seqs == 0 || max_seqlen_q == 0) return MI_OK;
+  const int G = n_q_heads / n_kv_heads;
+  const int tq = 16 / G;
+  const int q_blocks = (max_seqlen_q + tq - 1) / tq;
+  const dim3 grid((q_blocks + 3) / 4, n_kv_heads, n_seqs);
+  const float sl2 = scale * 1.4426950408889634f;
+  hipStream_t st = S(stream);
+#define LAUNCH_PRE(GG)                                                                                       \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,      \
+                     v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads, n_kv_heads, \
+                     block_size / 16, sl2)
+  switch (G) {
+    case 1: LAUNCH_PRE(1); break;
+    case 2: LAUNCH_PRE(2); break;
+    case 4: LAUNCH_PRE(4); break;
+    case 8: LAUNCH_PRE(8); break;
+    default: LAUNCH_PRE(16); break;
+  }
+#undef LAUNCH_PRE
+  return check_launch();
+}

@@ -1,0 +1,124 @@
+"""ctypes binding of libmi355_nanovllm.so (C ABI in include/mi355_nanovllm.h).
+
+The library is the product: there is no eager / CPU fallback anywhere in this
+package.  If the shared object is missing or a call fails, we raise.
+
+Tensors cross the boundary as ``tensor.data_ptr()`` plus sizes; every device
+call is enqueued on torch's *current* HIP stream so that it composes with
+torch.cuda.graph capture (hipGraph) and with RCCL collectives issued through
+torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch  # noqa: F401  (must be imported first: shares one libamdhip64 with the extension)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "MI355_NANOVLLM_LIB",
+    os.path.normpath(os.path.join(_HERE, "..", "lib", "libmi355_nanovllm.so")),
+)
+
+MI_OK = 0
+HEAD_DIM = 128
+KV_TILE_TOKENS = 16
+KV_TILE_ELEMS = 2048
+
+
+class MiError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"libmi355_nanovllm.so not found at {LIB_PATH}; build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C nano-vllm-ascend_amd/csrc` (there is no fallback path)."
+        )
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_p = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "mi_strerror": (c_char_p, [c_int]),
+    "mi_version": (c_char_p, []),
+    "mi_last_launch_error": (c_char_p, []),
+    "mi_kv_elem_offset": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mi_reshape_and_cache": (c_int, [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_scatter_update_kv": (c_int, [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_kv_cache_gather": (c_int, [_p, c_int, _p, c_int, _p, c_int, c_int, c_int, _p]),
+    "mi_paged_attn_decode_workspace": (c_size_t, [c_int, c_int]),
+    "mi_paged_attn_decode": (
+        c_int,
+        [_p, c_int64, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_float, _p],
+    ),
+    "mi_paged_attn_prefill": (
+        c_int,
+        [_p, c_int64, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int, c_int, c_int, c_float, _p],
+    ),
+    "mi_rmsnorm": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_int, c_float, _p]),
+    "mi_add_rmsnorm": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
+    "mi_rope": (c_int, [_p, _p, _p, c_int64, c_int, _p, c_int64, c_int, _p, _p, c_int, c_int, _p]),
+    "mi_qknorm_rope_store": (
+        c_int,
+        [_p, c_int64, _p, _p, c_float, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, c_int, _p],
+    ),
+    "mi_silu_mul": (c_int, [_p, _p, c_int, c_int, _p]),
+    "mi_gemm_bf16_skinny": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_embedding": (c_int, [_p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
+    "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),
+    "mi_argmax": (c_int, [_p, c_int64, _p, c_int, c_int, _p]),
+    "mi_sample": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_uint64, c_uint64, _p]),
+    "mi_xxh64_chain": (c_uint64, [_p, c_size_t, c_int, c_uint64]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def version() -> str:
+    return lib.mi_version().decode()
+
+
+def check(code: int, what: str) -> None:
+    if code != MI_OK:
+        msg = lib.mi_strerror(code).decode()
+        if code == -4:
+            msg += ": " + lib.mi_last_launch_error().decode()
+        raise MiError(f"{what} failed: {msg} (code {code})")
+
+
+def stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MiError(
+                "mi355_nanovllm kernels only run on a HIP device; got a "
+                f"{t.device} tensor (there is no CPU fallback)"
+            )
+
+
+def xxh64_chain(data: bytes, prefix: int = -1) -> int:
+    """xxh64(prefix_le64 ++ data) — BlockManager.compute_hash (block_manager.py:38-44)."""
+    if prefix == -1:
+        return lib.mi_xxh64_chain(data, len(data), 0, 0)
+    return lib.mi_xxh64_chain(data, len(data), 1, prefix & 0xFFFFFFFFFFFFFFFF)

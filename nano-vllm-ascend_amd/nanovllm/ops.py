@@ -1,0 +1,287 @@
+"""Tensor-level wrappers over the C ABI: shape checks, output allocation, strides.
+
+Nothing here computes anything: every function ends in exactly one (attention
+decode: two) kernel launch inside libmi355_nanovllm.so on torch's current stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from nanovllm import _C
+from nanovllm._C import HEAD_DIM, KV_TILE_ELEMS, check, lib, ptr, require_gpu, stream
+
+_BF16 = torch.bfloat16
+
+
+def _bf16(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and t.dtype != _BF16:
+            raise _C.MiError(f"expected bfloat16 tensor, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------- KV cache
+def kv_cache_shape(num_blocks: int, n_kv_heads: int, block_size: int) -> tuple[int, int, int, int]:
+    """Shape of one layer's K (or V) cache in the fragment-native layout."""
+    assert block_size % _C.KV_TILE_TOKENS == 0
+    return (num_blocks, n_kv_heads, block_size // _C.KV_TILE_TOKENS, KV_TILE_ELEMS)
+
+
+def reshape_and_cache(k, v, k_cache, v_cache, slot_flat, n_kv_heads: int, block_size: int) -> None:
+    require_gpu(k, v, k_cache, v_cache, slot_flat)
+    _bf16(k, v, k_cache, v_cache)
+    n = k.shape[0]
+    assert k.stride(-1) == 1 and v.stride(-1) == 1
+    assert slot_flat.dtype == torch.int32 and slot_flat.is_contiguous() and slot_flat.numel() == n
+    check(
+        lib.mi_reshape_and_cache(ptr(k), ptr(v), k.stride(0), v.stride(0), ptr(k_cache), ptr(v_cache),
+                                 ptr(slot_flat), n, n_kv_heads, HEAD_DIM, block_size, stream()),
+        "mi_reshape_and_cache",
+    )
+
+
+def scatter_update_kv(k, v, k_cache, v_cache, slot_2d, n_kv_heads: int, block_size: int) -> None:
+    require_gpu(k, v, k_cache, v_cache, slot_2d)
+    _bf16(k, v, k_cache, v_cache)
+    n = k.shape[0]
+    assert slot_2d.dtype == torch.int32 and slot_2d.is_contiguous() and slot_2d.shape == (n, 2)
+    check(
+        lib.mi_scatter_update_kv(ptr(k), ptr(v), k.stride(0), v.stride(0), ptr(k_cache), ptr(v_cache),
+                                 ptr(slot_2d), n, n_kv_heads, HEAD_DIM, block_size, stream()),
+        "mi_scatter_update_kv",
+    )
+
+
+def kv_cache_gather(cache, is_v: bool, slot_flat, n_kv_heads: int, block_size: int) -> torch.Tensor:
+    """Rows of the cache in the reference's logical layout [n, n_kv_heads*128]."""
+    require_gpu(cache, slot_flat)
+    n = slot_flat.numel()
+    out = torch.empty((n, n_kv_heads * HEAD_DIM), dtype=_BF16, device=cache.device)
+    check(
+        lib.mi_kv_cache_gather(ptr(cache), int(is_v), ptr(slot_flat), n, ptr(out), n_kv_heads, HEAD_DIM,
+                               block_size, stream()),
+        "mi_kv_cache_gather",
+    )
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+_WORKSPACES: dict[torch.device, torch.Tensor] = {}
+
+
+def attn_workspace(device, batch: int, n_q_heads: int) -> torch.Tensor:
+    need = lib.mi_paged_attn_decode_workspace(batch, n_q_heads)
+    ws = _WORKSPACES.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _WORKSPACES[device] = ws
+    return ws
+
+
+def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, n_q_heads: int, n_kv_heads: int,
+                      block_size: int, scale: float, out=None, workspace=None) -> torch.Tensor:
+    require_gpu(q, k_cache, v_cache, block_tables, context_lens)
+    _bf16(q, k_cache, v_cache)
+    batch = q.shape[0]
+    q2 = q.view(batch, -1) if q.dim() == 3 else q
+    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * HEAD_DIM
+    assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
+    if out is None:
+        out = torch.empty((batch, n_q_heads * HEAD_DIM), dtype=_BF16, device=q.device)
+    if workspace is None:
+        workspace = attn_workspace(q.device, batch, n_q_heads)
+    check(
+        lib.mi_paged_attn_decode(ptr(q2), q2.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                 block_tables.stride(0), ptr(context_lens), ptr(out), ptr(workspace),
+                                 workspace.numel() * workspace.element_size(), batch, n_q_heads, n_kv_heads,
+                                 HEAD_DIM, block_size, float(scale), stream()),
+        "mi_paged_attn_decode",
+    )
+    return out
+
+
+def paged_attn_prefill(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens, max_seqlen_q: int,
+                       n_q_heads: int, n_kv_heads: int, block_size: int, scale: float, out=None) -> torch.Tensor:
+    require_gpu(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
+    _bf16(q, k_cache, v_cache)
+    T = q.shape[0]
+    q2 = q.view(T, -1) if q.dim() == 3 else q
+    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * HEAD_DIM
+    assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert cu_seqlens_q.dtype == torch.int32 and kv_lens.dtype == torch.int32
+    n_seqs = cu_seqlens_q.numel() - 1
+    assert kv_lens.numel() == n_seqs and block_tables.shape[0] >= n_seqs
+    if out is None:
+        out = torch.empty((T, n_q_heads * HEAD_DIM), dtype=_BF16, device=q.device)
+    check(
+        lib.mi_paged_attn_prefill(ptr(q2), q2.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                  block_tables.stride(0), ptr(cu_seqlens_q), ptr(kv_lens), n_seqs,
+                                  int(max_seqlen_q), ptr(out), n_q_heads, n_kv_heads, HEAD_DIM, block_size,
+                                  float(scale), stream()),
+        "mi_paged_attn_prefill",
+    )
+    return out
+
+
+# --------------------------------------------------------------------------- norms
+def rmsnorm(x, w, eps: float, out=None) -> torch.Tensor:
+    """x: [rows, cols] (contiguous rows) or [T, H, cols] with arbitrary token stride."""
+    require_gpu(x, w)
+    _bf16(x, w)
+    cols = x.shape[-1]
+    assert x.stride(-1) == 1 and w.numel() == cols
+    if x.dim() == 3:
+        outer, inner = x.shape[0], x.shape[1]
+        assert x.stride(1) == cols
+        outer_stride = x.stride(0)
+    else:
+        x2 = x.reshape(-1, cols) if x.is_contiguous() else x
+        assert x2.dim() == 2
+        outer, inner, outer_stride = x2.shape[0], 1, x2.stride(0)
+    if out is None:
+        out = torch.empty(x.shape, dtype=_BF16, device=x.device)
+    check(lib.mi_rmsnorm(ptr(x), outer_stride, ptr(w), ptr(out), outer, inner, cols, float(eps), stream()),
+          "mi_rmsnorm")
+    return out
+
+
+def add_rmsnorm(x, residual, w, eps: float, out=None, residual_out=None):
+    require_gpu(x, residual, w)
+    _bf16(x, residual, w)
+    assert x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if out is None:
+        out = torch.empty_like(x)
+    if residual_out is None:
+        residual_out = torch.empty_like(x)
+    check(
+        lib.mi_add_rmsnorm(ptr(x), ptr(residual), ptr(w), ptr(out), ptr(residual_out), rows, cols, float(eps),
+                           stream()),
+        "mi_add_rmsnorm",
+    )
+    return out, residual_out
+
+
+# --------------------------------------------------------------------------- rope (+ fused)
+def rope(positions, q, k, cos_sin, n_q_heads: int, n_kv_heads: int):
+    """q: [T, Hq, 128] / k: [T, Hkv, 128] views (token stride free) -> contiguous copies."""
+    require_gpu(positions, q, k, cos_sin)
+    _bf16(q, k)
+    T = q.shape[0]
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == T
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
+    q3 = q.view(T, n_q_heads, HEAD_DIM) if q.dim() == 2 else q
+    k3 = k.view(T, n_kv_heads, HEAD_DIM) if k.dim() == 2 else k
+    assert q3.stride(2) == 1 and q3.stride(1) == HEAD_DIM and k3.stride(2) == 1 and k3.stride(1) == HEAD_DIM
+    q_out = torch.empty((T, n_q_heads, HEAD_DIM), dtype=_BF16, device=q.device)
+    k_out = torch.empty((T, n_kv_heads, HEAD_DIM), dtype=_BF16, device=q.device)
+    check(
+        lib.mi_rope(ptr(positions), ptr(cos_sin), ptr(q3), q3.stride(0), n_q_heads, ptr(k3), k3.stride(0),
+                    n_kv_heads, ptr(q_out), ptr(k_out), T, HEAD_DIM, stream()),
+        "mi_rope",
+    )
+    return q_out, k_out
+
+
+def qknorm_rope_store(qkv, q_w, k_w, eps: float, positions, cos_sin, k_cache, v_cache, slots,
+                      n_q_heads: int, n_kv_heads: int, block_size: int, q_out=None) -> torch.Tensor:
+    require_gpu(qkv, positions, cos_sin, k_cache, v_cache, slots)
+    _bf16(qkv, k_cache, v_cache)
+    T = qkv.shape[0]
+    assert qkv.stride(1) == 1 and qkv.shape[1] == (n_q_heads + 2 * n_kv_heads) * HEAD_DIM
+    assert positions.dtype == torch.int64 and positions.is_contiguous()
+    assert slots.dtype == torch.int32 and slots.is_contiguous()
+    is2d = int(slots.dim() == 2)
+    if q_out is None:
+        q_out = torch.empty((T, n_q_heads * HEAD_DIM), dtype=_BF16, device=qkv.device)
+    check(
+        lib.mi_qknorm_rope_store(ptr(qkv), qkv.stride(0), ptr(q_w), ptr(k_w), float(eps), ptr(positions),
+                                 ptr(cos_sin), ptr(q_out), ptr(k_cache), ptr(v_cache), ptr(slots), is2d, T,
+                                 n_q_heads, n_kv_heads, HEAD_DIM, block_size, stream()),
+        "mi_qknorm_rope_store",
+    )
+    return q_out
+
+
+# --------------------------------------------------------------------------- mlp / linear / embed
+def silu_mul(x, out=None) -> torch.Tensor:
+    require_gpu(x)
+    _bf16(x)
+    assert x.is_contiguous()
+    inter = x.shape[-1] // 2
+    rows = x.numel() // x.shape[-1]
+    if out is None:
+        out = torch.empty((*x.shape[:-1], inter), dtype=_BF16, device=x.device)
+    check(lib.mi_silu_mul(ptr(x), ptr(out), rows, inter, stream()), "mi_silu_mul")
+    return out
+
+
+SKINNY_MAX_M = 64
+
+
+def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
+    """y = x @ w.T (+ bias) for M <= 64 rows (decode)."""
+    require_gpu(x, w, bias)
+    _bf16(x, w, bias)
+    assert x.is_contiguous() and w.is_contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((*x.shape[:-1], N), dtype=_BF16, device=x.device)
+    check(lib.mi_gemm_bf16_skinny(ptr(x), ptr(w), ptr(bias), ptr(out), M, N, K, stream()), "mi_gemm_bf16_skinny")
+    return out
+
+
+def embedding(ids, w, vocab_start: int = 0, out=None) -> torch.Tensor:
+    require_gpu(ids, w)
+    _bf16(w)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and w.is_contiguous()
+    n, hidden = ids.numel(), w.shape[1]
+    if out is None:
+        out = torch.empty((n, hidden), dtype=_BF16, device=w.device)
+    check(lib.mi_embedding(ptr(ids), ptr(w), ptr(out), n, hidden, vocab_start, w.shape[0], stream()),
+          "mi_embedding")
+    return out
+
+
+def gather_last_tokens(x, cu_seqlens_q) -> torch.Tensor:
+    require_gpu(x, cu_seqlens_q)
+    _bf16(x)
+    assert x.is_contiguous() and cu_seqlens_q.dtype == torch.int32
+    n_seqs, hidden = cu_seqlens_q.numel() - 1, x.shape[-1]
+    out = torch.empty((n_seqs, hidden), dtype=_BF16, device=x.device)
+    check(lib.mi_gather_last_tokens(ptr(x), ptr(cu_seqlens_q), ptr(out), n_seqs, hidden, stream()),
+          "mi_gather_last_tokens")
+    return out
+
+
+# --------------------------------------------------------------------------- sampling
+def argmax(logits, out=None) -> torch.Tensor:
+    require_gpu(logits)
+    _bf16(logits)
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    rows, vocab = logits.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    check(lib.mi_argmax(ptr(logits), logits.stride(0), ptr(out), rows, vocab, stream()), "mi_argmax")
+    return out
+
+
+def sample(logits, temperatures, seed: int, step: int, out=None) -> torch.Tensor:
+    require_gpu(logits, temperatures)
+    _bf16(logits)
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    assert temperatures.dtype == torch.float32 and temperatures.is_contiguous()
+    rows, vocab = temperatures.numel(), logits.shape[1]
+    assert logits.shape[0] >= rows
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    check(
+        lib.mi_sample(ptr(logits), logits.stride(0), ptr(temperatures), ptr(out), rows, vocab,
+                      seed & 0xFFFFFFFFFFFFFFFF, step & 0xFFFFFFFFFFFFFFFF, stream()),
+        "mi_sample",
+    )
+    return out

@@ -1,0 +1,47 @@
+"""pytest configuration: paths, the `gpu` marker, shared fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "nano-vllm-ascend_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def bf16_from_bits(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).view(torch.bfloat16)
+
+
+@pytest.fixture(scope="session")
+def golden_layers():
+    return np.load(os.path.join(GOLDEN, "layers.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_attention():
+    return np.load(os.path.join(GOLDEN, "attention.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tiny():
+    return np.load(os.path.join(GOLDEN, "tiny_model.npz"))

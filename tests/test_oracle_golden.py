@@ -1,0 +1,193 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tools/gen_golden.py, run in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import oracle
+from conftest import GOLDEN, bf16_from_bits as bf
+from oracle.model import OracleConfig, OracleQwen3
+
+
+def _eq(a: torch.Tensor, b: torch.Tensor):
+    assert a.shape == b.shape and a.dtype == b.dtype
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (
+        f"{(a.view(torch.int16) != b.view(torch.int16)).sum().item()} of {a.numel()} elements differ")
+
+
+def test_rmsnorm_bit_exact(golden_layers):
+    g = golden_layers
+    for tag in ("h1024", "head128", "h256"):
+        x, w, r = bf(g[f"rms_{tag}_x"]), bf(g[f"rms_{tag}_w"]), bf(g[f"rms_{tag}_r"])
+        _eq(oracle.rms_norm(x, w, 1e-6), bf(g[f"rms_{tag}_y"]))
+        y, r2 = oracle.add_rms_norm(x, r, w, 1e-6)
+        _eq(y, bf(g[f"rms_{tag}_addy"]))
+        _eq(r2, bf(g[f"rms_{tag}_addr"]))
+
+
+def test_rope_bit_exact(golden_layers):
+    g = golden_layers
+    pos = torch.from_numpy(g["rope_pos"])
+    table = oracle.build_cos_sin_cache(128, 40960, 1000000.0)
+    assert torch.equal(table[pos], torch.from_numpy(g["rope_table_rows"]))
+    _eq(oracle.apply_rope(pos, bf(g["rope_q"]), table), bf(g["rope_q_out"]))
+    _eq(oracle.apply_rope(pos, bf(g["rope_k"]), table), bf(g["rope_k_out"]))
+
+
+def test_silu_and_mul_bit_exact(golden_layers):
+    g = golden_layers
+    _eq(oracle.silu_and_mul(bf(g["silu_x"])), bf(g["silu_y"]))
+
+
+def _caches(g, prefix):
+    hq, hkv, d, bs, nblk = (int(v) for v in g["meta"])
+    return hq, hkv, d, bs, nblk
+
+
+def test_kv_scatter_bit_exact(golden_attention):
+    g = golden_attention
+    hq, hkv, d, bs, nblk = _caches(g, "pre")
+    kc = torch.zeros(nblk, bs, hkv, d, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    slots = torch.from_numpy(g["pre_slots"])
+    oracle.kv_scatter(bf(g["pre_k"]), bf(g["pre_v"]), kc, vc, slots)
+    _eq(kc.view(-1, hkv, d)[slots.long()], bf(g["pre_krows"]))
+    _eq(vc.view(-1, hkv, d)[slots.long()], bf(g["pre_vrows"]))
+    assert int((kc.view(-1, hkv * d) != 0).any(dim=1).sum()) == int(g["pre_cache_nonzero_rows"])
+    # decode-style scatter on a populated cache
+    kc, vc = bf(g["dec_kcache_before"]).clone(), bf(g["dec_vcache_before"]).clone()
+    kc0 = kc.clone()
+    slots = torch.from_numpy(g["dec_slots"])
+    oracle.kv_scatter(bf(g["dec_k"]), bf(g["dec_v"]), kc, vc, slots)
+    _eq(kc.view(-1, hkv, d)[slots.long()], bf(g["dec_krows_after"]))
+    _eq(vc.view(-1, hkv, d)[slots.long()], bf(g["dec_vrows_after"]))
+    assert int((kc != kc0).view(-1, hkv * d).any(dim=1).sum()) == int(g["dec_cache_rows_changed"])
+
+
+def test_attention_vs_reference_native(golden_attention):
+    """The reference's CPU attention keeps S and P in bf16 with a bf16-rounded scale
+    (attention_torch_native.py:80,139,189); the oracle is the exact fp32 softmax.
+    Bound: a few bf16 ulps of the output magnitude (|out| <= ~1 here)."""
+    g = golden_attention
+    hq, hkv, d, bs, nblk = _caches(g, "")
+    # prefill
+    kc = torch.zeros(nblk, bs, hkv, d, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    oracle.kv_scatter(bf(g["pre_k"]), bf(g["pre_v"]), kc, vc, torch.from_numpy(g["pre_slots"]))
+    cu = torch.from_numpy(g["pre_cu"])
+    o = oracle.paged_attention_prefill(bf(g["pre_q"]), kc, vc, torch.from_numpy(g["pre_tables"]), cu,
+                                       cu[1:] - cu[:-1])
+    ref = bf(g["pre_out"])
+    err = (o.float() - ref.float()).abs().max().item()
+    assert err <= 3e-2, err
+    # decode
+    kc, vc = bf(g["dec_kcache_before"]).clone(), bf(g["dec_vcache_before"]).clone()
+    oracle.kv_scatter(bf(g["dec_k"]), bf(g["dec_v"]), kc, vc, torch.from_numpy(g["dec_slots"]))
+    o = oracle.paged_attention_decode(bf(g["dec_q"]), kc, vc, torch.from_numpy(g["dec_tables"]),
+                                      torch.from_numpy(g["dec_ctx"]))
+    ref = bf(g["dec_out"])
+    err = (o.float() - ref.float()).abs().max().item()
+    assert err <= 3e-2, err
+    # ctx == 1 attends exactly one token: output equals that V row, bit for bit
+    v0 = bf(g["dec_v"])[0]  # [hkv, d]
+    expect = v0.repeat_interleave(hq // hkv, dim=0).reshape(-1)
+    _eq(o[0], expect)
+
+
+def test_sampler_probabilities(golden_layers):
+    g = golden_layers
+    logits, temps = bf(g["samp_logits"]), torch.from_numpy(g["samp_temps"])
+    p = torch.softmax(logits.float() / temps.unsqueeze(-1), dim=-1)
+    assert torch.equal(p, torch.from_numpy(g["samp_probs"]))
+
+
+def _tiny_oracle(g):
+    from transformers import Qwen3Config
+
+    weights = {k[3:]: bf(g[k]) for k in g.files if k.startswith("w::")}
+    hf = Qwen3Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                     head_dim=128, intermediate_size=256, vocab_size=256, max_position_embeddings=512,
+                     rms_norm_eps=1e-6, tie_word_embeddings=True, attention_bias=False, hidden_act="silu")
+    cfg = OracleConfig.from_hf(hf)
+    block_size, nblk = (int(v) for v in g["meta"])
+    return OracleQwen3(cfg, weights, nblk, block_size), block_size
+
+
+def test_tiny_model_matches_reference_run(golden_tiny):
+    """Replay the reference's own greedy run (its scheduler, block manager, prepare_*,
+    model) through the oracle model with the same token stream.  The reference
+    pipeline is bf16 end to end with bf16 S/P in attention, so logits agree to a
+    bf16-ulp-scale bound, and greedy tokens agree wherever the reference's top-2
+    margin exceeds that bound."""
+    g = golden_tiny
+    model, bs = _tiny_oracle(g)
+    lens = g["prompt_lens"].tolist()
+    flat = g["prompts"].tolist()
+    prompts, o = [], 0
+    for n in lens:
+        prompts.append(flat[o:o + n])
+        o += n
+    # the reference scheduler with ample blocks hands out block ids FIFO: 0.. per sequence
+    tables, nxt = [], 0
+    for n in lens:
+        nb = (n + bs - 1) // bs
+        tables.append(list(range(nxt, nxt + nb)))
+        nxt += nb
+    toks = [list(p) for p in prompts]
+    worst = 0.0
+    for step in range(int(g["n_steps"])):
+        ref_logits = bf(g[f"s{step}_logits"]).float()
+        ref_tokens = g[f"s{step}_tokens"].tolist()
+        seqs = g[f"s{step}_seqs"].tolist()
+        if int(g[f"s{step}_prefill"]):
+            ids = torch.tensor(sum((toks[s] for s in seqs), []), dtype=torch.int64)
+            pos = torch.tensor(sum((list(range(len(toks[s]))) for s in seqs), []), dtype=torch.int64)
+            cu = torch.tensor([0] + list(np.cumsum([len(toks[s]) for s in seqs])), dtype=torch.int32)
+            slots = torch.tensor(sum(([tables[s][i // bs] * bs + i % bs for i in range(len(toks[s]))]
+                                      for s in seqs), []), dtype=torch.int32)
+            width = max(len(tables[s]) for s in seqs)
+            bt = torch.tensor([tables[s] + [-1] * (width - len(tables[s])) for s in seqs], dtype=torch.int32)
+            logits = model.prefill(ids, pos, cu, slots, bt, fp32_logits=True)
+        else:
+            for s in seqs:  # may_append: new block when the new token starts one (block_manager.py:102-109)
+                if len(toks[s]) % bs == 1 and len(tables[s]) * bs < len(toks[s]):
+                    tables[s].append(nxt)
+                    nxt += 1
+            ids = torch.tensor([toks[s][-1] for s in seqs], dtype=torch.int64)
+            pos = torch.tensor([len(toks[s]) - 1 for s in seqs], dtype=torch.int64)
+            ctx = torch.tensor([len(toks[s]) for s in seqs], dtype=torch.int32)
+            slot2d = torch.tensor([[tables[s][-1], (len(toks[s]) - 1) % bs] for s in seqs], dtype=torch.int32)
+            width = max(len(tables[s]) for s in seqs)
+            bt = torch.tensor([tables[s] + [-1] * (width - len(tables[s])) for s in seqs], dtype=torch.int32)
+            logits = model.decode(ids, pos, slot2d, ctx, bt, fp32_logits=True)
+        err = (logits - ref_logits).abs().max().item()
+        worst = max(worst, err)
+        # token agreement where the reference's decision margin is larger than the error bound
+        top2 = ref_logits.topk(2, dim=-1).values
+        margin = (top2[:, 0] - top2[:, 1])
+        mine = logits.argmax(dim=-1).tolist()
+        for i, s in enumerate(seqs):
+            if margin[i] > 2 * 6e-2:
+                assert mine[i] == ref_tokens[i], (step, i)
+            toks[s].append(ref_tokens[i])  # follow the reference's token stream
+    assert worst <= 6e-2, worst
+    assert sum(toks, []) == g["final_tokens"].tolist()
+
+
+def test_hash_kats_against_xxhash_package():
+    """block_manager.py:38-44 calls the `xxhash` pip package; pin the KATs the
+    reference produced against the package installed here."""
+    import xxhash
+
+    with open(os.path.join(GOLDEN, "hash_kats.json")) as f:
+        kats = json.load(f)
+    for k in kats:
+        data = np.array(k["tokens"]).tobytes()
+        assert xxhash.xxh64(data).intdigest() == k["hash"]
+        nxt = np.array(k.get("chained_tokens", k["tokens"])).tobytes()
+        h = xxhash.xxh64()
+        h.update(k["chained_with_prefix"].to_bytes(8, "little"))
+        h.update(nxt)
+        assert h.intdigest() == k["chained"]
