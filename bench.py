@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s (+ p50 TTFT) of Qwen3-0.6B, bs=32, seq=1024, block 16,
+bf16, paged decode under hipGraph — BASELINE.json configs[1] — on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W          # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W   # N ranks, tensor parallel over RCCL
+
+A "step" is one engine decode step over the batch of 32 sequences (scheduler -> metadata
+-> graph replay -> sampling -> postprocess), i.e. 32 new tokens.  Inputs are synthetic
+(random-init Qwen3-0.6B-shaped weights N(0,0.02^2), random prompt ids in [0,10000],
+random.seed(0)); the 32 x 1024-token prompts are prefilled through the
+engine first (that is where p50 TTFT comes from), so the KV cache is resident in HBM
+when the timed region starts.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (paged_attn_decode) timed live with HIP events on its
+                launch stream over the engine's real KV cache: algorithmic KV bytes per
+                launch / average duration vs the 8 TB/s HBM peak;
+  step_roofline the whole decode step against BASELINE.md's bytes(B, ctx) model;
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's arithmetic) timed on
+                this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import statistics
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "nano-vllm-ascend_amd"), os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+BATCH, PROMPT_LEN, BLOCK = 32, 1024, 16
+
+
+def step_bytes(batch: int, ctx: int, tp: int = 1) -> float:
+    """algorithmic HBM bytes of one decode step (whole job, all ranks)."""
+    return 1_192_099_840 + batch * (114_688 * ctx + 418_560)
+
+
+def cpu_baseline(sample_steps: int = 1):
+    """The oracle's decode step at bs=32 / ctx=1024 on the host cores (random KV contents
+    instead of a CPU prefill: same arithmetic per step, bounded run time)."""
+    import torch
+    from transformers import Qwen3Config
+
+    from model_configs import QWEN3_0_6B
+    from oracle.model import OracleConfig, OracleQwen3, random_weights
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(cores, 32)))  # the cores this process may use, capped
+    hf = Qwen3Config(**{k: v for k, v in QWEN3_0_6B.items() if k not in ("architectures", "model_type", "torch_dtype")})
+    cfg = OracleConfig.from_hf(hf)
+    blocks_per_seq = PROMPT_LEN // BLOCK + 1
+    model = OracleQwen3(cfg, random_weights(cfg, seed=0), BATCH * blocks_per_seq, BLOCK)
+    g = torch.Generator().manual_seed(0)
+    # random KV contents (one layer's worth, repeated: values do not affect the timing)
+    layer = torch.randn(model.k_cache.shape[1:], generator=g).to(model.k_cache.dtype)
+    model.k_cache.copy_(layer.unsqueeze(0).expand_as(model.k_cache))
+    model.v_cache.copy_(layer.flip(0).unsqueeze(0).expand_as(model.v_cache))
+    tables = torch.arange(BATCH * blocks_per_seq, dtype=torch.int32).view(BATCH, blocks_per_seq)
+    ids = torch.randint(0, 10000, (BATCH,), generator=g)
+    t0 = time.perf_counter()
+    for s in range(sample_steps):
+        n = PROMPT_LEN + 1 + s
+        pos = torch.full((BATCH,), n - 1, dtype=torch.int64)
+        ctx = torch.full((BATCH,), n, dtype=torch.int32)
+        slot = torch.stack([tables[:, (n - 1) // BLOCK], torch.full((BATCH,), (n - 1) % BLOCK, dtype=torch.int32)], 1)
+        logits = model.decode(ids, pos, slot, ctx, tables)
+        ids = logits.float().argmax(-1)
+    dt = time.perf_counter() - t0
+    return {"value": BATCH * sample_steps / dt, "unit": "tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{sample_steps} decode step(s) of bs={BATCH} ctx={PROMPT_LEN} "
+            f"(oracle/ CPU port, random KV contents), {dt:.1f} s"}
+
+
+def attention_roofline(llm, seqs, iters: int = 20):
+    import torch
+
+    with torch.inference_mode():
+        return _attention_roofline(llm, seqs, iters)
+
+
+def _attention_roofline(llm, seqs, iters):
+    """Time mi_paged_attn_decode (+ its split-merge) alone, on the engine's KV cache and block
+    tables, cycling over all layers so successive launches never hit the Infinity Cache."""
+    import torch
+
+    from nanovllm import ops
+
+    mr = llm.model_runner
+    dev = mr.device
+    real = len(seqs)
+    # KV rows exist for every token but the one just sampled: attend len-1 tokens per sequence
+    ctx_host = [len(x) - 1 for x in seqs]
+    width = max(len(x.block_table) for x in seqs)
+    tables = torch.tensor([x.block_table + [-1] * (width - len(x.block_table)) for x in seqs],
+                          dtype=torch.int32, device=dev)
+    ctx = torch.tensor(ctx_host, dtype=torch.int32, device=dev)
+    attn_mods = [m for m in mr.model.modules() if hasattr(m, "k_cache") and hasattr(m, "v_cache")]
+    a0 = attn_mods[0]
+    q = torch.randn(real, a0.num_heads * 128, device=dev).bfloat16()
+    out = torch.empty_like(q)
+    ws = ops.attn_workspace(dev, real, a0.num_heads)
+
+    def launch_all():
+        for m in attn_mods:
+            ops.paged_attn_decode(q, m.k_cache, m.v_cache, tables, ctx, m.num_heads, m.num_kv_heads,
+                                  mr.block_size, m.scale, out=out, workspace=ws)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch_all()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):  # graph replay: no host launch gaps between the launches
+        launch_all()
+    graph.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        graph.replay()
+    e.record()
+    torch.cuda.synchronize()
+    dur = s.elapsed_time(e) * 1e-3 / (iters * len(attn_mods))
+    ctx_sum = int(sum(ctx_host))
+    algo = ctx_sum * 2 * a0.num_kv_heads * 128 * 2  # K+V rows of every context token, bf16
+    return {"kernel": "paged_attn_decode_kernel+merge", "bound": "hbm", "achieved": algo / dur / 1e9,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / dur / HBM_PEAK, "traffic": None,
+            "bytes_per_launch": algo, "avg_launch_us": dur * 1e6, "launches_timed": iters * len(attn_mods)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from model_configs import QWEN3_0_6B, make_model_dir
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.engine.llm_engine import run_worker
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    if world > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank))))
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    model_dir = os.path.join(tmp, f"mi355_qwen3_0p6b_{port}")
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
+        with open(os.path.join(model_dir, "config.json"), "w") as f:
+            json.dump(QWEN3_0_6B, f)
+    if world > 1:
+        dist.barrier()
+    total_new = args.warmup + args.steps + 2
+    blocks_needed = BATCH * ((PROMPT_LEN + total_new) // BLOCK + 2) + 64
+    kw = dict(tensor_parallel_size=world, kvcache_block_size=BLOCK, max_num_seqs=BATCH, max_model_len=4096,
+              max_num_batched_tokens=16384, num_kvcache_blocks=max(blocks_needed, 4096), hccl_port=port + 1,
+              synthetic_seed=0, warmup=os.environ.get("BENCH_NO_WARMUP") is None,
+              enforce_eager=os.environ.get("BENCH_EAGER") is not None)
+    if rank != 0:
+        run_worker(model_dir, **kw)
+        return
+
+    llm = LLM(model_dir, **kw)
+    random.seed(0)
+    prompts = [[random.randint(0, 10000) for _ in range(PROMPT_LEN)] for _ in range(BATCH)]
+    sp = SamplingParams(temperature=1.0, max_tokens=total_new, ignore_eos=True, greedy=True)
+    seqs = [llm.add_request(p, sp) for p in prompts]
+    prefill_steps = 0
+    while any(s.num_completion_tokens == 0 for s in seqs):  # prefill (2 steps of 16 x 1024 tokens)
+        llm.step()
+        prefill_steps += 1
+    ttft = sorted(llm.ttft[s.seq_id] for s in seqs)
+    for _ in range(args.warmup):
+        llm.step()
+    torch.cuda.synchronize()
+    ctx0 = len(seqs[0])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, n = llm.step()
+        assert n == -BATCH
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx1 = len(seqs[0])
+    algo = sum(step_bytes(BATCH, c) for c in range(ctx0 + 1, ctx1 + 1))
+    value = BATCH * args.steps / elapsed
+    result = {
+        "metric": "decode tokens/s, Qwen3-0.6B bs=32 seq=1024 (p50 TTFT in ttft_p50_ms)",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Qwen3-0.6B bf16 paged decode under hipGraph, bs=32, 1024-token prompts, "
+                               "block_size=16 (BASELINE.json configs[1])",
+                   "batch": BATCH, "prompt_len": PROMPT_LEN, "ctx_first": ctx0 + 1, "ctx_last": ctx1,
+                   "block_size": BLOCK, "parallelism": f"tp{world}", "greedy": True},
+        "ttft_p50_ms": statistics.median(ttft) * 1e3, "ttft_max_ms": ttft[-1] * 1e3,
+        "prefill_steps": prefill_steps,
+        "step_roofline": {"bound": "hbm", "achieved": algo / elapsed / 1e9, "peak": HBM_PEAK / 1e9 * world,
+                          "unit": "GB/s", "frac": algo / elapsed / (HBM_PEAK * world),
+                          "bytes_per_step": algo / args.steps},
+    }
+    result["roofline"] = attention_roofline(llm, seqs) if world == 1 else None
+    llm.exit()
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

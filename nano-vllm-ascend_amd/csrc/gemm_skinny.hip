@@ -17,16 +17,16 @@
 
 namespace mi {
 
-template <int MT, int WAVES, bool BIAS>
+template <int MT, int WAVES, int STEPS, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
     uint16_t* __restrict__ y, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][MT][256]
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
   const int n0 = blockIdx.x * 16;
-  const int kslice = K / WAVES;
+  const int kslice = K / WAVES;  // multiple of 32 * STEPS (checked on the host)
   const int kbeg = wave * kslice;
 
   f32x4 acc[MT];
@@ -35,26 +35,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 
   // A fragment for k-step s: lane (g, r) <- w[n0 + r][k + 32 s + 8 g .. +8]
   const uint16_t* wp = w + (int64_t)(n0 + r) * K + kbeg + 8 * g;
-  // B fragment: lane (g, c) <- x[16 m + c][k + 32 s + 8 g .. +8]
-  const uint16_t* xp = x + (int64_t)r * K + kbeg + 8 * g;
+  // B fragment of column tile m: lane (g, c) <- x[16 m + c][k + 32 s + 8 g .. +8].  Rows >= M are
+  // clamped to row M-1: MFMA output columns are independent, the duplicates are never stored.
+  const uint16_t* xp[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) xp[m] = x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 8 * g;
 
-  for (int k = 0; k < kslice; k += 256) {
-    const int steps = min(8, (kslice - k) >> 5);
-    u32x4 a[8];
+  for (int k = 0; k < kslice; k += 32 * STEPS) {
+    u32x4 a[STEPS], bfrag[MT][STEPS];
+    // every load of the block is issued before the first MFMA: no branches, no waits in between
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      if (s < steps) a[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + k + 32 * s));
+    for (int s = 0; s < STEPS; ++s)
+      a[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + k + 32 * s));
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s < steps) {
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          u32x4 b = {0, 0, 0, 0};
-          if (16 * m + r < M) b = *reinterpret_cast<const u32x4*>(xp + (int64_t)16 * m * K + k + 32 * s);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[s]), as_frag(b), acc[m], 0, 0, 0);
-        }
-      }
-    }
+      for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[s]), as_frag(bfrag[m][s]), acc[m], 0, 0, 0);
   }
 
   // C fragment: lane (g, c) holds y[m-tile col c][n0 + 4 g + i], i = 0..3
@@ -89,49 +90,53 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   }
 }
 
-template <int MT, int WAVES>
+template <int MT, int WAVES, int STEPS>
 static void launch(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y, int M, int N,
                    int K, hipStream_t st) {
   const size_t lds = (size_t)WAVES * MT * 256 * sizeof(float);
   if (bias)
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, WAVES, true>), dim3(N / 16), dim3(WAVES * 64), lds, st, x, w,
-                       bias, y, M, N, K);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, WAVES, STEPS, true>), dim3(N / 16), dim3(WAVES * 64), lds, st,
+                       x, w, bias, y, M, N, K);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, WAVES, false>), dim3(N / 16), dim3(WAVES * 64), lds, st, x, w,
-                       bias, y, M, N, K);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, WAVES, STEPS, false>), dim3(N / 16), dim3(WAVES * 64), lds, st,
+                       x, w, bias, y, M, N, K);
+}
+
+// STEPS k-steps (32 * STEPS elements of K) are in flight per wave and loop iteration.
+template <int MT, int WAVES>
+static bool try_waves(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y, int M, int N,
+                      int K, int want_steps, hipStream_t st) {
+  if (K % WAVES) return false;
+  const int kslice = K / WAVES;
+  constexpr int MAXS = MT <= 2 ? 8 : 4;  // register budget: (MT + 1) * STEPS fragments
+  if (MAXS >= 8 && want_steps >= 8 && kslice % 256 == 0) return launch<MT, WAVES, 8>(x, w, bias, y, M, N, K, st), true;
+  if (want_steps >= 4 && kslice % 128 == 0) return launch<MT, WAVES, 4>(x, w, bias, y, M, N, K, st), true;
+  if (want_steps >= 2 && kslice % 64 == 0) return launch<MT, WAVES, 2>(x, w, bias, y, M, N, K, st), true;
+  if (kslice % 32 == 0) return launch<MT, WAVES, 1>(x, w, bias, y, M, N, K, st), true;
+  return false;
 }
 
 template <int MT>
 static int pick_waves(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y, int M, int N,
                       int K, hipStream_t st) {
-  // K-slices of 256 (eight 1 KiB fragment loads in flight per wave) when K allows;
-  // keep at least 2 waves per workgroup so small-N layers still fill the CUs.
-  int waves = 1;
-  for (int c : {16, 12, 8, 6, 4, 3, 2}) {
-    if (K % (c * 32) == 0 && K / c >= 128) {
-      waves = c;
-      break;
-    }
+  // Few row tiles (N/16 < ~2 per CU): spread K over many waves so every CU slot holds loads;
+  // many row tiles (lm_head): fewer, fatter waves.
+  const int tiles = N / 16;
+  bool ok = false;
+  if (tiles >= 2048) {
+    ok = try_waves<MT, 4>(x, w, bias, y, M, N, K, 8, st) || try_waves<MT, 2>(x, w, bias, y, M, N, K, 8, st) ||
+         try_waves<MT, 1>(x, w, bias, y, M, N, K, 8, st);
+  } else if (K >= 2048) {
+    ok = (K % (16 * 128) == 0 && try_waves<MT, 16>(x, w, bias, y, M, N, K, 8, st)) ||
+         (K % (12 * 128) == 0 && try_waves<MT, 12>(x, w, bias, y, M, N, K, 8, st)) ||
+         try_waves<MT, 8>(x, w, bias, y, M, N, K, 8, st) || try_waves<MT, 4>(x, w, bias, y, M, N, K, 8, st);
+  } else {
+    ok = (K % (8 * 128) == 0 && try_waves<MT, 8>(x, w, bias, y, M, N, K, 8, st)) ||
+         (K % (4 * 128) == 0 && try_waves<MT, 4>(x, w, bias, y, M, N, K, 8, st)) ||
+         try_waves<MT, 2>(x, w, bias, y, M, N, K, 8, st);
   }
-  // large-N layers (lm_head) have plenty of workgroups: use fatter K-slices
-  if ((int64_t)N / 16 >= 2048) {
-    for (int c : {4, 3, 2, 1}) {
-      if (K % (c * 32) == 0 && K / c >= 256) {
-        waves = c;
-        break;
-      }
-    }
-  }
-  switch (waves) {
-    case 16: launch<MT, 16>(x, w, bias, y, M, N, K, st); break;
-    case 12: launch<MT, 12>(x, w, bias, y, M, N, K, st); break;
-    case 8: launch<MT, 8>(x, w, bias, y, M, N, K, st); break;
-    case 6: launch<MT, 6>(x, w, bias, y, M, N, K, st); break;
-    case 4: launch<MT, 4>(x, w, bias, y, M, N, K, st); break;
-    case 3: launch<MT, 3>(x, w, bias, y, M, N, K, st); break;
-    case 2: launch<MT, 2>(x, w, bias, y, M, N, K, st); break;
-    default: launch<MT, 1>(x, w, bias, y, M, N, K, st); break;
-  }
+  if (!ok) ok = try_waves<MT, 1>(x, w, bias, y, M, N, K, 8, st);
+  if (!ok) return MI_EUNSUPPORTED;
   return check_launch();
 }
 

@@ -27,10 +27,6 @@ __device__ __forceinline__ void load_tile(const uint16_t* __restrict__ tile, int
 #pragma unroll
   for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4*>(tile + i * 512 + lane * 8);
 }
-__device__ __forceinline__ void zero_tile(u32x4 (&f)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = u32x4{0, 0, 0, 0};
-}
 
 // Attend one chunk.  `limit`: tokens with index < limit are visible to this lane's column.
 __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
@@ -84,24 +80,25 @@ __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (
   }
 }
 
+// Issue the 16 fragment loads of chunk `c` (tiles 2c, 2c+1).  `c` and the table row are
+// wave-uniform, so the two block ids come from scalar loads and all vector loads are issued
+// back to back with no wait in between.  A second tile past the end of the context is
+// redirected to the (valid) first tile; its scores are masked by `limit`, so its bytes never
+// reach the output (p == 0 exactly) and no branch or zero-fill is needed.
 __device__ __forceinline__ void load_chunk(const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
                                            const int32_t* __restrict__ table_row, int c, int n_tiles, int h,
                                            int n_kv_heads, int tpb, int lane, u32x4 (&K0)[4], u32x4 (&K1)[4],
                                            u32x4 (&V0)[4], u32x4 (&V1)[4]) {
-  const int tile0 = 2 * c, tile1 = 2 * c + 1;
-  const int blk0 = __builtin_amdgcn_readfirstlane(table_row[tile0 / tpb]);
+  const int tile0 = 2 * c;
+  const int tile1 = (2 * c + 1 < n_tiles) ? 2 * c + 1 : tile0;
+  const int blk0 = table_row[tile0 / tpb];
+  const int blk1 = table_row[tile1 / tpb];
   const int64_t base0 = (((int64_t)blk0 * n_kv_heads + h) * tpb + (tile0 % tpb)) * MI_KV_TILE_ELEMS;
+  const int64_t base1 = (((int64_t)blk1 * n_kv_heads + h) * tpb + (tile1 % tpb)) * MI_KV_TILE_ELEMS;
   load_tile(kc + base0, lane, K0);
+  load_tile(kc + base1, lane, K1);
   load_tile(vc + base0, lane, V0);
-  if (tile1 < n_tiles) {
-    const int blk1 = __builtin_amdgcn_readfirstlane(table_row[tile1 / tpb]);
-    const int64_t base1 = (((int64_t)blk1 * n_kv_heads + h) * tpb + (tile1 % tpb)) * MI_KV_TILE_ELEMS;
-    load_tile(kc + base1, lane, K1);
-    load_tile(vc + base1, lane, V1);
-  } else {
-    zero_tile(K1);
-    zero_tile(V1);
-  }
+  load_tile(vc + base1, lane, V1);
 }
 
 // ---------------------------------------------------------------------------
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
   __shared__ float sm_l[4][16];
 
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, n = lane & 15;
   const int ctx = max(ctx_lens[b], 0);
   const int n_chunks = (ctx + 31) >> 5, n_tiles = (ctx + 15) >> 4;
@@ -130,8 +127,8 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const uint16_t* qp = q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 + 8 * g;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      u32x4 v = {0, 0, 0, 0};
-      if (n < G && c0 < c1) v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);  // n >= G reads head 0 (valid memory)
+      if (n >= G) v = u32x4{0, 0, 0, 0};
       Q[kk] = as_frag(v);
     }
   }
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     int n_q_heads, int n_kv_heads, int tpb, float scale_log2e) {
   constexpr int TQ = 16 / G;
   const int seq = blockIdx.z, h = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, n = lane & 15;
   const int q_start = cu_q[seq];
   const int q_len = cu_q[seq + 1] - q_start;
@@ -230,8 +227,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* qp = q + (int64_t)(q_start + (valid ? my_qt : qt0)) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * g;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      u32x4 v = {0, 0, 0, 0};
-      if (valid) v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);  // invalid columns read row qt0 (valid)
+      if (!valid) v = u32x4{0, 0, 0, 0};
       Q[kk] = as_frag(v);
     }
   }

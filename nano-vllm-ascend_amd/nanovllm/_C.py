@@ -87,6 +87,27 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.argtypes = _args
 
 
+if os.environ.get("MI355_TRACE"):  # debugging aid: name each launch, make faults synchronous
+    class _Traced:
+        def __init__(self, inner):
+            self._inner = inner
+
+        def __getattr__(self, name):
+            fn = getattr(self._inner, name)
+
+            def call(*args):
+                print(f"[mi355] {name}{tuple(a for a in args if isinstance(a, (int, float)) and abs(a) < 1 << 40)}",
+                      flush=True)
+                rc = fn(*args)
+                if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()
+                return rc
+
+            return call
+
+    lib = _Traced(lib)
+
+
 def version() -> str:
     return lib.mi_version().decode()
 

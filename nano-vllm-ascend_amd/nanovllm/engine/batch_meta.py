@@ -1,0 +1,98 @@
+"""Host-side step metadata: Python sequences -> flat integer arrays.
+
+These arrays are what reaches the device (input ids, positions, slot mappings,
+context lengths, block tables), so they are part of the bit-exact parity contract
+with the reference's ModelRunner.prepare_prefill (model_runner.py:238-290),
+prepare_decode (:344-366), prepare_decode_padding (:292-342) and
+prepare_block_tables (:231-236).  Pure numpy: testable without a GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from nanovllm.engine.sequence import Sequence
+
+
+@dataclass
+class PrefillMeta:
+    input_ids: np.ndarray      # int64 [T]
+    positions: np.ndarray      # int64 [T]
+    cu_seqlens_q: np.ndarray   # int32 [n+1]
+    cu_seqlens_k: np.ndarray   # int32 [n+1]
+    max_seqlen_q: int
+    max_seqlen_k: int
+    slot_mapping: np.ndarray   # int32 [T]   flat: block_id*block_size + offset
+    block_tables: np.ndarray   # int32 [n, W]  -1 padded
+    kv_lens: np.ndarray        # int32 [n]
+
+
+@dataclass
+class DecodeMeta:
+    input_ids: np.ndarray      # int64 [B]
+    positions: np.ndarray      # int64 [B]
+    context_lens: np.ndarray   # int32 [B]
+    slot_mapping: np.ndarray   # int32 [B, 2]  [block_id, offset]
+    block_tables: np.ndarray   # int32 [B, W]
+    real_bs: int
+
+
+def block_table_matrix(seqs: list[Sequence], rows: int | None = None, cols: int | None = None) -> np.ndarray:
+    """-1 padded [rows, cols] table; defaults: one row per sequence, widest table."""
+    width = max((len(s.block_table) for s in seqs), default=0)
+    cols = width if cols is None else cols
+    rows = len(seqs) if rows is None else rows
+    out = np.full((rows, max(cols, 1) if cols == 0 else cols), -1, dtype=np.int32)
+    for i, s in enumerate(seqs):
+        n = min(len(s.block_table), cols)
+        if n:
+            out[i, :n] = s.block_table[:n]
+    return out
+
+
+def prefill_meta(seqs: list[Sequence], block_size: int) -> PrefillMeta:
+    """Every token of every scheduled sequence is (re)computed — cached prefix blocks are
+    not skipped (model_runner.py:248-249) — and positions restart at 0 per sequence."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    cu = np.zeros(len(seqs) + 1, dtype=np.int32)
+    np.cumsum(lens, out=cu[1:])
+    total = int(cu[-1])
+    ids = np.empty(total, dtype=np.int64)
+    pos = np.empty(total, dtype=np.int64)
+    slots = np.empty(total, dtype=np.int32)
+    within = np.arange(int(lens.max()) if len(seqs) else 0, dtype=np.int64)
+    for s, a, n in zip(seqs, cu[:-1], lens):
+        a, n = int(a), int(n)
+        ids[a:a + n] = s.token_ids
+        pos[a:a + n] = within[:n]
+        if s.block_table:
+            table = np.asarray(s.block_table[: s.num_blocks], dtype=np.int64)
+            slots[a:a + n] = (table[within[:n] // block_size] * block_size + within[:n] % block_size)
+        else:
+            slots[a:a + n] = -1
+    mx = int(lens.max()) if len(seqs) else 0
+    return PrefillMeta(ids, pos, cu, cu.copy(), mx, mx, slots, block_table_matrix(seqs), lens.astype(np.int32))
+
+
+def decode_meta(seqs: list[Sequence], pad_to: int | None = None, dummy_block: int = 0,
+                table_cols: int | None = None) -> DecodeMeta:
+    """One new token per sequence.  With `pad_to` (graph mode) rows beyond the real batch
+    are token 0 / position 0 / context_len 0 / slot [dummy_block, 0] and the table is a
+    static [pad_to, table_cols] matrix of -1 (model_runner.py:303-331)."""
+    real = len(seqs)
+    rows = real if pad_to is None else pad_to
+    ids = np.zeros(rows, dtype=np.int64)
+    pos = np.zeros(rows, dtype=np.int64)
+    ctx = np.zeros(rows, dtype=np.int32)
+    slot = np.empty((rows, 2), dtype=np.int32)
+    slot[:, 0], slot[:, 1] = dummy_block, 0
+    for i, s in enumerate(seqs):
+        n = s.num_tokens
+        ids[i] = s.last_token
+        pos[i] = n - 1
+        ctx[i] = n
+        slot[i, 0] = s.block_table[-1]
+        slot[i, 1] = s.last_block_num_tokens - 1
+    tables = block_table_matrix(seqs, rows=rows, cols=table_cols)
+    return DecodeMeta(ids, pos, ctx, slot, tables, real)

@@ -1,0 +1,140 @@
+"""Paged-KV block allocator with chained-hash prefix caching
+(reference: nanovllm/engine/block_manager.py:26-118; semantics in SURVEY.md §9).
+
+Block tables are part of the parity contract: for the same request stream this
+allocator must hand out the same block ids, in the same order, as the reference's.
+The rules it reproduces:
+  * free list is FIFO (initially 0..N-1); a miss takes its head; freed ids go to the tail,
+    and a sequence's blocks are released last-block-first;
+  * only full blocks are hashed: xxh64(prev_hash as 8 LE bytes, then the tokens as int64 LE);
+    a hit needs the hash AND equal token ids; after the first miss every later block misses;
+  * a freed block keeps its hash/tokens until it is handed out again, so it can be revived;
+  * decode: a new block is taken when len % block_size == 1, and a block is sealed (hashed,
+    registered) when len % block_size == 0.
+
+The hash itself is computed by the C ABI's mi_xxh64_chain (the reference calls the
+`xxhash` pip package; tests pin both against the reference's known answers).
+"""
+from __future__ import annotations
+
+from array import array
+from collections import deque
+
+from nanovllm._C import xxh64_chain
+from nanovllm.engine.sequence import Sequence
+
+_NO_HASH = -1
+
+
+class Block:
+    __slots__ = ("block_id", "ref_count", "hash", "token_ids")
+
+    def __init__(self, block_id: int):
+        self.block_id = block_id
+        self.ref_count = 0
+        self.hash = _NO_HASH
+        self.token_ids: list[int] = []
+
+    def update(self, hash: int, token_ids: list[int]) -> None:
+        self.hash, self.token_ids = hash, token_ids
+
+    def reset(self) -> None:
+        self.ref_count, self.hash, self.token_ids = 1, _NO_HASH, []
+
+
+class BlockManager:
+    def __init__(self, num_blocks: int, block_size: int, non_cache_token_ids: list[int] | None = None):
+        self.block_size = block_size
+        self.blocks = [Block(i) for i in range(num_blocks)]
+        self.hash_to_block_id: dict[int, int] = {}
+        self.free_block_ids: deque[int] = deque(range(num_blocks))
+        self.used_block_ids: set[int] = set()
+        self.non_cache_token_ids = set(non_cache_token_ids or ())
+
+    # -- hashing ---------------------------------------------------------------------------------
+    @classmethod
+    def compute_hash(cls, token_ids: list[int], prefix: int = _NO_HASH) -> int:
+        return xxh64_chain(array("q", token_ids).tobytes(), prefix)
+
+    # -- block bookkeeping -----------------------------------------------------------------------
+    def _take(self, block_id: int) -> Block:
+        blk = self.blocks[block_id]
+        assert blk.ref_count == 0
+        blk.reset()
+        self.free_block_ids.remove(block_id)
+        self.used_block_ids.add(block_id)
+        return blk
+
+    def _release(self, block_id: int) -> None:
+        assert self.blocks[block_id].ref_count == 0
+        self.used_block_ids.discard(block_id)
+        self.free_block_ids.append(block_id)
+
+    # reference names kept as aliases (ut/ tests of the reference poke at them)
+    _allocate_block = _take
+    _deallocate_block = _release
+
+    # -- prefill -----------------------------------------------------------------------------------
+    def can_allocate(self, seq: Sequence) -> bool:
+        return len(self.free_block_ids) >= seq.num_blocks
+
+    def allocate(self, seq: Sequence) -> None:
+        assert not seq.block_table
+        bs, lookup = self.block_size, self.hash_to_block_id
+        chain, missed = _NO_HASH, False
+        for i in range(seq.num_blocks):
+            toks = seq.block(i)
+            if self.non_cache_token_ids and not self.non_cache_token_ids.isdisjoint(toks):
+                missed = True
+            chain = self.compute_hash(toks, chain) if len(toks) == bs else _NO_HASH
+            hit_id = lookup.get(chain, -1)
+            if hit_id == -1 or self.blocks[hit_id].token_ids != toks:
+                missed = True
+            if missed:
+                hit_id = self.free_block_ids[0]
+                blk = self._take(hit_id)
+            else:
+                seq.num_cached_tokens += bs
+                if hit_id in self.used_block_ids:
+                    blk = self.blocks[hit_id]
+                    blk.ref_count += 1
+                else:  # freed but not yet recycled: revive it
+                    blk = self._take(hit_id)
+            if chain != _NO_HASH:
+                blk.update(chain, toks)
+                lookup[chain] = hit_id
+            seq.block_table.append(hit_id)
+
+    def deallocate(self, seq: Sequence) -> None:
+        for block_id in reversed(seq.block_table):
+            blk = self.blocks[block_id]
+            blk.ref_count -= 1
+            if blk.ref_count == 0:
+                self._release(block_id)
+        seq.block_table.clear()
+
+    # -- decode ------------------------------------------------------------------------------------
+    def can_append(self, seq: Sequence) -> bool:
+        needs_block = len(seq) % self.block_size == 1
+        return len(self.free_block_ids) >= int(needs_block)
+
+    def may_append(self, seq: Sequence) -> None:
+        """Called after the previous step's append_token: len(seq) already counts the token
+        whose KV row this step writes."""
+        table = seq.block_table
+        tail = self.blocks[table[-1]]
+        rem = len(seq) % self.block_size
+        if rem == 1:  # the new token opens a block
+            assert tail.hash != _NO_HASH
+            new_id = self.free_block_ids[0]
+            self._take(new_id)
+            table.append(new_id)
+        elif rem == 0:  # the new token fills the tail block: seal it
+            assert tail.hash == _NO_HASH
+            toks = seq.block(seq.num_blocks - 1)
+            prev = self.blocks[table[-2]].hash if len(table) > 1 else _NO_HASH
+            h = self.compute_hash(toks, prev)
+            tail.update(h, toks)
+            self.hash_to_block_id[h] = tail.block_id
+        else:
+            assert tail.hash == _NO_HASH

@@ -1,0 +1,174 @@
+"""Engine loop (reference: nanovllm/engine/llm_engine.py:28-175, text path).
+
+`LLM(model_dir, **Config kwargs)`, `add_request`, `step() -> (finished, ±num_tokens)`,
+`is_finished`, `abort_request`, `generate(prompts | token ids, SamplingParams)` keep the
+reference's shapes: step() returns +prefill tokens / -decode sequences so callers derive
+throughput (llm_engine.py:126) and generate() returns
+[{"text","token_ids","prompt_len","cache_tokens"}] ordered by sequence id (:170-173).
+
+Tensor-parallel ranks: either spawned here as child processes (the reference's mode,
+:39-45) or already running (`torchrun`: WORLD_SIZE set) — then only rank 0 constructs an
+engine and the other ranks call `run_worker(model, **kwargs)`.
+
+TTFT is recorded per request as (end of the prefill step that produced its first token
+- add_request time), the definition of bench/serving_bench.py:35-48,112-121.
+"""
+from __future__ import annotations
+
+import atexit
+import os
+from dataclasses import fields
+from random import randint
+from time import perf_counter
+
+import torch.multiprocessing as mp
+
+from nanovllm.config import Config
+from nanovllm.engine.model_runner import ModelRunner
+from nanovllm.engine.scheduler import Scheduler
+from nanovllm.engine.sequence import Sequence
+from nanovllm.sampling_params import SamplingParams
+
+
+def _make_config(model, kwargs) -> Config:
+    names = {f.name for f in fields(Config)}
+    return Config(model, **{k: v for k, v in kwargs.items() if k in names})
+
+
+def _externally_launched() -> bool:
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ
+
+
+def _worker_entry(config: Config, rank: int):
+    ModelRunner(config, rank).loop()
+
+
+def run_worker(model, **kwargs) -> None:
+    """Body of ranks > 0 when the ranks were started by torchrun."""
+    config = _make_config(model, kwargs)
+    ModelRunner(config, int(os.environ["RANK"])).loop()
+
+
+class LLMEngine:
+    def __init__(self, model, **kwargs):
+        config = _make_config(model, kwargs)
+        self.config = config
+        self.block_size = config.kvcache_block_size
+        self.ps = []
+        if config.tensor_parallel_size > 1 and not _externally_launched():
+            ctx = mp.get_context("spawn")
+            for rank in range(1, config.tensor_parallel_size):
+                p = ctx.Process(target=_worker_entry, args=(config, rank))
+                p.start()
+                self.ps.append(p)
+        self.model_runner = ModelRunner(config, 0)
+        self.tokenizer = self._load_tokenizer(config)
+        if self.tokenizer is not None and self.tokenizer.eos_token_id is not None:
+            config.eos = self.tokenizer.eos_token_id
+        self.scheduler = Scheduler(config)
+        self.ttft: dict[int, float] = {}
+        self._exited = False
+        if kwargs.get("warmup", True):
+            self.warmup_model()
+        atexit.register(self.exit)
+
+    @staticmethod
+    def _load_tokenizer(config: Config):
+        files = ("tokenizer.json", "tokenizer_config.json", "vocab.json", "tokenizer.model")
+        if not any(os.path.exists(os.path.join(config.model, f)) for f in files):
+            return None  # synthetic mode: token-id prompts only
+        from transformers import AutoTokenizer
+
+        return AutoTokenizer.from_pretrained(config.model, use_fast=True)
+
+    # ------------------------------------------------------------------ warm-up (llm_engine.py:53-87)
+    def warmup_model(self):
+        cfg = self.config
+        n = max(1, min(cfg.max_num_batched_tokens // cfg.max_model_len, cfg.max_num_seqs))
+        prompts = [[randint(0, 10000) % self._vocab() for _ in range(cfg.max_model_len)] for _ in range(n)]
+        self.generate(prompts, SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=1), use_tqdm=False)
+        prompts = [[randint(0, 10000) % self._vocab() for _ in range(randint(10, 50))]
+                   for _ in range(cfg.max_num_seqs)]
+        self.generate(prompts, SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=2), use_tqdm=False)
+        self.ttft.clear()
+
+    def _vocab(self) -> int:
+        text = getattr(self.config.hf_config, "text_config", self.config.hf_config)
+        return text.vocab_size
+
+    def exit(self):
+        if self._exited:
+            return
+        self._exited = True
+        self.model_runner.call("exit")
+        del self.model_runner
+        for p in self.ps:
+            p.join()
+
+    # ------------------------------------------------------------------ requests
+    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams, request_id: str | None = None):
+        if isinstance(prompt, str):
+            if self.tokenizer is None:
+                raise ValueError("this model directory has no tokenizer: pass token ids")
+            prompt = self.tokenizer.encode(prompt)
+        seq = Sequence(prompt, sampling_params, request_id=request_id, block_size=self.block_size)
+        seq.arrival_time = perf_counter()
+        self.scheduler.add(seq)
+        return seq
+
+    def abort_request(self, request_id: str) -> None:
+        self.scheduler.abort_seq_group(request_id)
+
+    def is_finished(self) -> bool:
+        return self.scheduler.is_finished()
+
+    def step(self):
+        seqs, is_prefill = self.scheduler.schedule()
+        token_ids = self.model_runner.call("run", seqs, is_prefill)
+        if is_prefill:
+            now = perf_counter()
+            for s in seqs:
+                if s.num_completion_tokens == 0 and s.seq_id not in self.ttft:
+                    s.first_token_time = now
+                    self.ttft[s.seq_id] = now - s.arrival_time
+        self.scheduler.postprocess(seqs, token_ids)
+        outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
+                   for s in seqs if s.is_finished]
+        num_tokens = sum(len(s) for s in seqs) if is_prefill else -len(seqs)
+        return outputs, num_tokens
+
+    def generate(self, prompts, sampling_params, use_tqdm: bool = True):
+        pbar = None
+        if use_tqdm:
+            from tqdm.auto import tqdm
+
+            pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True)
+        if not isinstance(sampling_params, list):
+            sampling_params = [sampling_params] * len(prompts)
+        for prompt, sp in zip(prompts, sampling_params):
+            self.add_request(prompt, sp)
+        done = {}
+        prefill_tps = decode_tps = 0.0
+        while not self.is_finished():
+            t = perf_counter()
+            finished, num_tokens = self.step()
+            dt = perf_counter() - t
+            if num_tokens > 0:
+                prefill_tps = num_tokens / dt
+            elif num_tokens < 0:
+                decode_tps = -num_tokens / dt
+            if pbar is not None:
+                pbar.set_postfix({"Prefill": f"{int(prefill_tps)}tok/s", "Decode": f"{int(decode_tps)}tok/s"})
+            for seq_id, token_ids, prompt_len, cache_tokens in finished:
+                done[seq_id] = (token_ids, prompt_len, cache_tokens)
+                if pbar is not None:
+                    pbar.update(1)
+        if pbar is not None:
+            pbar.close()
+        out = []
+        for seq_id in sorted(done):
+            token_ids, prompt_len, cache_tokens = done[seq_id]
+            text = self.tokenizer.decode(token_ids) if self.tokenizer is not None else ""
+            out.append({"text": text, "token_ids": token_ids, "prompt_len": prompt_len,
+                        "cache_tokens": cache_tokens})
+        return out

@@ -1,0 +1,317 @@
+"""Device-side executor of one TP rank (reference: nanovllm/engine/model_runner.py).
+
+Role for role the same as the reference class — build + load the model, size and
+allocate the paged KV cache, turn scheduled sequences into device metadata, run the
+model eagerly (prefill) or by replaying a captured device graph (decode), sample on
+rank 0 — re-designed for one MI355X per process:
+
+  * step metadata is assembled on the host by engine/batch_meta.py (bit-exact with the
+    reference's prepare_* lists) directly into ONE pinned staging buffer and reaches the
+    GPU with ONE async copy per decode step (the reference does 5-6, :354-357,:234);
+  * decode steps are hipGraphs captured per batch bucket (1,2,4,...,max_num_seqs) with
+    torch.cuda.CUDAGraph on the stream the C-ABI kernels are enqueued on — the
+    counterpart of the torchair "reduce-overhead" capture (:150-154).  Padded rows use
+    context_len 0 and the dummy slot in the reserved last block exactly as :303-311;
+  * tensor-parallel ranks are separate processes joined by an RCCL ("nccl") group;
+    rank 0 publishes each step to the workers through a shared-memory seqlock carrying
+    compact int64 arrays (engine/rpc.py) instead of a pickled Sequence list (:172-187).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from nanovllm.config import Config
+from nanovllm.engine import batch_meta
+from nanovllm.engine.rpc import StepChannel
+from nanovllm.engine.sequence import Sequence
+from nanovllm.layers.sampler import Sampler
+from nanovllm.models.models_map import model_dict
+from nanovllm.utils.context import reset_context, set_context
+from nanovllm.utils.loader import has_checkpoint, init_synthetic_weights, load_model
+
+
+def _torch_dtype_of(hf_config) -> torch.dtype:
+    text = getattr(hf_config, "text_config", hf_config)
+    dt = getattr(text, "torch_dtype", None) or getattr(text, "dtype", None)
+    if isinstance(dt, str):
+        dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "float16": torch.float16,
+              "fp16": torch.float16, "float32": torch.float32}.get(dt.lower(), getattr(torch, dt, None))
+    return dt or torch.bfloat16
+
+
+def graph_buckets(max_num_seqs: int) -> list[int]:
+    b, out = 1, []
+    while b < max_num_seqs:
+        out.append(b)
+        b *= 2
+    out.append(max_num_seqs)
+    return out
+
+
+class ModelRunner:
+    def __init__(self, config: Config, rank: int, event=None):
+        self.config = config
+        self.hf_config = config.hf_config
+        self.block_size = config.kvcache_block_size
+        self.enforce_eager = config.enforce_eager
+        self.world_size = config.tensor_parallel_size
+        self.rank = rank
+        self.event = event
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("nanovllm (MI355X build) needs a HIP device: there is no CPU execution path")
+        local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
+        self.device = torch.device("cuda", local)
+        torch.cuda.set_device(self.device)
+        if self.world_size > 1 and not dist.is_initialized():
+            # backend "nccl" is RCCL on ROCm; rendezvous on the loopback interface
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{config.hccl_port}",
+                                    world_size=self.world_size, rank=rank, device_id=self.device)
+        self.channel = StepChannel(config.hccl_port, self.world_size, rank) if self.world_size > 1 else None
+
+        dtype = _torch_dtype_of(self.hf_config)
+        if dtype != torch.bfloat16:
+            raise NotImplementedError(f"the gfx950 kernels are bf16; checkpoint dtype is {dtype}")
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            with torch.device(self.device):
+                arch = self.hf_config.architectures[0] if getattr(self.hf_config, "architectures", None) \
+                    else "Qwen3ForCausalLM"
+                self.model = model_dict[arch](self.hf_config)
+        finally:
+            torch.set_default_dtype(prev)
+        if has_checkpoint(config.model):
+            load_model(self.model, config.model)
+            self.synthetic = False
+        else:
+            init_synthetic_weights(self.model, self.hf_config, seed=config.synthetic_seed)
+            self.synthetic = True
+        self.model.eval()
+        self.sampler = Sampler(seed=config.synthetic_seed)
+        torch.cuda.empty_cache()
+        self.allocate_kv_cache()
+        self._alloc_staging()
+        self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
+        self.graph_logits: dict[int, torch.Tensor] = {}
+        if config.use_graphs:
+            self.capture_decode_graphs()
+        if self.world_size > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ lifecycle / RPC
+    def exit(self):
+        self.graphs.clear()
+        self.graph_logits.clear()
+        torch.cuda.synchronize()
+        if self.channel is not None:
+            dist.barrier()
+            self.channel.close()
+        if self.world_size > 1 and dist.is_initialized():
+            dist.destroy_process_group()
+
+    def loop(self):
+        """TP worker main loop (rank > 0): execute whatever rank 0 publishes."""
+        while True:
+            method, seqs, is_prefill = self.channel.recv()
+            if method == "exit":
+                self.exit()
+                return
+            self.run(seqs, is_prefill)
+
+    def call(self, method_name: str, *args):
+        if self.channel is not None and self.rank == 0:
+            self.channel.send(method_name, *args)
+        return getattr(self, method_name)(*args)
+
+    # ------------------------------------------------------------------ KV cache
+    def allocate_kv_cache(self):
+        """model_runner.py:195-229: size from free memory, ONE tensor [2, L, ...], per-layer
+        slices bound to every module that has k_cache/v_cache.  Layout per layer is the
+        fragment-native [nblk, Hkv, block/16, 2048] of include/mi355_nanovllm.h."""
+        cfg, hf = self.config, getattr(self.hf_config, "text_config", self.hf_config)
+        free, total = torch.cuda.mem_get_info(self.device)
+        used = total - free
+        stats = torch.cuda.memory_stats(self.device)
+        peak = stats.get("allocated_bytes.all.peak", 0)
+        current = stats.get("allocated_bytes.all.current", 0)
+        n_kv = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        layers = hf.num_hidden_layers
+        block_bytes = 2 * layers * self.block_size * n_kv * head_dim * 2
+        if cfg.num_kvcache_blocks <= 0:
+            available = total * cfg.gpu_memory_utilization - used - peak + current
+            cfg.num_kvcache_blocks = int(available) // block_bytes
+        assert cfg.num_kvcache_blocks > 0, "no memory left for even one KV cache block"
+        self.kv_cache = torch.zeros((2, layers, cfg.num_kvcache_blocks, n_kv, self.block_size // 16, 2048),
+                                    dtype=torch.bfloat16, device=self.device)
+        layer_id = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache = self.kv_cache[0, layer_id]
+                module.v_cache = self.kv_cache[1, layer_id]
+                layer_id += 1
+        assert layer_id == layers
+
+    # ------------------------------------------------------------------ staging buffers
+    def _alloc_staging(self):
+        cfg = self.config
+        B = cfg.max_num_seqs
+        W = -(-(cfg.max_model_len + 1) // self.block_size)  # a max-length prompt still decodes one token
+        self.table_cols = W
+        # [ids i64 B][pos i64 B][temps f32 B][ctx i32 B][slots i32 2B][tables i32 B*W]
+        off, spans = 0, {}
+        for name, nbytes in (("ids", 8 * B), ("pos", 8 * B), ("temps", 4 * B), ("ctx", 4 * B),
+                             ("slots", 8 * B), ("tables", 4 * B * W)):
+            spans[name] = (off, nbytes)
+            off += (nbytes + 15) // 16 * 16
+        self._stage_bytes = off
+        self.host_stage = torch.empty(off, dtype=torch.uint8, pin_memory=True)
+        self.dev_stage = torch.zeros(off, dtype=torch.uint8, device=self.device)
+
+        def views(buf):
+            def v(name, dtype, shape):
+                o, n = spans[name]
+                return buf[o:o + n].view(dtype).view(shape)
+            return {"ids": v("ids", torch.int64, (B,)), "pos": v("pos", torch.int64, (B,)),
+                    "temps": v("temps", torch.float32, (B,)), "ctx": v("ctx", torch.int32, (B,)),
+                    "slots": v("slots", torch.int32, (B, 2)), "tables": v("tables", torch.int32, (B, W))}
+
+        self.dev = views(self.dev_stage)
+        self.host = {k: t.numpy() for k, t in views(self.host_stage).items()}
+        self.host["tables"][:] = -1
+        self._row_owner = [(-1, 0)] * B  # (seq_id, blocks written) per table row
+        self.tokens_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
+        self.tokens_host = torch.zeros(B, dtype=torch.int64, pin_memory=True)
+
+    def _fill_decode_stage(self, seqs: list[Sequence], bucket: int):
+        """Same values as batch_meta.decode_meta(seqs, pad_to=bucket, ...), written in place;
+        block-table rows are updated incrementally (a row changes by at most one entry per step)."""
+        h = self.host
+        real = len(seqs)
+        dummy = self.config.num_kvcache_blocks - 1
+        for i, s in enumerate(seqs):
+            n = s.num_tokens
+            h["ids"][i] = s.last_token
+            h["pos"][i] = n - 1
+            h["ctx"][i] = n
+            h["slots"][i, 0] = s.block_table[-1]
+            h["slots"][i, 1] = s.last_block_num_tokens - 1
+            h["temps"][i] = 0.0 if s.greedy else s.temperature
+            owner, written = self._row_owner[i]
+            nb = len(s.block_table)
+            if owner == s.seq_id and written <= nb:
+                if written < nb:
+                    h["tables"][i, written:nb] = s.block_table[written:nb]
+            else:
+                row = h["tables"][i]
+                row[:nb] = s.block_table
+                row[nb:] = -1
+            self._row_owner[i] = (s.seq_id, nb)
+        if bucket > real:
+            h["ids"][real:bucket] = 0
+            h["pos"][real:bucket] = 0
+            h["ctx"][real:bucket] = 0
+            h["slots"][real:bucket, 0] = dummy
+            h["slots"][real:bucket, 1] = 0
+            for i in range(real, bucket):
+                if self._row_owner[i][0] != -1:
+                    h["tables"][i] = -1
+                    self._row_owner[i] = (-1, 0)
+        self.dev_stage.copy_(self.host_stage, non_blocking=True)
+
+    # ------------------------------------------------------------------ metadata -> context
+    def prepare_prefill(self, seqs: list[Sequence]):
+        m = batch_meta.prefill_meta(seqs, self.block_size)
+
+        def up(a):
+            return torch.from_numpy(a).pin_memory().to(self.device, non_blocking=True)
+
+        set_context(True, cu_seqlens_q=up(m.cu_seqlens_q), cu_seqlens_k=up(m.cu_seqlens_k),
+                    max_seqlen_q=m.max_seqlen_q, max_seqlen_k=m.max_seqlen_k, slot_mapping=up(m.slot_mapping),
+                    context_lens=None, block_tables=up(m.block_tables), block_size=self.block_size,
+                    kv_lens=up(m.kv_lens))
+        return up(m.input_ids), up(m.positions)
+
+    def prepare_decode(self, seqs: list[Sequence], bucket: int | None = None):
+        """Eager decode uses the same staging buffers with bucket == real batch."""
+        real = len(seqs)
+        bucket = bucket or real
+        self._fill_decode_stage(seqs, bucket)
+        d = self.dev
+        set_context(False, slot_mapping=d["slots"][:bucket], context_lens=d["ctx"][:bucket],
+                    block_tables=d["tables"][:bucket], is_enforce_eager=not self.config.use_graphs,
+                    real_bs=real, block_size=self.block_size)
+        return d["ids"][:bucket], d["pos"][:bucket]
+
+    def prepare_sample(self, seqs: list[Sequence]):
+        t = torch.tensor([0.0 if s.greedy else s.temperature for s in seqs], dtype=torch.float32).pin_memory()
+        return t.to(self.device, non_blocking=True)
+
+    # ------------------------------------------------------------------ graphs
+    @torch.inference_mode()
+    def capture_decode_graphs(self):
+        cfg, d = self.config, self.dev
+        # neutral metadata: every row padded (context_len 0, dummy slot)
+        self._fill_decode_stage([], cfg.max_num_seqs)
+        pool = None
+        for bs in reversed(graph_buckets(cfg.max_num_seqs)):
+            set_context(False, slot_mapping=d["slots"][:bs], context_lens=d["ctx"][:bs],
+                        block_tables=d["tables"][:bs], is_enforce_eager=False, real_bs=bs,
+                        block_size=self.block_size)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up run outside capture (workspaces, RCCL channels)
+                self.model.compute_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=pool):
+                logits = self.model.compute_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
+            pool = pool or graph.pool()
+            self.graphs[bs] = graph
+            self.graph_logits[bs] = logits
+        reset_context()
+        torch.cuda.synchronize()
+
+    def _bucket_for(self, n: int) -> int | None:
+        for b in sorted(self.graphs):
+            if b >= n:
+                return b
+        return None
+
+    # ------------------------------------------------------------------ one step
+    @torch.inference_mode()
+    def run_model(self, input_ids: torch.Tensor, positions: torch.Tensor, is_prefill: bool, bucket: int | None):
+        if is_prefill or bucket is None or bucket not in self.graphs:
+            return self.model.compute_logits(self.model(input_ids, positions))
+        self.graphs[bucket].replay()
+        return self.graph_logits[bucket]
+
+    @torch.inference_mode()
+    def run(self, seqs: list[Sequence], is_prefill: bool) -> list[int] | None:
+        if not seqs:  # everything got preempted this step (reference would crash)
+            return []
+        real = len(seqs)
+        if is_prefill:
+            input_ids, positions = self.prepare_prefill(seqs)
+            bucket = None
+            temps = self.prepare_sample(seqs) if self.rank == 0 else None
+        else:
+            bucket = self._bucket_for(real) if self.graphs else None
+            input_ids, positions = self.prepare_decode(seqs, bucket)
+            temps = self.dev["temps"][:real]
+        logits = self.run_model(input_ids, positions, is_prefill, bucket)
+        self.last_logits = logits  # debugging / parity hook (a reference, not a copy)
+        tokens = None
+        if self.rank == 0:
+            self.sampler(logits, temps, out=self.tokens_dev[:real])
+            self.tokens_host[:real].copy_(self.tokens_dev[:real], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            tokens = self.tokens_host[:real].tolist()
+        reset_context()
+        return tokens

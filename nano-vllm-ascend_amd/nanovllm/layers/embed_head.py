@@ -1,0 +1,52 @@
+"""Vocab-parallel embedding and LM head (reference: nanovllm/layers/embed_head.py)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from nanovllm import ops
+from nanovllm.layers.linear import linear_forward
+from nanovllm.layers.parallel import all_reduce_sum, tp_rank, tp_size
+from nanovllm.utils.context import get_context
+
+
+class VocabParallelEmbedding(nn.Module):
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.tp_rank = tp_rank()
+        self.tp_size = tp_size()
+        assert num_embeddings % self.tp_size == 0
+        self.num_embeddings = num_embeddings
+        self.num_embeddings_per_partition = num_embeddings // self.tp_size
+        self.vocab_start_idx = self.num_embeddings_per_partition * self.tp_rank
+        self.vocab_end_idx = self.vocab_start_idx + self.num_embeddings_per_partition
+        self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim))
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        rows = param.data.size(0)
+        param.data.copy_(loaded_weight.narrow(0, self.tp_rank * rows, rows))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """embed_head.py:34-42: the kernel applies the vocab-range mask (rows owned by other
+        ranks come out zero), then the partial embeddings are summed over ranks."""
+        y = ops.embedding(x, self.weight, self.vocab_start_idx)
+        return all_reduce_sum(y)
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False):
+        assert not bias
+        super().__init__(num_embeddings, embedding_dim)
+
+    def forward(self, x: torch.Tensor):
+        context = get_context()
+        if context.is_prefill:  # keep only each sequence's last token (embed_head.py:58-60)
+            x = ops.gather_last_tokens(x, context.cu_seqlens_q)
+        logits = linear_forward(x, self.weight, None)
+        if self.tp_size > 1:  # vocab shards -> rank 0 (embed_head.py:62-65)
+            parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+            dist.gather(logits, parts, 0)
+            logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
+        return logits

@@ -1,0 +1,114 @@
+"""Tensor-parallel linear layers (reference: nanovllm/layers/linear.py) — same class
+names, constructor arguments and per-parameter `weight_loader` sharding rules.
+
+forward(): activations with at most 64 rows (every decode step) go through the
+hand-written weight-streaming MFMA kernel mi_gemm_bf16_skinny; larger prefill batches
+are plain compute-bound GEMMs and use the library GEMM behind F.linear (hipBLASLt).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from nanovllm import ops
+from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
+
+
+def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    rows = x.numel() // x.shape[-1]
+    if rows <= ops.SKINNY_MAX_M and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0:
+        return ops.gemm_skinny(x, weight, bias)
+    ops.require_gpu(x, weight)
+    return F.linear(x, weight, bias)
+
+
+class LinearBase(nn.Module):
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, tp_dim: int | None = None):
+        super().__init__()
+        self.tp_dim = tp_dim
+        self.tp_rank = tp_rank()
+        self.tp_size = tp_size()
+        self.weight = nn.Parameter(torch.empty(output_size, input_size))
+        self.weight.weight_loader = self.weight_loader
+        if bias:
+            self.bias = nn.Parameter(torch.empty(output_size))
+            self.bias.weight_loader = self.weight_loader
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class ReplicatedLinear(LinearBase):
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        super().__init__(input_size, output_size, bias)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        param.data.copy_(loaded_weight)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return linear_forward(x, self.weight, self.bias)
+
+
+class ColumnParallelLinear(LinearBase):
+    """Output features sharded over ranks (linear.py:54-73)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        super().__init__(input_size, divide(output_size, tp_size()), bias, 0)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        rows = param.data.size(self.tp_dim)
+        param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * rows, rows))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return linear_forward(x, self.weight, self.bias)
+
+
+class MergedColumnParallelLinear(ColumnParallelLinear):
+    """Several column-parallel matrices stacked along dim 0, e.g. gate|up (linear.py:76-93)."""
+
+    def __init__(self, input_size: int, output_sizes: list[int], bias: bool = False):
+        self.output_sizes = output_sizes
+        super().__init__(input_size, sum(output_sizes), bias)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: int):
+        offset = sum(self.output_sizes[:loaded_shard_id]) // self.tp_size
+        size = self.output_sizes[loaded_shard_id] // self.tp_size
+        dst = param.data.narrow(self.tp_dim, offset, size)
+        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+
+
+class QKVParallelLinear(ColumnParallelLinear):
+    """Packed q|k|v projection, heads sharded over ranks (linear.py:96-128)."""
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
+                 total_num_kv_heads: int | None = None, bias: bool = False):
+        total_num_kv_heads = total_num_kv_heads or total_num_heads
+        self.head_size = head_size
+        self.num_heads = divide(total_num_heads, tp_size())
+        self.num_kv_heads = divide(total_num_kv_heads, tp_size())
+        super().__init__(hidden_size, (total_num_heads + 2 * total_num_kv_heads) * head_size, bias)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: str):
+        assert loaded_shard_id in ("q", "k", "v")
+        q_rows, kv_rows = self.num_heads * self.head_size, self.num_kv_heads * self.head_size
+        offset, size = {"q": (0, q_rows), "k": (q_rows, kv_rows), "v": (q_rows + kv_rows, kv_rows)}[loaded_shard_id]
+        dst = param.data.narrow(self.tp_dim, offset, size)
+        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+
+
+class RowParallelLinear(LinearBase):
+    """Input features sharded; partial sums all-reduced (linear.py:131-153)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        super().__init__(divide(input_size, tp_size()), output_size, bias, 1)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        cols = param.data.size(self.tp_dim)
+        param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * cols, cols))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = linear_forward(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        return all_reduce_sum(y)

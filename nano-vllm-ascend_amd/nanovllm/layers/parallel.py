@@ -1,0 +1,29 @@
+"""Tensor-parallel helpers shared by the layers (rank / world size of the TP group).
+
+One process per GPU; the group is the default torch.distributed group whose "nccl"
+backend is RCCL over xGMI on ROCm.  With tensor_parallel_size == 1 no process group
+is needed at all.
+"""
+from __future__ import annotations
+
+import torch.distributed as dist
+
+
+def tp_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def tp_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def divide(numerator: int, denominator: int) -> int:
+    assert numerator % denominator == 0, f"{numerator} is not divisible by {denominator}"
+    return numerator // denominator
+
+
+def all_reduce_sum(t):
+    """C1/C2 of SURVEY.md §2.2: SUM over the TP ranks, in place."""
+    if tp_size() > 1:
+        dist.all_reduce(t)
+    return t

@@ -1,0 +1,181 @@
+"""Qwen3 / Qwen2 decoder (reference: nanovllm/models/qwen3.py) wired onto the HIP layers.
+
+Module and parameter names equal the reference's (and therefore HF checkpoints through
+`packed_modules_mapping`), so the same loader and the same call sites work.
+
+`fused=True` (default) replaces the four-op sequence q_norm -> k_norm -> rotary ->
+KV scatter (qwen3.py:83-88, attention.py:22-35) by the single kernel
+mi_qknorm_rope_store, whose rounding points are identical (tests require equal bits).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from nanovllm import ops
+from nanovllm.layers.activation import SiluAndMul
+from nanovllm.layers.attention import Attention
+from nanovllm.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
+from nanovllm.layers.layernorm import RMSNorm
+from nanovllm.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from nanovllm.layers.parallel import tp_size
+from nanovllm.layers.rotary_embedding import get_rope
+from nanovllm.utils.context import get_context
+
+
+def rope_theta_of(config) -> float:
+    """transformers >= 5 moved rope_theta into config.rope_parameters; the reference's
+    getattr(config, "rope_theta", 1000000) (qwen3.py:137) then silently takes the 1e6
+    fallback.  Read the real value, fall back identically."""
+    theta = getattr(config, "rope_theta", None)
+    if theta is None:
+        params = getattr(config, "rope_parameters", None) or {}
+        theta = params.get("rope_theta", 1000000)
+    return float(theta)
+
+
+class Qwen3Attention(nn.Module):
+    def __init__(self, hidden_size: int, num_heads: int, num_kv_heads: int, max_position: int = 4096 * 32,
+                 head_dim: int | None = None, rms_norm_eps: float = 1e-06, qkv_bias: bool = False,
+                 rope_theta: float = 10000, rope_scaling: tuple | None = None, fused: bool = True) -> None:
+        super().__init__()
+        world = tp_size()
+        self.total_num_heads = num_heads
+        assert num_heads % world == 0 and num_kv_heads % world == 0
+        self.num_heads = num_heads // world
+        self.total_num_kv_heads = num_kv_heads
+        self.num_kv_heads = num_kv_heads // world
+        self.head_dim = head_dim or hidden_size // num_heads
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim ** -0.5
+        self.qkv_bias = qkv_bias
+        self.fused = fused
+        self.rms_norm_eps = rms_norm_eps
+
+        self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=qkv_bias)
+        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=False)
+        self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim, max_position=max_position,
+                                   base=rope_theta)
+        self.attn = Attention(self.num_heads, self.head_dim, None, self.num_kv_heads)
+        if not qkv_bias:  # Qwen3: per-head q/k RMSNorm instead of qkv biases (qwen3.py:70-72)
+            self.q_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
+            self.k_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
+        qkv = self.qkv_proj(hidden_states)
+        if self.fused and self.attn.k_cache.numel() > 0:
+            o = self._attend_fused(positions, qkv)
+        else:
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            q = q.view(-1, self.num_heads, self.head_dim)
+            k = k.view(-1, self.num_kv_heads, self.head_dim)
+            v = v.view(-1, self.num_kv_heads, self.head_dim)
+            if not self.qkv_bias:
+                q = self.q_norm(q)
+                k = self.k_norm(k)
+            q, k = self.rotary_emb(positions, q, k)
+            o = self.attn(q, k, v)
+        return self.o_proj(o.flatten(1, -1))
+
+    def _attend_fused(self, positions: torch.Tensor, qkv: torch.Tensor) -> torch.Tensor:
+        ctx, attn = get_context(), self.attn
+        attn.block_size = ctx.block_size
+        rope = self.rotary_emb
+        if rope.cos_sin_cache.device != qkv.device:
+            rope.cos_sin_cache = rope.cos_sin_cache.to(qkv.device)
+        qw = None if self.qkv_bias else self.q_norm.weight
+        kw = None if self.qkv_bias else self.k_norm.weight
+        q = ops.qknorm_rope_store(qkv, qw, kw, self.rms_norm_eps, positions, rope.cos_sin_cache, attn.k_cache,
+                                  attn.v_cache, ctx.slot_mapping, self.num_heads, self.num_kv_heads,
+                                  ctx.block_size)
+        if ctx.is_prefill:
+            kv_lens = ctx.kv_lens
+            if kv_lens is None:
+                kv_lens = (ctx.cu_seqlens_k[1:] - ctx.cu_seqlens_k[:-1]).contiguous()
+            return ops.paged_attn_prefill(q, attn.k_cache, attn.v_cache, ctx.block_tables, ctx.cu_seqlens_q,
+                                          kv_lens, ctx.max_seqlen_q, self.num_heads, self.num_kv_heads,
+                                          ctx.block_size, attn.scale)
+        return ops.paged_attn_decode(q, attn.k_cache, attn.v_cache, ctx.block_tables, ctx.context_lens,
+                                     self.num_heads, self.num_kv_heads, ctx.block_size, attn.scale)
+
+
+class Qwen3MLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str) -> None:
+        super().__init__()
+        assert hidden_act == "silu"
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=False)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=False)
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+
+
+class Qwen3DecoderLayer(nn.Module):
+    def __init__(self, config, fused: bool = True) -> None:
+        super().__init__()
+        self.self_attn = Qwen3Attention(
+            hidden_size=config.hidden_size,
+            num_heads=config.num_attention_heads,
+            num_kv_heads=config.num_key_value_heads,
+            max_position=config.max_position_embeddings,
+            rms_norm_eps=config.rms_norm_eps,
+            qkv_bias=getattr(config, "attention_bias", True),
+            head_dim=getattr(config, "head_dim", None),
+            rope_theta=rope_theta_of(config),
+            rope_scaling=getattr(config, "rope_scaling", None),
+            fused=fused,
+        )
+        self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class Qwen3Model(nn.Module):
+    def __init__(self, config, fused: bool = True) -> None:
+        super().__init__()
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([Qwen3DecoderLayer(config, fused) for _ in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        hidden_states = self.embed_tokens(input_ids)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class Qwen3ForCausalLM(nn.Module):
+    packed_modules_mapping = {
+        "q_proj": ("qkv_proj", "q"),
+        "k_proj": ("qkv_proj", "k"),
+        "v_proj": ("qkv_proj", "v"),
+        "gate_proj": ("gate_up_proj", 0),
+        "up_proj": ("gate_up_proj", 1),
+    }
+
+    def __init__(self, config, fused: bool = True) -> None:
+        super().__init__()
+        self.model = Qwen3Model(config, fused)
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if getattr(config, "tie_word_embeddings", False):
+            self.lm_head.weight.data = self.model.embed_tokens.weight.data
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        return self.model(input_ids, positions)
+
+    def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        return self.lm_head(hidden_states)

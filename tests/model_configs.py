@@ -1,0 +1,24 @@
+"""Synthetic HF model directories (config.json only) for tests, smoke and bench."""
+import json
+import os
+import tempfile
+
+QWEN3_0_6B = dict(
+    architectures=["Qwen3ForCausalLM"], model_type="qwen3", hidden_size=1024, num_hidden_layers=28,
+    num_attention_heads=16, num_key_value_heads=8, head_dim=128, intermediate_size=3072, vocab_size=151936,
+    max_position_embeddings=40960, rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=True,
+    attention_bias=False, hidden_act="silu", torch_dtype="bfloat16", bos_token_id=151643, eos_token_id=151645,
+)
+
+TINY = dict(QWEN3_0_6B, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+            intermediate_size=256, vocab_size=256, max_position_embeddings=512, eos_token_id=255, bos_token_id=0)
+
+MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
+           bos_token_id=0)
+
+
+def make_model_dir(cfg: dict, root: str | None = None) -> str:
+    d = tempfile.mkdtemp(prefix="mi355_model_", dir=root)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    return d

@@ -1,0 +1,446 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the CPU oracle
+and the reference-generated golden vectors.  Integer / copy work is bit-exact;
+floating-point tolerances are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import bf16_from_bits as bf
+from kv_layout import to_fragment, to_logical
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nanovllm import ops as _ops
+
+    return _ops
+
+
+def ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """distance in bf16 ulps between two bf16 tensors (monotone integer mapping)"""
+    def key(t):
+        i = t.cpu().contiguous().view(torch.int16).to(torch.int32)
+        return torch.where(i < 0, -(i & 0x7FFF), i)
+    return (key(a) - key(b)).abs()
+
+
+def assert_bf16_close(got, want, max_ulp=1, max_frac=1e-3, atol=0.0):
+    """Equal up to `max_ulp` bf16 ulps on at most `max_frac` of the elements (fp32
+    summation order / rsqrt / exp last-bit effects before a bf16 rounding).  `atol`
+    covers outputs that cancel to ~0, where the fp32 accumulation noise of the dot
+    product (K * 2^-24 * |x||w|) is many ulps of a tiny result."""
+    d = ulp_diff(got, want)
+    bad = d > max_ulp
+    if atol > 0:
+        bad &= (got.cpu().float() - want.float()).abs() > atol
+    assert not bool(bad.any()), f"max ulp diff {int(d[bad].max())} on {int(bad.sum())} elements"
+    frac = float((d > 0).float().mean())
+    assert frac <= max_frac, f"{frac:.2e} of elements differ"
+
+
+# --------------------------------------------------------------------------- norms / rope / silu vs golden
+def test_rmsnorm_golden(ops, golden_layers):
+    g = golden_layers
+    for tag in ("h1024", "head128", "h256"):
+        x, w, r = bf(g[f"rms_{tag}_x"]).to(DEV), bf(g[f"rms_{tag}_w"]).to(DEV), bf(g[f"rms_{tag}_r"]).to(DEV)
+        assert_bf16_close(ops.rmsnorm(x, w, 1e-6), bf(g[f"rms_{tag}_y"]))
+        y, r2 = ops.add_rmsnorm(x, r, w, 1e-6)
+        assert_bf16_close(y, bf(g[f"rms_{tag}_addy"]))
+        assert torch.equal(r2.cpu().view(torch.int16), bf(g[f"rms_{tag}_addr"]).view(torch.int16))  # pure add+round
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1024), (32, 1024), (33, 5120), (257, 2048), (7, 64), (512, 128), (3, 8192)])
+def test_rmsnorm_random(ops, rows, cols):
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2).bfloat16()
+    r = torch.randn(rows, cols, generator=g).bfloat16()
+    w = (1 + 0.2 * torch.randn(cols, generator=g)).bfloat16()
+    assert_bf16_close(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6), oracle.rms_norm(x, w, 1e-6))
+    y, r2 = ops.add_rmsnorm(x.to(DEV), r.to(DEV), w.to(DEV), 1e-6)
+    yo, ro = oracle.add_rms_norm(x, r, w, 1e-6)
+    assert_bf16_close(y, yo)
+    assert torch.equal(r2.cpu().view(torch.int16), ro.view(torch.int16))
+    # in-place aliasing (what the runner does)
+    xd, rd = x.to(DEV), r.to(DEV)
+    ops.add_rmsnorm(xd, rd, w.to(DEV), 1e-6, out=xd, residual_out=rd)
+    assert_bf16_close(xd, yo)
+    assert torch.equal(rd.cpu().view(torch.int16), ro.view(torch.int16))
+
+
+def test_rmsnorm_strided_heads(ops):
+    """per-head q/k norm on strided views of a packed qkv row (qwen3.py:79-85)"""
+    g = torch.Generator().manual_seed(5)
+    T, hq, hkv = 9, 16, 8
+    qkv = torch.randn(T, (hq + 2 * hkv) * 128, generator=g).bfloat16()
+    w = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16()
+    qd = qkv.to(DEV)
+    q_view = qd[:, : hq * 128].view(T, hq, 128)
+    k_view = qd[:, hq * 128 : (hq + hkv) * 128].view(T, hkv, 128)
+    assert_bf16_close(ops.rmsnorm(q_view, w.to(DEV), 1e-6), oracle.rms_norm(qkv[:, : hq * 128].view(T, hq, 128), w, 1e-6))
+    assert_bf16_close(ops.rmsnorm(k_view, w.to(DEV), 1e-6),
+                      oracle.rms_norm(qkv[:, hq * 128 : (hq + hkv) * 128].view(T, hkv, 128), w, 1e-6))
+
+
+def test_rope_golden_bit_exact(ops, golden_layers):
+    g = golden_layers
+    pos = torch.from_numpy(g["rope_pos"])
+    table = oracle.build_cos_sin_cache(128, 40960, 1000000.0)
+    q, k = bf(g["rope_q"]), bf(g["rope_k"])
+    q2, k2 = ops.rope(pos.to(DEV), q.to(DEV), k.to(DEV), table.to(DEV), 4, 2)
+    assert torch.equal(q2.cpu().view(torch.int16), bf(g["rope_q_out"]).view(torch.int16))
+    assert torch.equal(k2.cpu().view(torch.int16), bf(g["rope_k_out"]).view(torch.int16))
+
+
+def test_silu_mul(ops, golden_layers):
+    g = golden_layers
+    assert_bf16_close(ops.silu_mul(bf(g["silu_x"]).to(DEV)), bf(g["silu_y"]))
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(32, 2 * 3072, generator=gen) * 3).bfloat16()
+    assert_bf16_close(ops.silu_mul(x.to(DEV)), oracle.silu_and_mul(x))
+
+
+# --------------------------------------------------------------------------- KV scatter (bit-exact)
+@pytest.mark.parametrize("block_size", [16, 32, 256])
+def test_kv_scatter_roundtrip(ops, block_size):
+    g = torch.Generator().manual_seed(block_size)
+    hkv, nblk, T = 8, 12, 150
+    # k, v are strided views of a packed qkv row, as in the model
+    qkv = torch.randn(T, (16 + 2 * hkv) * 128, generator=g).bfloat16()
+    k = qkv[:, 16 * 128 : (16 + hkv) * 128].view(T, hkv, 128)
+    v = qkv[:, (16 + hkv) * 128 :].view(T, hkv, 128)
+    slots = torch.randperm(nblk * block_size, generator=g)[:T].to(torch.int32)
+    slots[5] = -1  # skipped token
+    kc_o = torch.zeros(nblk, block_size, hkv, 128, dtype=torch.bfloat16)
+    vc_o = torch.zeros_like(kc_o)
+    oracle.kv_scatter(k, v, kc_o, vc_o, slots)
+    qd = qkv.to(DEV)
+    kd = qd[:, 16 * 128 : (16 + hkv) * 128].view(T, hkv, 128)
+    vd = qd[:, (16 + hkv) * 128 :].view(T, hkv, 128)
+    kc = torch.zeros(ops.kv_cache_shape(nblk, hkv, block_size), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.reshape_and_cache(kd, vd, kc, vc, slots.to(DEV), hkv, block_size)
+    assert torch.equal(to_logical(kc.cpu(), block_size, False).view(torch.int16), kc_o.view(torch.int16))
+    assert torch.equal(to_logical(vc.cpu(), block_size, True).view(torch.int16), vc_o.view(torch.int16))
+    # device-side gather helper agrees with the host model of the layout
+    allslots = torch.arange(nblk * block_size, dtype=torch.int32, device=DEV)
+    rows = ops.kv_cache_gather(kc, False, allslots, hkv, block_size).cpu()
+    assert torch.equal(rows.view(torch.int16), kc_o.view(nblk * block_size, hkv * 128).view(torch.int16))
+    rows = ops.kv_cache_gather(vc, True, allslots, hkv, block_size).cpu()
+    assert torch.equal(rows.view(torch.int16), vc_o.view(nblk * block_size, hkv * 128).view(torch.int16))
+    # decode-style 2-D slots ([block, offset], model_runner.py:353) on top of it
+    B = 7
+    k2 = torch.randn(B, hkv, 128, generator=g).bfloat16()
+    v2 = torch.randn(B, hkv, 128, generator=g).bfloat16()
+    s2 = torch.stack([torch.randperm(nblk, generator=g)[:B], torch.randint(0, block_size, (B,), generator=g)], 1).to(torch.int32)
+    oracle.kv_scatter(k2, v2, kc_o, vc_o, (s2[:, 0] * block_size + s2[:, 1]))
+    ops.scatter_update_kv(k2.to(DEV), v2.to(DEV), kc, vc, s2.to(DEV), hkv, block_size)
+    assert torch.equal(to_logical(kc.cpu(), block_size, False).view(torch.int16), kc_o.view(torch.int16))
+    assert torch.equal(to_logical(vc.cpu(), block_size, True).view(torch.int16), vc_o.view(torch.int16))
+
+
+def test_kv_scatter_golden(ops, golden_attention):
+    g = golden_attention
+    hq, hkv, d, bs, nblk = (int(v) for v in g["meta"])
+    kc = torch.zeros(ops.kv_cache_shape(nblk, hkv, bs), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    slots = torch.from_numpy(g["pre_slots"]).to(DEV)
+    ops.reshape_and_cache(bf(g["pre_k"]).to(DEV), bf(g["pre_v"]).to(DEV), kc, vc, slots, hkv, bs)
+    assert torch.equal(ops.kv_cache_gather(kc, False, slots, hkv, bs).cpu().view(torch.int16),
+                       bf(g["pre_krows"]).reshape(-1, hkv * d).view(torch.int16))
+    assert torch.equal(ops.kv_cache_gather(vc, True, slots, hkv, bs).cpu().view(torch.int16),
+                       bf(g["pre_vrows"]).reshape(-1, hkv * d).view(torch.int16))
+    assert int((to_logical(kc.cpu(), bs, False).reshape(-1, hkv * d) != 0).any(dim=1).sum()) == int(g["pre_cache_nonzero_rows"])
+
+
+def test_fused_qknorm_rope_store_equals_unfused(ops):
+    g = torch.Generator().manual_seed(77)
+    T, hq, hkv, bs, nblk = 37, 16, 8, 16, 8
+    qkv = (torch.randn(T, (hq + 2 * hkv) * 128, generator=g) * 2).bfloat16().to(DEV)
+    qw = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16().to(DEV)
+    kw = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16().to(DEV)
+    pos = torch.randint(0, 4096, (T,), generator=g).to(DEV)
+    table = oracle.build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    slots = torch.randperm(nblk * bs, generator=g)[:T].to(torch.int32).to(DEV)
+    q_view = qkv[:, : hq * 128].view(T, hq, 128)
+    k_view = qkv[:, hq * 128 : (hq + hkv) * 128].view(T, hkv, 128)
+    v_view = qkv[:, (hq + hkv) * 128 :].view(T, hkv, 128)
+    qn, kn = ops.rmsnorm(q_view, qw, 1e-6), ops.rmsnorm(k_view, kw, 1e-6)
+    qr, kr = ops.rope(pos, qn, kn, table, hq, hkv)
+    kc1 = torch.zeros(ops.kv_cache_shape(nblk, hkv, bs), dtype=torch.bfloat16, device=DEV)
+    vc1 = torch.zeros_like(kc1)
+    ops.reshape_and_cache(kr, v_view, kc1, vc1, slots, hkv, bs)
+    kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(kc1)
+    q2 = ops.qknorm_rope_store(qkv, qw, kw, 1e-6, pos, table, kc2, vc2, slots, hq, hkv, bs)
+    assert torch.equal(q2.view(torch.int16), qr.reshape(T, -1).view(torch.int16))
+    assert torch.equal(kc1.view(torch.int16), kc2.view(torch.int16))
+    assert torch.equal(vc1.view(torch.int16), vc2.view(torch.int16))
+    # and against the oracle (norm is last-bit sensitive -> ulp tolerance)
+    qo = oracle.apply_rope(pos.cpu(), oracle.rms_norm(q_view.cpu(), qw.cpu(), 1e-6), table.cpu())
+    assert_bf16_close(q2.cpu().view(T, hq, 128), qo)
+    # 2-D slots, no norm weights (attention_bias models)
+    s2 = torch.stack([slots // bs, slots % bs], 1).contiguous()
+    kc3, vc3 = torch.zeros_like(kc1), torch.zeros_like(kc1)
+    q3 = ops.qknorm_rope_store(qkv, None, None, 1e-6, pos, table, kc3, vc3, s2, hq, hkv, bs)
+    qr3, kr3 = ops.rope(pos, q_view, k_view, table, hq, hkv)
+    assert torch.equal(q3.view(torch.int16), qr3.reshape(T, -1).view(torch.int16))
+    kc4, vc4 = torch.zeros_like(kc1), torch.zeros_like(kc1)
+    ops.reshape_and_cache(kr3, v_view, kc4, vc4, slots, hkv, bs)
+    assert torch.equal(kc3.view(torch.int16), kc4.view(torch.int16)) and torch.equal(vc3.view(torch.int16), vc4.view(torch.int16))
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (256, 128), (512, 160), (16, 32)])
+def test_gemm_skinny(ops, M, N, K):
+    """fp32 accumulate, one rounding: <= 1 bf16 ulp from the oracle on a small fraction
+    of outputs (summation order)."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    y = ops.gemm_skinny(x.to(DEV), w.to(DEV))
+    atol = K * 2.0 ** -22  # fp32 accumulation noise bound for |x| ~ 3, |w| ~ 0.15
+    assert_bf16_close(y, oracle.linear(x, w), max_ulp=1, max_frac=2e-2, atol=atol)
+    yb = ops.gemm_skinny(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert_bf16_close(yb, oracle.linear(x, w, b), max_ulp=1, max_frac=2e-2, atol=atol)
+    # transpose / fragment-layout detector: asymmetric weights, identity-like x
+    if M >= 16 and K >= 32:
+        xe = torch.zeros(M, K).bfloat16()
+        xe[3, 5] = 1.0
+        ye = ops.gemm_skinny(xe.to(DEV), w.to(DEV)).cpu()
+        assert torch.equal(ye[3].view(torch.int16), w[:, 5].contiguous().view(torch.int16))
+        assert float(ye.float().abs().sum() - ye[3].float().abs().sum()) == 0.0
+
+
+def test_gemm_lm_head_shape(ops):
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 32, 151936, 1024
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.02).bfloat16()
+    y = ops.gemm_skinny(x.to(DEV), w.to(DEV)).cpu()
+    ref = oracle.linear(x, w)
+    assert_bf16_close(y, ref, max_ulp=1, max_frac=2e-2, atol=1024 * 2.0 ** -22)
+
+
+# --------------------------------------------------------------------------- attention
+def _random_paged_case(gen, hq, hkv, block_size, ctx_lens, extra_blocks=3, scale_q=1.0):
+    d = 128
+    need = sum((n + block_size - 1) // block_size for n in ctx_lens)
+    nblk = need + extra_blocks
+    kc = torch.randn(nblk, block_size, hkv, d, generator=gen).bfloat16()
+    vc = torch.randn(nblk, block_size, hkv, d, generator=gen).bfloat16()
+    perm = torch.randperm(nblk, generator=gen).tolist()
+    tables = []
+    for n in ctx_lens:
+        nb = (n + block_size - 1) // block_size
+        tables.append([perm.pop() for _ in range(nb)])
+    width = max(1, max(len(t) for t in tables)) + 2  # trailing -1 padding columns
+    bt = torch.tensor([t + [-1] * (width - len(t)) for t in tables], dtype=torch.int32)
+    q = (torch.randn(len(ctx_lens), hq, d, generator=gen) * scale_q).bfloat16()
+    return q, kc, vc, bt
+
+
+def test_decode_attention_golden(ops, golden_attention):
+    """vs the reference's own CPU attention (bf16 S/P): bound 3e-2; vs oracle: 2e-3."""
+    g = golden_attention
+    hq, hkv, d, bs, nblk = (int(v) for v in g["meta"])
+    kc_l, vc_l = bf(g["dec_kcache_before"]).clone(), bf(g["dec_vcache_before"]).clone()
+    kc, vc = to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV)
+    slots = torch.from_numpy(g["dec_slots"])
+    s2 = torch.stack([slots // bs, slots % bs], 1).to(torch.int32).contiguous().to(DEV)
+    ops.scatter_update_kv(bf(g["dec_k"]).to(DEV), bf(g["dec_v"]).to(DEV), kc, vc, s2, hkv, bs)
+    ctx = torch.from_numpy(g["dec_ctx"])
+    bt = torch.from_numpy(g["dec_tables"])
+    out = ops.paged_attn_decode(bf(g["dec_q"]).to(DEV), kc, vc, bt.to(DEV), ctx.to(DEV), hq, hkv, bs,
+                                1.0 / math.sqrt(d)).cpu()
+    assert (out.float() - bf(g["dec_out"]).float()).abs().max().item() <= 3e-2
+    oracle.kv_scatter(bf(g["dec_k"]), bf(g["dec_v"]), kc_l, vc_l, slots)
+    want = oracle.paged_attention_decode(bf(g["dec_q"]), kc_l, vc_l, bt, ctx, keep_fp32=True)
+    assert (out.float() - want).abs().max().item() <= 8e-3  # half a bf16 ulp at |o|<=2 + fp32 noise
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (64, 8), (16, 1)])
+@pytest.mark.parametrize("block_size", [16, 64, 256])
+def test_decode_attention_random(ops, hq, hkv, block_size):
+    """fp32-softmax oracle; kernel keeps P to ~16 bits (hi/lo bf16 split), so the only
+    error left is the final bf16 rounding: |out - oracle_fp32| <= half a bf16 ulp."""
+    gen = torch.Generator().manual_seed(hq * 1000 + hkv * 10 + block_size)
+    ctx_lens = [1, 15, 16, 17, 31, 32, 33, 100, 513, 1024, 0, 2049]
+    q, kc_l, vc_l, bt = _random_paged_case(gen, hq, hkv, block_size, ctx_lens)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    want = oracle.paged_attention_decode(q, kc_l, vc_l, bt, ctx, keep_fp32=True)
+    out = ops.paged_attn_decode(q.to(DEV), to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV),
+                                bt.to(DEV), ctx.to(DEV), hq, hkv, block_size, 1.0 / math.sqrt(128)).cpu()
+    err = (out.float() - want).abs()
+    tol = want.abs() * 2 ** -8 + 1e-4
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}"
+    assert float(out[ctx_lens.index(0)].float().abs().max()) == 0.0  # padded row -> zeros
+    # strided q (a view into a packed qkv row) gives the same bits
+    packed = torch.zeros(len(ctx_lens), (hq + 2 * hkv) * 128, dtype=torch.bfloat16)
+    packed[:, : hq * 128] = q.reshape(len(ctx_lens), -1)
+    out2 = ops.paged_attn_decode(packed.to(DEV)[:, : hq * 128], to_fragment(kc_l, False).to(DEV),
+                                 to_fragment(vc_l, True).to(DEV), bt.to(DEV), ctx.to(DEV), hq, hkv, block_size,
+                                 1.0 / math.sqrt(128)).cpu()
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+
+
+def test_decode_attention_sharp_softmax(ops):
+    """large score spread (forces the online-softmax rescale path across chunks/waves/splits)"""
+    gen = torch.Generator().manual_seed(9)
+    ctx_lens = [700, 1024, 3000]
+    q, kc_l, vc_l, bt = _random_paged_case(gen, 16, 8, 16, ctx_lens, scale_q=6.0)
+    # spike: one late key aligned with q of sequence 1
+    blk, off = int(bt[1][1000 // 16]), 1000 % 16
+    kc_l[blk, off, :, :] = (q[1].view(8, 2, 128)[:, 0] * 1.5).bfloat16()
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    want = oracle.paged_attention_decode(q, kc_l, vc_l, bt, ctx, keep_fp32=True)
+    out = ops.paged_attn_decode(q.to(DEV), to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV),
+                                bt.to(DEV), ctx.to(DEV), 16, 8, 16, 1.0 / math.sqrt(128)).cpu()
+    err = (out.float() - want).abs()
+    assert bool((err <= want.abs() * 2 ** -8 + 2e-4).all()), err.max().item()
+
+
+@pytest.mark.parametrize("batch", [1, 32, 256])
+def test_decode_attention_batch_sizes(ops, batch):
+    gen = torch.Generator().manual_seed(batch)
+    ctx_lens = [int(x) for x in torch.randint(1, 300, (batch,), generator=gen)]
+    q, kc_l, vc_l, bt = _random_paged_case(gen, 16, 8, 16, ctx_lens)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    want = oracle.paged_attention_decode(q, kc_l, vc_l, bt, ctx, keep_fp32=True)
+    out = ops.paged_attn_decode(q.to(DEV), to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV),
+                                bt.to(DEV), ctx.to(DEV), 16, 8, 16, 1.0 / math.sqrt(128)).cpu()
+    err = (out.float() - want).abs()
+    assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
+
+
+def test_prefill_attention_golden(ops, golden_attention):
+    g = golden_attention
+    hq, hkv, d, bs, nblk = (int(v) for v in g["meta"])
+    kc = torch.zeros(ops.kv_cache_shape(nblk, hkv, bs), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.reshape_and_cache(bf(g["pre_k"]).to(DEV), bf(g["pre_v"]).to(DEV), kc, vc,
+                          torch.from_numpy(g["pre_slots"]).to(DEV), hkv, bs)
+    cu = torch.from_numpy(g["pre_cu"])
+    lens = (cu[1:] - cu[:-1]).to(torch.int32)
+    out = ops.paged_attn_prefill(bf(g["pre_q"]).to(DEV), kc, vc, torch.from_numpy(g["pre_tables"]).to(DEV),
+                                 cu.to(DEV), lens.to(DEV), int(lens.max()), hq, hkv, bs, 1.0 / math.sqrt(d)).cpu()
+    assert (out.float() - bf(g["pre_out"]).float()).abs().max().item() <= 3e-2
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (16, 1)])
+@pytest.mark.parametrize("block_size", [16, 256])
+def test_prefill_attention_random(ops, hq, hkv, block_size):
+    gen = torch.Generator().manual_seed(hq + hkv + block_size)
+    q_lens = [1, 7, 16, 33, 129, 260]
+    kv_lens = [1, 7, 16, 33, 129 + 64, 260]  # one sequence with a 64-token cached prefix
+    T = sum(q_lens)
+    _, kc_l, vc_l, bt = _random_paged_case(gen, hq, hkv, block_size, kv_lens)
+    q = torch.randn(T, hq, 128, generator=gen).bfloat16()
+    cu = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
+    kvl = torch.tensor(kv_lens, dtype=torch.int32)
+    want = oracle.paged_attention_prefill(q, kc_l, vc_l, bt, cu, kvl, keep_fp32=True)
+    out = ops.paged_attn_prefill(q.to(DEV), to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV),
+                                 bt.to(DEV), cu.to(DEV), kvl.to(DEV), max(q_lens), hq, hkv, block_size,
+                                 1.0 / math.sqrt(128)).cpu()
+    err = (out.float() - want).abs()
+    assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
+
+
+# --------------------------------------------------------------------------- gathers / sampling
+def test_embedding_and_last_token(ops):
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(1000, 1024, generator=g).bfloat16()
+    ids = torch.randint(0, 1000, (57,), generator=g)
+    out = ops.embedding(ids.to(DEV), w.to(DEV)).cpu()
+    assert torch.equal(out.view(torch.int16), oracle.embedding(ids, w).view(torch.int16))
+    # vocab-parallel shard: rows outside [250, 500) are zero (embed_head.py:36-40)
+    shard = w[250:500].contiguous()
+    out = ops.embedding(ids.to(DEV), shard.to(DEV), vocab_start=250).cpu()
+    want = oracle.embedding(ids, shard, 250)
+    own = (ids >= 250) & (ids < 500)
+    assert torch.equal(out[own].view(torch.int16), want[own].view(torch.int16))
+    # rows of other ranks are zero; the reference's mask-multiply yields -0.0 for negative entries
+    # (embed_head.py:40), the kernel writes +0.0 - identical after the all-reduce sum that follows
+    assert bool((out[~own].float() == 0).all()) and bool((want[~own].float() == 0).all())
+    x = torch.randn(57, 1024, generator=g).bfloat16()
+    cu = torch.tensor([0, 5, 6, 40, 57], dtype=torch.int32)
+    last = ops.gather_last_tokens(x.to(DEV), cu.to(DEV)).cpu()
+    assert torch.equal(last.view(torch.int16), x[(cu[1:] - 1).long()].view(torch.int16))
+
+
+def test_argmax_lowest_index_of_max(ops):
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(32, 151936, generator=g).bfloat16()
+    logits[3, 777] = 50.0
+    logits[3, 90000] = 50.0  # tie -> lowest index
+    logits[4, 151935] = 60.0  # last column
+    got = ops.argmax(logits.to(DEV)).cpu()
+    want = torch.tensor([int(torch.nonzero(r == r.max())[0]) for r in logits.float()])
+    assert torch.equal(got, want)
+    # padded logits rows (graph mode): only the first `rows` are sampled (sampler.py:10-12)
+    temps = torch.zeros(5)
+    got5 = ops.sample(logits.to(DEV), temps.to(DEV), seed=1, step=0).cpu()
+    assert torch.equal(got5, want[:5])
+
+
+def test_sample_distribution(ops, golden_layers):
+    """Gumbel-max draws follow softmax(logits/T) (sampler.py:13-16): chi-square on the
+    reference's own probabilities for its sampler fixture."""
+    g = golden_layers
+    logits = bf(g["samp_logits"])[:, :64].contiguous()
+    temps = torch.from_numpy(g["samp_temps"])
+    probs = torch.softmax(logits.float() / temps.unsqueeze(-1), dim=-1)
+    n = 4000
+    counts = torch.zeros(3, 64)
+    ld, td = logits.to(DEV), temps.to(DEV)
+    for step in range(n):
+        t = ops.sample(ld, td, seed=123, step=step).cpu()
+        counts[torch.arange(3), t] += 1
+    exp = probs * n
+    mask = exp >= 5
+    chi2 = (((counts - exp) ** 2 / exp) * mask).sum(dim=1)
+    dof = mask.sum(dim=1) - 1
+    assert bool((chi2 < dof + 5 * torch.sqrt(2.0 * dof)).all()), (chi2, dof)
+    # determinism: same (seed, step) -> same draw; different step -> different stream
+    a = ops.sample(ld, td, seed=9, step=5).cpu()
+    b = ops.sample(ld, td, seed=9, step=5).cpu()
+    assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------- hipGraph capture
+def test_kernels_capture_into_hipgraph(ops):
+    gen = torch.Generator().manual_seed(8)
+    ctx_lens = [40, 41, 0, 17]
+    q, kc_l, vc_l, bt = _random_paged_case(gen, 16, 8, 16, ctx_lens)
+    kc, vc = to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV)
+    qd, btd = q.to(DEV), bt.to(DEV)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32, device=DEV)
+    w = (torch.randn(1024, 2048, generator=gen) * 0.05).bfloat16().to(DEV)
+    nw = torch.ones(1024, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(4, 2048, dtype=torch.bfloat16, device=DEV)
+    ws = ops.attn_workspace(torch.device(DEV), 4, 16)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        def body():
+            ops.paged_attn_decode(qd, kc, vc, btd, ctx, 16, 8, 16, 128 ** -0.5, out=out, workspace=ws)
+            return ops.rmsnorm(ops.gemm_skinny(out, w), nw, 1e-6)
+        eager = body().clone()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        res = body()
+    new_ctx = torch.tensor([33, 8, 0, 17], dtype=torch.int32)  # new metadata (within the tables), same graph
+    ctx.copy_(new_ctx)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = oracle.paged_attention_decode(q, kc_l, vc_l, bt, new_ctx)
+    want = oracle.rms_norm(oracle.linear(want, w.cpu()), nw.cpu(), 1e-6)
+    assert_bf16_close(res, want, max_ulp=2, max_frac=5e-2, atol=1e-3)
+    assert eager.shape == res.shape

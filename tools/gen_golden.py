@@ -367,9 +367,10 @@ def gen_tiny_model():
             return super().forward(q, k, v)
 
     ref_qwen3.Attention = NativeAdapter
-    hf = Qwen3Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
-                     head_dim=128, intermediate_size=256, vocab_size=256, max_position_embeddings=512,
-                     rms_norm_eps=1e-6, tie_word_embeddings=True, attention_bias=False, hidden_act="silu")
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from model_configs import TINY  # the same dict the tests build their model directory from
+
+    hf = Qwen3Config(**{k: v for k, v in TINY.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
     weights = random_weights(cfg, seed=3, std=0.08)
     # non-trivial norm weights so the norm multiplies are exercised

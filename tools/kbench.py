@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one MI355X (HIP events on the launch stream).
+
+Reports each hot kernel's duration and its fraction of the 8 TB/s HBM roofline
+at the BASELINE shapes (Qwen3-0.6B, bs=32, ctx=1024, block 16).  Buffers are
+cycled over 28 "layers" so nothing is served from the 256 MiB Infinity Cache.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nano-vllm-ascend_amd"))
+from nanovllm import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+PEAK = 8.0e12
+
+
+def timeit(fn, n_layers, iters=5, warm=2, reps=None):
+    """Capture `n_layers` back-to-back launches into a hipGraph (removes the ~10 us
+    python/ctypes launch cost) and time `iters` replays with HIP events."""
+    reps = reps or max(1, 28 // n_layers)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for l in range(n_layers):
+            fn(l)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            for l in range(n_layers):
+                fn(l)
+    for _ in range(warm):
+        graph.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        graph.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / (iters * n_layers * reps)
+
+
+def main():
+    B, ctx, bs, hq, hkv, L = 32, int(os.environ.get("CTX", 1024)), 16, 16, 8, 28
+    res = {}
+    nb_seq = (ctx + bs - 1) // bs
+    nblk = B * nb_seq
+    g = torch.Generator(device="cpu").manual_seed(0)
+    kc = [torch.randn(ops.kv_cache_shape(nblk, hkv, bs), device=DEV).bfloat16() for _ in range(L)]
+    vc = [torch.randn(ops.kv_cache_shape(nblk, hkv, bs), device=DEV).bfloat16() for _ in range(L)]
+    perm = torch.randperm(nblk, generator=g).to(torch.int32).view(B, nb_seq).to(DEV)
+    ctxl = torch.full((B,), ctx, dtype=torch.int32, device=DEV)
+    q = torch.randn(B, hq * 128, device=DEV).bfloat16()
+    out = torch.empty(B, hq * 128, dtype=torch.bfloat16, device=DEV)
+    ws = ops.attn_workspace(DEV, B, hq)
+    t = timeit(lambda l: ops.paged_attn_decode(q, kc[l], vc[l], perm, ctxl, hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
+    byt = B * 2 * ctx * hkv * 128 * 2
+    res["paged_attn_decode(+merge)"] = {"us": t * 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
+
+    def gemm(name, N, K, M=32):
+        ws_ = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(L if N < 100000 else 3)]
+        x = torch.randn(M, K, device=DEV).bfloat16()
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        n = len(ws_)
+        t = timeit(lambda l: ops.gemm_skinny(x, ws_[l], out=y), n)
+        byt = N * K * 2
+        res[name] = {"us": t * 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
+        # torch (hipBLASLt) comparison column
+        t2 = timeit(lambda l: torch.nn.functional.linear(x, ws_[l]), n)
+        res[name]["torch_us"] = t2 * 1e6
+
+    gemm("qkv 4096x1024", 4096, 1024)
+    gemm("o 1024x2048", 1024, 2048)
+    gemm("gate_up 6144x1024", 6144, 1024)
+    gemm("down 1024x3072", 1024, 3072)
+    gemm("lm_head 151936x1024", 151936, 1024)
+
+    x = torch.randn(B, 1024, device=DEV).bfloat16()
+    r = torch.randn(B, 1024, device=DEV).bfloat16()
+    w = torch.ones(1024, device=DEV).bfloat16()
+    t = timeit(lambda l: ops.add_rmsnorm(x, r, w, 1e-6, out=x, residual_out=r), 1, iters=20, reps=50)
+    res["add_rmsnorm 32x1024"] = {"us": t * 1e6}
+    gu = torch.randn(B, 6144, device=DEV).bfloat16()
+    so = torch.empty(B, 3072, dtype=torch.bfloat16, device=DEV)
+    t = timeit(lambda l: ops.silu_mul(gu, out=so), 1, iters=20, reps=50)
+    res["silu_mul 32x6144"] = {"us": t * 1e6}
+    qkv = torch.randn(B, 4096, device=DEV).bfloat16()
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
+    table = torch.randn(4096, 128, device=DEV)
+    slots = torch.stack([perm[:, -1], torch.full((B,), (ctx - 1) % bs, dtype=torch.int32, device=DEV)], 1).contiguous()
+    qo = torch.empty(B, 2048, dtype=torch.bfloat16, device=DEV)
+    t = timeit(lambda l: ops.qknorm_rope_store(qkv, w[:128], w[:128], 1e-6, pos, table, kc[l], vc[l], slots, hq, hkv, bs, q_out=qo), L)
+    res["qknorm_rope_store"] = {"us": t * 1e6}
+    logits = torch.randn(B, 151936, device=DEV).bfloat16()
+    t = timeit(lambda l: ops.argmax(logits), 1, iters=20, reps=10)
+    res["argmax 32x151936"] = {"us": t * 1e6}
+    # empty-launch floor through ctypes (host-bound)
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        ops.silu_mul(gu, out=so)
+    torch.cuda.synchronize()
+    res["host launch via ctypes"] = {"us": (time.perf_counter() - t0) / 2000 * 1e6}
+    for k, v in res.items():
+        print(f"{k:32s} " + "  ".join(f"{a}={b:9.2f}" if isinstance(b, float) else f"{a}={b}" for a, b in v.items()))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/kbench.json", "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
