@@ -197,6 +197,32 @@ int mi_silu_mul(const mi_bf16* x, mi_bf16* out, int rows, int inter,
 int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_bf16* bias,
                         mi_bf16* y, int M, int N, int K, mi_stream stream);
 
+/* Fragment-native weight layout for the decode GEMMs: w_packed[N/16][K/32][64][8] with
+ * w_packed[(tn*K/32 + tk)*512 + lane*8 + e] = w[(16 tn + lane%16)*K + 32 tk + 8 (lane/16) + e],
+ * so one wavefront load is one contiguous 1 KiB MFMA A fragment.  Built once per weight
+ * (after TP sharding); N % 16 == 0, K % 32 == 0. */
+int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream);
+
+/* As mi_gemm_bf16_skinny on packed weights.  epilogue 0: y[M][N] (+bias).
+ * epilogue 1 (SiluAndMul fused, activation.py:10-12 on top of MergedColumnParallelLinear,
+ * linear.py:76-93): w is gate|up stacked, y[M][N/2] = bf16(bf16(silu(bf16 g)) * bf16 u)
+ * with g = row j, u = row j + N/2 of the product — the unfused rounding points. */
+int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16* bias,
+                        mi_bf16* y, int M, int N, int K, int epilogue, mi_stream stream);
+
+/* Split-K over workgroups for the small-N row-parallel projections (o_proj, down_proj):
+ * partials[ksplit][M][N] fp32, summed in split order and rounded to bf16 by the consumer
+ * mi_add_rmsnorm_splitk — together bit-identical to mi_gemm_bf16_packed + mi_add_rmsnorm
+ * up to fp32 summation order. 1 <= ksplit <= 16, K % (32*ksplit) == 0. */
+int mi_gemm_bf16_packed_splitk(const mi_bf16* x, const mi_bf16* w_packed, float* partials,
+                               int M, int N, int K, int ksplit, mi_stream stream);
+
+/* mi_add_rmsnorm whose x is bf16(sum_s partials[s]) (RowParallelLinear output, linear.py:150
+ * followed by RMSNorm.add_rms_forward, layernorm.py:27-38). */
+int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* residual,
+                          const mi_bf16* w, mi_bf16* y, mi_bf16* residual_out, int rows,
+                          int cols, float eps, mi_stream stream);
+
 /* ---- embedding / head (reference: layers/embed_head.py) ------------------- */
 /* VocabParallelEmbedding.forward (embed_head.py:34-42): out[t] = w[ids[t]-vocab_start]
  * if vocab_start <= ids[t] < vocab_start+vocab_local else 0 (TP mask). */

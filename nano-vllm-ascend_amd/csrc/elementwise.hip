@@ -10,9 +10,9 @@ namespace mi {
 // RMSNorm / add+RMSNorm   (reference: layers/layernorm.py:16-38)
 //   LPR lanes cooperate on one row, each holding VPL vectors of 8 bf16.
 // ---------------------------------------------------------------------------
-template <int LPR, int VPL, bool ADD>
+template <int LPR, int VPL, bool ADD, bool PART>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(
-    const uint16_t* __restrict__ x, int64_t x_outer_stride, int inner,
+    const uint16_t* __restrict__ x, const float* __restrict__ part, int nsplit, int64_t x_outer_stride, int inner,
     const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
     uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out,
     int rows, int cols, float eps) {
@@ -33,7 +33,19 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   for (int i = 0; i < VPL; ++i) {
     const int vec = sub + i * LPR;
     if (active && vec < nvec) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + xoff + vec * 8);
+      u32x4 raw;
+      if (PART) {
+        // x is the bf16 rounding of the split-K GEMM result: sum the fp32 partials in split order
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; ++sp) {
+          const float* pp = part + ((int64_t)sp * rows + row) * cols + vec * 8;
+          lo += *reinterpret_cast<const f32x4*>(pp);
+          hi += *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+        raw = u32x4{pack_bf(lo[0], lo[1]), pack_bf(lo[2], lo[3]), pack_bf(hi[0], hi[1]), pack_bf(hi[2], hi[3])};
+      } else {
+        raw = *reinterpret_cast<const u32x4*>(x + xoff + vec * 8);
+      }
       u32x4 rr = {0, 0, 0, 0};
       if (ADD) rr = *reinterpret_cast<const u32x4*>(residual + yoff + vec * 8);
       u32x4 ro;
@@ -76,17 +88,19 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   }
 }
 
-template <bool ADD>
-static int launch_rmsnorm(const uint16_t* x, int64_t xs, int inner, const uint16_t* r,
+template <bool ADD, bool PART = false>
+static int launch_rmsnorm(const uint16_t* x, const float* part, int nsplit, int64_t xs, int inner, const uint16_t* r,
                           const uint16_t* w, uint16_t* y, uint16_t* ro, int rows, int cols,
                           float eps, hipStream_t st) {
   const int nvec = cols / 8;
   auto go = [&](auto lpr_c, auto vpl_c) {
     constexpr int LPR = decltype(lpr_c)::value, VPL = decltype(vpl_c)::value;
-    const int rows_per_block = (256 / 64) * (64 / LPR);
+    // decode-sized inputs (a few dozen rows): one wave per workgroup so the rows spread over CUs
+    const int threads = rows * LPR <= 64 * 64 ? 64 : 256;
+    const int rows_per_block = (threads / 64) * (64 / LPR);
     const int grid = (rows + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL((rmsnorm_kernel<LPR, VPL, ADD>), dim3(grid), dim3(256), 0, st, x, xs, inner, r, w,
-                       y, ro, rows, cols, eps);
+    hipLaunchKernelGGL((rmsnorm_kernel<LPR, VPL, ADD, PART>), dim3(grid), dim3(threads), 0, st, x, part, nsplit, xs,
+                       inner, r, w, y, ro, rows, cols, eps);
   };
   using std::integral_constant;
   if (nvec <= 8) go(integral_constant<int, 8>{}, integral_constant<int, 1>{});
@@ -439,8 +453,8 @@ extern "C" int mi_rmsnorm(const mi_bf16* x, int64_t x_outer_stride, const mi_bf1
   if (cols % 8 != 0 || x_outer_stride % 8 != 0) return MI_EUNSUPPORTED;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return MI_EINVAL;
   if (outer == 0) return MI_OK;
-  return launch_rmsnorm<false>(x, x_outer_stride, inner, nullptr, w, y, nullptr, outer * inner, cols, eps,
-                               S(stream));
+  return launch_rmsnorm<false>(x, nullptr, 0, x_outer_stride, inner, nullptr, w, y, nullptr, outer * inner, cols,
+                               eps, S(stream));
 }
 
 extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* w, mi_bf16* y,
@@ -450,7 +464,20 @@ extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const m
   if (!aligned16(x) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
     return MI_EINVAL;
   if (rows == 0) return MI_OK;
-  return launch_rmsnorm<true>(x, (int64_t)cols, 1, residual, w, y, residual_out, rows, cols, eps, S(stream));
+  return launch_rmsnorm<true>(x, nullptr, 0, (int64_t)cols, 1, residual, w, y, residual_out, rows, cols, eps,
+                              S(stream));
+}
+
+extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* residual, const mi_bf16* w,
+                                     mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
+                                     mi_stream stream) {
+  if (!partials || !residual || !w || !y || !residual_out || rows < 0 || cols <= 0 || nsplit < 1) return MI_EINVAL;
+  if (cols % 8 != 0) return MI_EUNSUPPORTED;
+  if (!aligned16(partials) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
+    return MI_EINVAL;
+  if (rows == 0) return MI_OK;
+  return launch_rmsnorm<true, true>(nullptr, partials, nsplit, (int64_t)cols, 1, residual, w, y, residual_out, rows,
+                                    cols, eps, S(stream));
 }
 
 static int heads_grid(int64_t head_slots) { return (int)((head_slots * 8 + 255) / 256); }

@@ -1,40 +1,63 @@
-// Weight-streaming bf16 GEMM for the decode regime (M <= 64 rows of activations).
+// Weight-streaming bf16 GEMMs for the decode regime (M <= 64 rows of activations).
 //
 //   y[M][N] = x[M][K] @ w[N][K]^T (+ bias)        (reference: F.linear, linear.py:51,73,150)
 //
 // Decode linears are a pure HBM scan of the weight matrix (arithmetic intensity
-// ~M flop/B), so the kernel is organised around the weight stream:
-//   * one workgroup owns 16 consecutive weight rows (output features); its
-//     WAVES wavefronts each stream a K/WAVES slice of those rows straight into
-//     VGPRs as MFMA A fragments (16 B per lane, issued 8 deep before the first
-//     use - no LDS round trip for data that is read exactly once);
-//   * x is tiny and L2-resident; each wave reads its K slice of x as MFMA B
-//     fragments (x^T), so C[n][m] accumulates in fp32 on the matrix cores
+// ~M flop/B), so the kernels are organised around the weight stream:
+//   * a workgroup owns RT x 16 consecutive weight rows (output features); its WAVES
+//     wavefronts each stream a K-slice of those rows straight into VGPRs as MFMA A
+//     fragments (16 B per lane, STEPS k-steps issued before the first use - no LDS round
+//     trip for data that is read exactly once);
+//   * PACKED weights are stored fragment-native, [N/16][K/32][64 lanes][8 bf16]: one
+//     wave-load is one contiguous, fully coalesced 1 KiB of HBM and a wave's whole K-slice
+//     is one contiguous run (mi_pack_weight builds it once at load time).  The row-major
+//     variant reads the same fragments as 16 rows x 64 B pieces;
+//   * x is tiny and L2-resident; each wave reads its K-slice of x as MFMA B fragments
+//     (x^T), so C[n][m] accumulates in fp32 on the matrix cores
 //     (v_mfma_f32_16x16x32_bf16, MT = ceil(M/16) column tiles);
-//   * the K-slices are summed through LDS in a fixed order (deterministic) and
-//     rounded to bf16 once.
+//   * the K-slices of a workgroup are summed through LDS in a fixed order (deterministic)
+//     and rounded to bf16 once - or, for split-K over workgroups, written as fp32 partials
+//     that the consumer (mi_add_rmsnorm_splitk) sums in a fixed order before that rounding.
+// Epilogue EPI_SILU pairs gate row j with up row j + N/2 in one workgroup and writes
+// bf16(bf16(silu(bf16 gate)) * bf16 up): SiluAndMul (activation.py:10-12) on top of
+// MergedColumnParallelLinear with the reference's rounding points, minus one launch.
 #include "mi_common.hpp"
 
 namespace mi {
 
-template <int MT, int WAVES, int STEPS, bool BIAS>
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
+
+template <int MT, int RT, int WAVES, int STEPS, bool PACKED, int EPI, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-    uint16_t* __restrict__ y, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][MT][256]
+    uint16_t* __restrict__ y, float* __restrict__ part, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][RT*MT][256]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * 16;
-  const int kslice = K / WAVES;  // multiple of 32 * STEPS (checked on the host)
-  const int kbeg = wave * kslice;
+  const int ksplit = gridDim.y;
+  const int kslice = K / (ksplit * WAVES);  // multiple of 32 * STEPS (checked on the host)
+  const int kbeg = (blockIdx.y * WAVES + wave) * kslice;
+  const int ktiles = K >> 5;
 
-  f32x4 acc[MT];
+  // row tiles of this workgroup
+  int tile[RT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < RT; ++t)
+    tile[t] = EPI == EPI_SILU ? (int)blockIdx.x + t * (N >> 5) : (int)blockIdx.x * RT + t;
 
-  // A fragment for k-step s: lane (g, r) <- w[n0 + r][k + 32 s + 8 g .. +8]
-  const uint16_t* wp = w + (int64_t)(n0 + r) * K + kbeg + 8 * g;
+  f32x4 acc[RT][MT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint16_t* wp[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    wp[t] = PACKED ? w + ((int64_t)tile[t] * ktiles + (kbeg >> 5)) * 512 + lane * 8
+                   : w + (int64_t)(tile[t] * 16 + r) * K + kbeg + 8 * g;
+  constexpr int WSTEP = PACKED ? 512 : 32;  // elements between consecutive k-steps
   // B fragment of column tile m: lane (g, c) <- x[16 m + c][k + 32 s + 8 g .. +8].  Rows >= M are
   // clamped to row M-1: MFMA output columns are independent, the duplicates are never stored.
   const uint16_t* xp[MT];
@@ -42,11 +65,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   for (int m = 0; m < MT; ++m) xp[m] = x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 8 * g;
 
   for (int k = 0; k < kslice; k += 32 * STEPS) {
-    u32x4 a[STEPS], bfrag[MT][STEPS];
+    u32x4 a[RT][STEPS], bfrag[MT][STEPS];
     // every load of the block is issued before the first MFMA: no branches, no waits in between
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s)
-      a[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + k + 32 * s));
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+        a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 5) + s) * WSTEP));
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -54,90 +79,167 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[s]), as_frag(bfrag[m][s]), acc[m], 0, 0, 0);
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[t][s]), as_frag(bfrag[m][s]),
+                                                              acc[t][m], 0, 0, 0);
   }
 
-  // C fragment: lane (g, c) holds y[m-tile col c][n0 + 4 g + i], i = 0..3
+  // C fragment: lane (g, c) holds y[m-tile col c][16 tile + 4 g + i], i = 0..3
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-    *reinterpret_cast<f32x4*>(red + ((wave * MT + m) * 64 + lane) * 4) = acc[m];
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      *reinterpret_cast<f32x4*>(red + (((wave * RT + t) * MT + m) * 64 + lane) * 4) = acc[t][m];
   __syncthreads();
-  // each (m-tile, lane) result is finished by one thread, summing K-slices in wave order
-  for (int item = threadIdx.x; item < MT * 64; item += WAVES * 64) {
-    const int m = item >> 6, l = item & 63;
-    f32x4 s = *reinterpret_cast<const f32x4*>(red + ((0 * MT + m) * 64 + l) * 4);
+  // each (row tile, m-tile, lane) result is finished by one thread, summing K-slices in wave order
+  constexpr int ITEMS = (EPI == EPI_SILU ? 1 : RT) * MT * 64;
+  for (int item = threadIdx.x; item < ITEMS; item += WAVES * 64) {
+    const int l = item & 63, m = (item >> 6) % MT, t = (item >> 6) / MT;
+    auto total = [&](int tt) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(red + (((0 * RT + tt) * MT + m) * 64 + l) * 4);
 #pragma unroll
-    for (int wv = 1; wv < WAVES; ++wv) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(red + ((wv * MT + m) * 64 + l) * 4);
-      s += t;
-    }
-    const int row = 16 * m + (l & 15);
-    const int col = n0 + 4 * (l >> 4);
-    if (row < M) {
-      if (BIAS) {
-        const u32x2 bw = *reinterpret_cast<const u32x2*>(bias + col);
-        s[0] += lo_bf(bw[0]);
-        s[1] += hi_bf(bw[0]);
-        s[2] += lo_bf(bw[1]);
-        s[3] += hi_bf(bw[1]);
+      for (int wv = 1; wv < WAVES; ++wv) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(red + (((wv * RT + tt) * MT + m) * 64 + l) * 4);
+        s += u;
       }
-      u32x2 o;
-      o[0] = pack_bf(s[0], s[1]);
-      o[1] = pack_bf(s[2], s[3]);
-      *reinterpret_cast<u32x2*>(y + (int64_t)row * N + col) = o;
+      return s;
+    };
+    const int row = 16 * m + (l & 15);
+    if (row >= M) continue;
+    if (EPI == EPI_SILU) {
+      const f32x4 gt = total(0), up = total(1);
+      const int col = (int)blockIdx.x * 16 + 4 * (l >> 4);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gb = rbf(gt[i]);  // the gate_up GEMM output, rounded to bf16 as the unfused path
+        const float sb = rbf(gb / (1.0f + expf(-gb)));
+        o[i] = sb * rbf(up[i]);
+      }
+      u32x2 ov;
+      ov[0] = pack_bf(o[0], o[1]);
+      ov[1] = pack_bf(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(y + (int64_t)row * (N >> 1) + col) = ov;
+    } else {
+      f32x4 s = total(t);
+      const int col = tile[0] * 16 + t * 16 + 4 * (l >> 4);
+      if (EPI == EPI_PARTIAL) {
+        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.y * M + row) * N + col) = s;
+      } else {
+        if (BIAS) {
+          const u32x2 bw = *reinterpret_cast<const u32x2*>(bias + col);
+          s[0] += lo_bf(bw[0]);
+          s[1] += hi_bf(bw[0]);
+          s[2] += lo_bf(bw[1]);
+          s[3] += hi_bf(bw[1]);
+        }
+        u32x2 o;
+        o[0] = pack_bf(s[0], s[1]);
+        o[1] = pack_bf(s[2], s[3]);
+        *reinterpret_cast<u32x2*>(y + (int64_t)row * N + col) = o;
+      }
     }
   }
 }
 
-template <int MT, int WAVES, int STEPS>
-static void launch(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y, int M, int N,
-                   int K, hipStream_t st) {
-  const size_t lds = (size_t)WAVES * MT * 256 * sizeof(float);
-  if (bias)
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, WAVES, STEPS, true>), dim3(N / 16), dim3(WAVES * 64), lds, st,
-                       x, w, bias, y, M, N, K);
-  else
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, WAVES, STEPS, false>), dim3(N / 16), dim3(WAVES * 64), lds, st,
-                       x, w, bias, y, M, N, K);
+// fragment-native repack: dst[(tn * K/32 + tk) * 512 + lane * 8 + e] = src[(16 tn + lane%16) * K + 32 tk + 8 (lane/16) + e]
+__global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t* __restrict__ src,
+                                                          uint16_t* __restrict__ dst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+  const int64_t total = (int64_t)N * K / 8;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const int64_t frag = idx >> 6;
+  const int ktiles = K >> 5;
+  const int tk = frag % ktiles;
+  const int64_t tn = frag / ktiles;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(src + (tn * 16 + (lane & 15)) * K + tk * 32 + (lane >> 4) * 8);
+  *reinterpret_cast<u32x4*>(dst + idx * 8) = v;
 }
 
-// STEPS k-steps (32 * STEPS elements of K) are in flight per wave and loop iteration.
-template <int MT, int WAVES>
-static bool try_waves(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y, int M, int N,
-                      int K, int want_steps, hipStream_t st) {
-  if (K % WAVES) return false;
-  const int kslice = K / WAVES;
-  constexpr int MAXS = MT <= 2 ? 8 : 4;  // register budget: (MT + 1) * STEPS fragments
-  if (MAXS >= 8 && want_steps >= 8 && kslice % 256 == 0) return launch<MT, WAVES, 8>(x, w, bias, y, M, N, K, st), true;
-  if (want_steps >= 4 && kslice % 128 == 0) return launch<MT, WAVES, 4>(x, w, bias, y, M, N, K, st), true;
-  if (want_steps >= 2 && kslice % 64 == 0) return launch<MT, WAVES, 2>(x, w, bias, y, M, N, K, st), true;
-  if (kslice % 32 == 0) return launch<MT, WAVES, 1>(x, w, bias, y, M, N, K, st), true;
+struct GemmArgs {
+  const uint16_t *x, *w, *bias;
+  uint16_t* y;
+  float* part;
+  int M, N, K, ksplit;
+  hipStream_t st;
+};
+
+template <int MT, int RT, int WAVES, int STEPS, bool PACKED, int EPI>
+static void launch(const GemmArgs& a) {
+  const size_t lds = (size_t)WAVES * RT * MT * 256 * sizeof(float);
+  const int tiles = a.N / 16;
+  const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
+  if (a.bias && EPI == EPI_NONE)
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, PACKED, EPI, true>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.M, a.N, a.K);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, PACKED, EPI, false>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.M, a.N, a.K);
+}
+
+// choose STEPS (k-steps in flight per wave and iteration) from the K-slice and the register budget
+template <int MT, int RT, int WAVES, bool PACKED, int EPI>
+static bool try_waves(const GemmArgs& a) {
+  if (a.K % (a.ksplit * WAVES)) return false;
+  const int kslice = a.K / (a.ksplit * WAVES);
+  constexpr int FRAGS = MT + RT;  // fragments (4 VGPRs each) per k-step
+  constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 6 ? 4 : 2);
+  if (MAXS >= 8 && kslice % 256 == 0) return launch<MT, RT, WAVES, 8, PACKED, EPI>(a), true;
+  if (MAXS >= 4 && kslice % 128 == 0) return launch<MT, RT, WAVES, 4, PACKED, EPI>(a), true;
+  if (kslice % 64 == 0) return launch<MT, RT, WAVES, 2, PACKED, EPI>(a), true;
+  if (kslice % 32 == 0) return launch<MT, RT, WAVES, 1, PACKED, EPI>(a), true;
   return false;
 }
 
-template <int MT>
-static int pick_waves(const uint16_t* x, const uint16_t* w, const uint16_t* bias, uint16_t* y, int M, int N,
-                      int K, hipStream_t st) {
-  // Few row tiles (N/16 < ~2 per CU): spread K over many waves so every CU slot holds loads;
+template <int MT, int RT, bool PACKED, int EPI>
+static int pick_waves(const GemmArgs& a) {
+  // Few row tiles (small N): spread K over many waves so that every CU holds loads in flight -
+  // K-slices of 128 (four 1 KiB fragment loads per row tile and wave) when K allows;
   // many row tiles (lm_head): fewer, fatter waves.
-  const int tiles = N / 16;
+  const int wgs = (a.N / 16) / (EPI == EPI_SILU ? 2 : RT) * a.ksplit;
+  const int kper = a.K / a.ksplit;
   bool ok = false;
-  if (tiles >= 2048) {
-    ok = try_waves<MT, 4>(x, w, bias, y, M, N, K, 8, st) || try_waves<MT, 2>(x, w, bias, y, M, N, K, 8, st) ||
-         try_waves<MT, 1>(x, w, bias, y, M, N, K, 8, st);
-  } else if (K >= 2048) {
-    ok = (K % (16 * 128) == 0 && try_waves<MT, 16>(x, w, bias, y, M, N, K, 8, st)) ||
-         (K % (12 * 128) == 0 && try_waves<MT, 12>(x, w, bias, y, M, N, K, 8, st)) ||
-         try_waves<MT, 8>(x, w, bias, y, M, N, K, 8, st) || try_waves<MT, 4>(x, w, bias, y, M, N, K, 8, st);
-  } else {
-    ok = (K % (8 * 128) == 0 && try_waves<MT, 8>(x, w, bias, y, M, N, K, 8, st)) ||
-         (K % (4 * 128) == 0 && try_waves<MT, 4>(x, w, bias, y, M, N, K, 8, st)) ||
-         try_waves<MT, 2>(x, w, bias, y, M, N, K, 8, st);
+  if (wgs >= 2048) {
+    ok = try_waves<MT, RT, 4, PACKED, EPI>(a) || try_waves<MT, RT, 2, PACKED, EPI>(a);
+  } else if (kper % 128 == 0) {
+    switch (kper / 128) {
+      case 1: ok = try_waves<MT, RT, 1, PACKED, EPI>(a); break;
+      case 2: ok = try_waves<MT, RT, 2, PACKED, EPI>(a); break;
+      case 3: ok = try_waves<MT, RT, 3, PACKED, EPI>(a); break;
+      case 4: ok = try_waves<MT, RT, 4, PACKED, EPI>(a); break;
+      case 6: ok = try_waves<MT, RT, 6, PACKED, EPI>(a); break;
+      case 8: ok = try_waves<MT, RT, 8, PACKED, EPI>(a); break;
+      case 12: ok = try_waves<MT, RT, 12, PACKED, EPI>(a); break;
+      case 16: ok = try_waves<MT, RT, 16, PACKED, EPI>(a); break;
+      case 24: ok = try_waves<MT, RT, 12, PACKED, EPI>(a); break;
+      case 32: ok = try_waves<MT, RT, 16, PACKED, EPI>(a); break;
+      default: break;
+    }
   }
-  if (!ok) ok = try_waves<MT, 1>(x, w, bias, y, M, N, K, 8, st);
+  if (!ok) ok = try_waves<MT, RT, 8, PACKED, EPI>(a) || try_waves<MT, RT, 4, PACKED, EPI>(a) ||
+                try_waves<MT, RT, 2, PACKED, EPI>(a) || try_waves<MT, RT, 1, PACKED, EPI>(a);
   if (!ok) return MI_EUNSUPPORTED;
   return check_launch();
+}
+
+template <int RT, bool PACKED, int EPI>
+static int pick_mt(const GemmArgs& a) {
+  switch ((a.M + 15) / 16) {
+    case 1: return pick_waves<1, RT, PACKED, EPI>(a);
+    case 2: return pick_waves<2, RT, PACKED, EPI>(a);
+    case 3: return pick_waves<3, RT, PACKED, EPI>(a);
+    default: return pick_waves<4, RT, PACKED, EPI>(a);
+  }
+}
+
+static int check_gemm(const void* x, const void* w, const void* y, int M, int N, int K) {
+  if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return MI_EINVAL;
+  if (M > 64 || K % 32 || N % 16) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return MI_EINVAL;
+  return MI_OK;
 }
 
 }  // namespace mi
@@ -146,15 +248,43 @@ using namespace mi;
 
 extern "C" int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y, int M,
                                    int N, int K, mi_stream stream) {
-  if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return MI_EINVAL;
-  if (M > 64 || K % 32 || N % 16) return MI_EUNSUPPORTED;
-  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias))) return MI_EINVAL;
+  int rc = check_gemm(x, w, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (bias && !aligned16(bias)) return MI_EINVAL;
   if (M == 0) return MI_OK;
-  hipStream_t st = S(stream);
-  switch ((M + 15) / 16) {
-    case 1: return pick_waves<1>(x, w, bias, y, M, N, K, st);
-    case 2: return pick_waves<2>(x, w, bias, y, M, N, K, st);
-    case 3: return pick_waves<3>(x, w, bias, y, M, N, K, st);
-    default: return pick_waves<4>(x, w, bias, y, M, N, K, st);
-  }
+  return pick_mt<1, false, EPI_NONE>(GemmArgs{x, w, bias, y, nullptr, M, N, K, 1, S(stream)});
+}
+
+extern "C" int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream) {
+  if (!w || !w_packed || N <= 0 || K <= 0) return MI_EINVAL;
+  if (N % 16 || K % 32) return MI_EUNSUPPORTED;
+  if (!aligned16(w) || !aligned16(w_packed)) return MI_EINVAL;
+  const int64_t chunks = (int64_t)N * K / 8;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, S(stream), w,
+                     w_packed, N, K);
+  return check_launch();
+}
+
+extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16* bias, mi_bf16* y,
+                                   int M, int N, int K, int epilogue, mi_stream stream) {
+  int rc = check_gemm(x, w_packed, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (bias && !aligned16(bias)) return MI_EINVAL;
+  if (epilogue != 0 && epilogue != 1) return MI_EINVAL;
+  if (epilogue == 1 && (bias || N % 32)) return MI_EUNSUPPORTED;
+  if (M == 0) return MI_OK;
+  const GemmArgs a{x, w_packed, bias, y, nullptr, M, N, K, 1, S(stream)};
+  if (epilogue == 1) return pick_mt<2, true, EPI_SILU>(a);
+  // two row tiles per workgroup halve the x traffic per weight byte once there are plenty of tiles
+  if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, true, EPI_NONE>(a);
+  return pick_mt<1, true, EPI_NONE>(a);
+}
+
+extern "C" int mi_gemm_bf16_packed_splitk(const mi_bf16* x, const mi_bf16* w_packed, float* partials, int M, int N,
+                                          int K, int ksplit, mi_stream stream) {
+  int rc = check_gemm(x, w_packed, partials, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (ksplit < 1 || ksplit > 16 || K % (32 * ksplit)) return MI_EUNSUPPORTED;
+  if (M == 0) return MI_OK;
+  return pick_mt<1, true, EPI_PARTIAL>(GemmArgs{x, w_packed, nullptr, nullptr, partials, M, N, K, ksplit, S(stream)});
 }

@@ -19,33 +19,39 @@
 // Decode splits each sequence's context over `nsplit` workgroups (flash-decoding)
 // whose ranges are derived on the device from context_lens, so the launch
 // geometry is static and hipGraph-capturable; a second kernel merges the splits.
+#include <stdlib.h>
+
 #include "mi_common.hpp"
 
 namespace mi {
 
 __device__ __forceinline__ void load_tile(const uint16_t* __restrict__ tile, int lane, u32x4 (&f)[4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4*>(tile + i * 512 + lane * 8);
+  for (int i = 0; i < 4; ++i)  // streamed once: non-temporal (measured +10-15 % HBM read bandwidth)
+    f[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tile + i * 512 + lane * 8));
 }
 
-// Attend one chunk.  `limit`: tokens with index < limit are visible to this lane's column.
-__device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
-                                             const u32x4 (&V0)[4], const u32x4 (&V1)[4],
-                                             const bf16x8 (&Q)[4], int tok0, int limit, float scale_log2e,
-                                             int g, float& m, float& l, f32x4 (&acc)[8]) {
+// S^T = K . Q^T for one chunk, masked and scaled to the log2 domain.
+// `limit`: tokens with index < limit are visible to this lane's column.
+__device__ __forceinline__ void score_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4], const bf16x8 (&Q)[4],
+                                            int tok0, int limit, float scale_log2e, int g, float (&p)[8]) {
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K0[kk]), Q[kk], s0, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K1[kk]), Q[kk], s1, 0, 0, 0);
   }
-  float p[8];
   const int t0 = tok0 + 4 * g;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     p[r] = (t0 + r < limit) ? s0[r] * scale_log2e : -INFINITY;
     p[4 + r] = (t0 + 16 + r < limit) ? s1[r] * scale_log2e : -INFINITY;
   }
+}
+
+// online softmax update + O^T += V^T . P for one chunk
+__device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0)[4], const u32x4 (&V1)[4],
+                                                 float& m, float& l, f32x4 (&acc)[8]) {
   float mc = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
   mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
   mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
@@ -80,6 +86,23 @@ __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (
   }
 }
 
+__device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
+                                             const u32x4 (&V0)[4], const u32x4 (&V1)[4],
+                                             const bf16x8 (&Q)[4], int tok0, int limit, float scale_log2e,
+                                             int g, float& m, float& l, f32x4 (&acc)[8]) {
+  float p[8];
+  score_chunk(K0, K1, Q, tok0, limit, scale_log2e, g, p);
+  accumulate_chunk(p, V0, V1, m, l, acc);
+}
+
+// element strides of the KV cache: block id, kv head, 16-token tile inside a block
+struct KvStrides {
+  int64_t block, head, tile;
+};
+__host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb) {
+  return KvStrides{(int64_t)n_kv_heads * tpb * MI_KV_TILE_ELEMS, (int64_t)tpb * MI_KV_TILE_ELEMS, MI_KV_TILE_ELEMS};
+}
+
 // Issue the 16 fragment loads of chunk `c` (tiles 2c, 2c+1).  `c` and the table row are
 // wave-uniform, so the two block ids come from scalar loads and all vector loads are issued
 // back to back with no wait in between.  A second tile past the end of the context is
@@ -87,61 +110,111 @@ __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (
 // reach the output (p == 0 exactly) and no branch or zero-fill is needed.
 __device__ __forceinline__ void load_chunk(const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
                                            const int32_t* __restrict__ table_row, int c, int n_tiles, int h,
-                                           int n_kv_heads, int tpb, int lane, u32x4 (&K0)[4], u32x4 (&K1)[4],
+                                           KvStrides st, int tpb, int lane, u32x4 (&K0)[4], u32x4 (&K1)[4],
                                            u32x4 (&V0)[4], u32x4 (&V1)[4]) {
   const int tile0 = 2 * c;
   const int tile1 = (2 * c + 1 < n_tiles) ? 2 * c + 1 : tile0;
   const int blk0 = table_row[tile0 / tpb];
   const int blk1 = table_row[tile1 / tpb];
-  const int64_t base0 = (((int64_t)blk0 * n_kv_heads + h) * tpb + (tile0 % tpb)) * MI_KV_TILE_ELEMS;
-  const int64_t base1 = (((int64_t)blk1 * n_kv_heads + h) * tpb + (tile1 % tpb)) * MI_KV_TILE_ELEMS;
+  const int64_t base0 = (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(tile0 % tpb) * st.tile;
+  const int64_t base1 = (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(tile1 % tpb) * st.tile;
   load_tile(kc + base0, lane, K0);
   load_tile(kc + base1, lane, K1);
   load_tile(vc + base0, lane, V0);
   load_tile(vc + base1, lane, V1);
 }
 
+// one cache (K or V) of chunk `c`: 8 fragment loads
+__device__ __forceinline__ void load_chunk_k(const uint16_t* __restrict__ cache, const int32_t* __restrict__ table_row,
+                                             int c, int n_tiles, int h, KvStrides st, int tpb, int lane,
+                                             u32x4 (&T0)[4], u32x4 (&T1)[4]) {
+  const int tile0 = 2 * c;
+  const int tile1 = (2 * c + 1 < n_tiles) ? 2 * c + 1 : tile0;
+  const int blk0 = table_row[tile0 / tpb];
+  const int blk1 = table_row[tile1 / tpb];
+  load_tile(cache + (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(tile0 % tpb) * st.tile, lane, T0);
+  load_tile(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(tile1 % tpb) * st.tile, lane, T1);
+}
+
 // ---------------------------------------------------------------------------
-// decode: grid (nsplit, n_kv_heads, batch), 4 waves
+// decode: grid (splits, n_kv_heads, batch), WAVES wavefronts per workgroup
+//
+// A workgroup owns one (sequence, kv head[, split]); its waves take the chunks of its range
+// round-robin and keep a running (max, sum, O) each; all 16 fragment loads of a chunk are issued
+// back to back (a software-pipelined variant that re-issued K/V loads mid-chunk spilled 50 VGPRs at
+// the 128-register budget of a 16-wave workgroup and measured 1.7x slower).  The waves are merged
+// through LDS; with one split per sequence (the batched
+// regime: batch * kv_heads >= ~128 workgroups) the workgroup writes the final bf16 row itself
+// and nothing else is launched.  With more splits (small batches) fp32 partials go to the
+// workspace and a tiny second kernel merges them.
+// The launch geometry is static (hipGraph); the work adapts to context_lens on the device.
 // ---------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(256) void paged_attn_decode_kernel(
+__device__ __forceinline__ int chunks_per_split(int n_chunks, int splits, int waves) {
+  return waves * ((n_chunks + waves * splits - 1) / (waves * splits));
+}
+
+template <int G, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ ctx_lens, float* __restrict__ part_o, float* __restrict__ part_ml,
-    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) float sm_o[4][G][128];
-  __shared__ float sm_m[4][16];
-  __shared__ float sm_l[4][16];
+    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
+  __shared__ float sm_m[WAVES][16];
+  __shared__ float sm_l[WAVES][16];
 
-  const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
   const int ctx = max(ctx_lens[b], 0);
   const int n_chunks = (ctx + 31) >> 5, n_tiles = (ctx + 15) >> 4;
-  const int cps = (n_chunks + nsplit - 1) / nsplit;
+  const int cps = chunks_per_split(n_chunks, splits, WAVES);
   const int c0 = split * cps, c1 = min(n_chunks, c0 + cps);
-
-  bf16x8 Q[4];
-  {
-    const uint16_t* qp = q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 + 8 * g;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);  // n >= G reads head 0 (valid memory)
-      if (n >= G) v = u32x4{0, 0, 0, 0};
-      Q[kk] = as_frag(v);
+  const int64_t row0 = (int64_t)b * n_q_heads + h * G;  // first q head of this kv head
+  if (c0 >= n_chunks) {  // uniform for the workgroup: nothing to attend in this split
+    if (splits == 1) {   // empty context (graph padding row): the output row is zero
+      for (int idx = threadIdx.x; idx < G * 64; idx += WAVES * 64)
+        *reinterpret_cast<uint32_t*>(out + row0 * 128 + 2 * idx) = 0u;
+    } else {
+      for (int hn = threadIdx.x; hn < G; hn += WAVES * 64) {
+        part_ml[((row0 + hn) * 16 + split) * 2] = -INFINITY;
+        part_ml[((row0 + hn) * 16 + split) * 2 + 1] = 0.f;
+      }
     }
+    return;
   }
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int32_t* table_row = block_table + (int64_t)b * table_stride;
+
   float m = -INFINITY, l = 0.f;
   f32x4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int32_t* table_row = block_table + (int64_t)b * table_stride;
-  for (int c = c0 + wave; c < c1; c += 4) {
+  int c = c0 + wave;
+  if (c < c1) {
     u32x4 K0[4], K1[4], V0[4], V1[4];
-    load_chunk(kc, vc, table_row, c, n_tiles, h, n_kv_heads, tpb, lane, K0, K1, V0, V1);
-    attend_chunk(K0, K1, V0, V1, Q, c * 32, ctx, scale_log2e, g, m, l, acc);
+    load_chunk_k(kc, table_row, c, n_tiles, h, kvs, tpb, lane, K0, K1);  // KV stream first ...
+    load_chunk_k(vc, table_row, c, n_tiles, h, kvs, tpb, lane, V0, V1);
+    bf16x8 Q[4];                                                          // ... then the (L2-resident) query
+    {
+      const uint16_t* qp = q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 + 8 * g;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);  // n >= G reads head 0 (valid memory)
+        if (n >= G) v = u32x4{0, 0, 0, 0};
+        Q[kk] = as_frag(v);
+      }
+    }
+    {
+      while (true) {
+        attend_chunk(K0, K1, V0, V1, Q, c * 32, ctx, scale_log2e, g, m, l, acc);
+        c += WAVES;
+        if (c >= c1) break;
+        load_chunk_k(kc, table_row, c, n_tiles, h, kvs, tpb, lane, K0, K1);
+        load_chunk_k(vc, table_row, c, n_tiles, h, kvs, tpb, lane, V0, V1);
+      }
+    }
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -155,43 +228,59 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < G * 128; idx += 256) {
+  // merge the waves (wave 0 always has a chunk, so M is finite)
+  for (int idx = threadIdx.x; idx < G * 128; idx += WAVES * 64) {
     const int hn = idx >> 7, d = idx & 127;
-    const float m0 = sm_m[0][hn], m1 = sm_m[1][hn], m2 = sm_m[2][hn], m3 = sm_m[3][hn];
-    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    float M = sm_m[0][hn];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[w][hn]);
     float o = 0.f, L = 0.f;
-    if (M != -INFINITY) {
-      const float e0 = exp2f(m0 - M), e1 = exp2f(m1 - M), e2 = exp2f(m2 - M), e3 = exp2f(m3 - M);
-      o = e0 * sm_o[0][hn][d] + e1 * sm_o[1][hn][d] + e2 * sm_o[2][hn][d] + e3 * sm_o[3][hn][d];
-      L = e0 * sm_l[0][hn] + e1 * sm_l[1][hn] + e2 * sm_l[2][hn] + e3 * sm_l[3][hn];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const float e = exp2f(sm_m[w][hn] - M);
+      o += e * sm_o[w][hn][d];
+      L += e * sm_l[w][hn];
     }
-    const int64_t slot = ((int64_t)b * n_q_heads + h * G + hn) * nsplit + split;
-    part_o[slot * 128 + d] = o;
-    if (d == 0) {
-      part_ml[slot * 2] = M;
-      part_ml[slot * 2 + 1] = L;
+    if (splits == 1) {
+      out[(row0 + hn) * 128 + d] = f2bf(o / L);
+    } else {
+      const int64_t slot = (row0 + hn) * 16 + split;
+      part_o[slot * 128 + d] = o;
+      if (d == 0) {
+        part_ml[slot * 2] = M;
+        part_ml[slot * 2 + 1] = L;
+      }
     }
   }
 }
 
-// merge the splits: grid (batch * n_q_heads), 128 threads
-__global__ __launch_bounds__(128) void paged_attn_merge_kernel(const float* __restrict__ part_o,
+// merge the splits (small batches only): one wave per (sequence, q head) row, lane = 2 dims
+__global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __restrict__ part_o,
                                                                const float* __restrict__ part_ml,
-                                                               uint16_t* __restrict__ out, int nsplit) {
-  const int64_t row = blockIdx.x;
-  const int d = threadIdx.x;
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(row * nsplit + s) * 2]);
-  float num = 0.f, den = 0.f;
-  if (M != -INFINITY) {
-    for (int s = 0; s < nsplit; ++s) {
-      const float ms = part_ml[(row * nsplit + s) * 2];
-      const float e = exp2f(ms - M);
-      num += e * part_o[(row * nsplit + s) * 128 + d];
-      den += e * part_ml[(row * nsplit + s) * 2 + 1];
+                                                               uint16_t* __restrict__ out, int n_rows, int splits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float ms = -INFINITY, ls = 0.f;
+  if (lane < splits) {
+    const float2 ml = *reinterpret_cast<const float2*>(part_ml + (row * 16 + lane) * 2);
+    ms = ml.x;
+    ls = ml.y;
+  }
+  const float M = wave_max(ms);
+  const float e = (lane < splits && ms != -INFINITY) ? exp2f(ms - M) : 0.f;
+  const float den = wave_sum(e * ls);
+  float2 acc = {0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float es = __shfl(e, s, 64);
+    if (es != 0.f) {  // wave-uniform; empty splits never wrote their partial rows
+      const float2 o = *reinterpret_cast<const float2*>(part_o + (row * 16 + s) * 128 + 2 * lane);
+      acc.x += es * o.x;
+      acc.y += es * o.y;
     }
   }
-  out[row * 128 + d] = f2bf(den > 0.f ? num / den : 0.f);
+  const float inv = den > 0.f ? 1.0f / den : 0.f;
+  *reinterpret_cast<uint32_t*>(out + row * 128 + 2 * lane) = pack_bf(acc.x * inv, acc.y * inv);
 }
 
 // ---------------------------------------------------------------------------
@@ -240,7 +329,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const int32_t* table_row = block_table + (int64_t)seq * table_stride;
   for (int c = 0; c < n_chunks; ++c) {
     u32x4 K0[4], K1[4], V0[4], V1[4];
-    load_chunk(kc, vc, table_row, c, n_tiles, h, n_kv_heads, tpb, lane, K0, K1, V0, V1);
+    load_chunk(kc, vc, table_row, c, n_tiles, h, default_strides(n_kv_heads, tpb), tpb, lane, K0, K1, V0, V1);
     attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, scale_log2e, g, m, l, acc);
   }
   l += __shfl_xor(l, 16, 64);
@@ -257,9 +346,13 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   }
 }
 
-static int decode_nsplit(int batch, int n_kv_heads) {
-  const int base = batch * n_kv_heads;
-  int ns = 2048 / (base > 0 ? base : 1);
+// waves per workgroup: as many as the LDS merge buffer (WAVES * G * 512 B) and the register file allow
+static int decode_waves(int G) { return G <= 4 ? 16 : (G <= 8 ? 8 : 4); }
+
+// splits per (sequence, kv head): aim at ~16 waves per CU over the whole launch
+static int decode_splits(int batch, int n_kv_heads, int waves) {
+  const int base = batch * n_kv_heads * waves;
+  int ns = 4096 / (base > 0 ? base : 1);
   if (ns < 1) ns = 1;
   if (ns > 16) ns = 16;
   return ns;
@@ -269,6 +362,8 @@ static int decode_nsplit(int batch, int n_kv_heads) {
 
 using namespace mi;
 
+// [batch*n_q_heads][16 splits][128] fp32 partial outputs + [..][16][2] (max, sum); only touched
+// when a sequence is split over several workgroups (small batches).
 extern "C" size_t mi_paged_attn_decode_workspace(int batch, int n_q_heads) {
   if (batch <= 0 || n_q_heads <= 0) return 0;
   return (size_t)batch * n_q_heads * 16 * (128 + 2) * sizeof(float);
@@ -285,11 +380,10 @@ static int check_attn_common(const void* q, const void* kc, const void* vc, cons
   return MI_OK;
 }
 
-extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
-                                    const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
-                                    const int32_t* context_lens, mi_bf16* out, void* workspace,
-                                    size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
-                                    int block_size, float scale, mi_stream stream) {
+static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache, const mi_bf16* v_cache,
+                       const int32_t* block_table, int table_stride, const int32_t* context_lens, mi_bf16* out,
+                       void* workspace, size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                       int block_size, float scale, int num_splits, KvStrides kvs, mi_stream stream) {
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -298,29 +392,54 @@ extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, cons
   if (batch == 0) return MI_OK;
   if (ws_bytes < mi_paged_attn_decode_workspace(batch, n_q_heads)) return MI_EWORKSPACE;
   const int G = n_q_heads / n_kv_heads;
-  const int nsplit = decode_nsplit(batch, n_kv_heads);
+  const int waves = decode_waves(G);
+  int nsplit = num_splits > 0 ? num_splits : decode_splits(batch, n_kv_heads, waves);
+  if (nsplit > 16) nsplit = 16;
   float* part_o = static_cast<float*>(workspace);
   float* part_ml = part_o + (size_t)batch * n_q_heads * 16 * 128;
   const float sl2 = scale * 1.4426950408889634f;
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
-#define LAUNCH_DEC(GG)                                                                                       \
-  hipLaunchKernelGGL((paged_attn_decode_kernel<GG>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,       \
-                     v_cache, block_table, table_stride, context_lens, part_o, part_ml, n_q_heads,          \
-                     n_kv_heads, block_size / 16, sl2)
+#define LAUNCH_DEC(GG, WW)                                                                                   \
+  hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW>), grid, dim3(WW * 64), 0, st, q, q_row_stride, k_cache, \
+                     v_cache, block_table, table_stride, context_lens, part_o, part_ml, out, n_q_heads, kvs, \
+                     block_size / 16, sl2)
   switch (G) {
-    case 1: LAUNCH_DEC(1); break;
-    case 2: LAUNCH_DEC(2); break;
-    case 4: LAUNCH_DEC(4); break;
-    case 8: LAUNCH_DEC(8); break;
-    default: LAUNCH_DEC(16); break;
+    case 1: LAUNCH_DEC(1, 16); break;
+    case 2: LAUNCH_DEC(2, 16); break;
+    case 4: LAUNCH_DEC(4, 16); break;
+    case 8: LAUNCH_DEC(8, 8); break;
+    default: LAUNCH_DEC(16, 4); break;
   }
 #undef LAUNCH_DEC
   rc = check_launch();
-  if (rc != MI_OK) return rc;
-  hipLaunchKernelGGL(paged_attn_merge_kernel, dim3(batch * n_q_heads), dim3(128), 0, st, part_o, part_ml, out,
+  if (rc != MI_OK || nsplit == 1) return rc;
+  const int rows = batch * n_q_heads;
+  hipLaunchKernelGGL(paged_attn_merge_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, part_o, part_ml, out, rows,
                      nsplit);
   return check_launch();
+}
+
+extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                                    const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                    const int32_t* context_lens, mi_bf16* out, void* workspace,
+                                    size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                                    int block_size, float scale, mi_stream stream) {
+  return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out, workspace,
+                     ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, 0,
+                     default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream);
+}
+
+// experiment entry point (not part of the public header yet): explicit split count and cache strides
+extern "C" int mi_paged_attn_decode_ex(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                                       const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                       const int32_t* context_lens, mi_bf16* out, void* workspace,
+                                       size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                                       int block_size, float scale, int num_splits, int64_t stride_block,
+                                       int64_t stride_head, int64_t stride_tile, mi_stream stream) {
+  return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out, workspace,
+                     ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, num_splits,
+                     KvStrides{stride_block, stride_head, stride_tile}, stream);
 }
 
 extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,

@@ -72,6 +72,10 @@ _SIGNATURES = {
     ),
     "mi_silu_mul": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_skinny": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_pack_weight": (c_int, [_p, _p, c_int, c_int, _p]),
+    "mi_gemm_bf16_packed": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_gemm_bf16_packed_splitk": (c_int, [_p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_embedding": (c_int, [_p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
     "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),
     "mi_argmax": (c_int, [_p, c_int64, _p, c_int, c_int, _p]),

@@ -6,7 +6,7 @@ import torch.distributed as dist
 from torch import nn
 
 from nanovllm import ops
-from nanovllm.layers.linear import linear_forward
+from nanovllm.layers.linear import can_pack, linear_forward
 from nanovllm.layers.parallel import all_reduce_sum, tp_rank, tp_size
 from nanovllm.utils.context import get_context
 
@@ -39,12 +39,16 @@ class ParallelLMHead(VocabParallelEmbedding):
     def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False):
         assert not bias
         super().__init__(num_embeddings, embedding_dim)
+        self.weight_packed = None
+
+    def pack(self) -> None:
+        self.weight_packed = ops.pack_weight(self.weight.data, self.weight_packed) if can_pack(self.weight.data) else None
 
     def forward(self, x: torch.Tensor):
         context = get_context()
         if context.is_prefill:  # keep only each sequence's last token (embed_head.py:58-60)
             x = ops.gather_last_tokens(x, context.cu_seqlens_q)
-        logits = linear_forward(x, self.weight, None)
+        logits = linear_forward(x, self.weight, None, self.weight_packed)
         if self.tp_size > 1:  # vocab shards -> rank 0 (embed_head.py:62-65)
             parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
             dist.gather(logits, parts, 0)

@@ -15,12 +15,19 @@ from nanovllm import ops
 from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
 
 
-def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None,
+                   packed: torch.Tensor | None = None) -> torch.Tensor:
     rows = x.numel() // x.shape[-1]
     if rows <= ops.SKINNY_MAX_M and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0:
+        if packed is not None:
+            return ops.gemm_packed(x, packed, bias)
         return ops.gemm_skinny(x, weight, bias)
     ops.require_gpu(x, weight)
     return F.linear(x, weight, bias)
+
+
+def can_pack(weight: torch.Tensor) -> bool:
+    return weight.is_cuda and weight.dim() == 2 and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0
 
 
 class LinearBase(nn.Module):
@@ -36,6 +43,12 @@ class LinearBase(nn.Module):
             self.bias.weight_loader = self.weight_loader
         else:
             self.register_parameter("bias", None)
+        self.weight_packed: torch.Tensor | None = None
+
+    def pack(self) -> None:
+        """Build the fragment-native copy of the (already sharded) weight that the decode GEMMs
+        stream (mi_pack_weight); call again after the weight changes."""
+        self.weight_packed = ops.pack_weight(self.weight.data, self.weight_packed) if can_pack(self.weight.data) else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
@@ -49,7 +62,7 @@ class ReplicatedLinear(LinearBase):
         param.data.copy_(loaded_weight)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return linear_forward(x, self.weight, self.bias)
+        return linear_forward(x, self.weight, self.bias, self.weight_packed)
 
 
 class ColumnParallelLinear(LinearBase):
@@ -63,7 +76,7 @@ class ColumnParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * rows, rows))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return linear_forward(x, self.weight, self.bias)
+        return linear_forward(x, self.weight, self.bias, self.weight_packed)
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
@@ -110,5 +123,5 @@ class RowParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * cols, cols))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = linear_forward(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        y = linear_forward(x, self.weight, self.bias if self.tp_rank == 0 else None, self.weight_packed)
         return all_reduce_sum(y)

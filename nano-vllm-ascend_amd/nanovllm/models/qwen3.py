@@ -145,17 +145,62 @@ class Qwen3DecoderLayer(nn.Module):
 class Qwen3Model(nn.Module):
     def __init__(self, config, fused: bool = True) -> None:
         super().__init__()
+        self.fused = fused
         self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
         self.layers = nn.ModuleList([Qwen3DecoderLayer(config, fused) for _ in range(config.num_hidden_layers)])
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        if self.fused and input_ids.numel() <= ops.SKINNY_MAX_M and tp_size() == 1 and self._can_stream():
+            return self._forward_streaming(input_ids, positions)
         hidden_states = self.embed_tokens(input_ids)
         residual = None
         for layer in self.layers:
             hidden_states, residual = layer(positions, hidden_states, residual)
         hidden_states, _ = self.norm(hidden_states, residual)
         return hidden_states
+
+    # -- decode-regime fast path ------------------------------------------------------------------
+    def _can_stream(self) -> bool:
+        l0 = self.layers[0]
+        return (l0.self_attn.attn.k_cache.numel() > 0 and l0.self_attn.qkv_proj.weight_packed is not None
+                and l0.self_attn.o_proj.weight_packed is not None and l0.mlp.down_proj.weight_packed is not None
+                and l0.mlp.gate_up_proj.weight_packed is not None and l0.self_attn.qkv_proj.bias is None)
+
+    @staticmethod
+    def _ksplit(weight: torch.Tensor) -> int:
+        """Split K over enough workgroups that a small-N projection still covers the 256 CUs."""
+        n, k = weight.shape
+        want = max(1, 256 // max(1, n // 16))
+        ks = 1
+        while ks * 2 <= min(want, 16) and k % (ks * 2 * 128) == 0:
+            ks *= 2
+        return ks
+
+    def _forward_streaming(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        """<= 64 tokens (every decode step): 7 launches per layer instead of 10 -
+          add+RMSNorm (summing the previous projection's split-K partials) -> packed qkv GEMM ->
+          q/k-norm+RoPE+KV-store -> paged attention -> split-K o_proj -> add+RMSNorm ->
+          packed gate_up GEMM with the SwiGLU epilogue -> split-K down_proj.
+        Rounding points are those of the module-by-module path (tests require equal results up to
+        fp32 summation order)."""
+        h = self.embed_tokens(input_ids)
+        residual, parts = None, None
+        for layer in self.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
+            if residual is None:
+                residual, x = h, ops.rmsnorm(h, ln1.weight, ln1.eps)
+            else:
+                x, residual = ops.add_rmsnorm_splitk(parts, residual, ln1.weight, ln1.eps)
+            qkv = ops.gemm_packed(x, attn.qkv_proj.weight_packed)
+            o = attn._attend_fused(positions, qkv)
+            parts = ops.gemm_packed_splitk(o, attn.o_proj.weight_packed, self._ksplit(attn.o_proj.weight))
+            x, residual = ops.add_rmsnorm_splitk(parts, residual, ln2.weight, ln2.eps)
+            act = ops.gemm_packed(x, mlp.gate_up_proj.weight_packed, silu_mul=True)
+            parts = ops.gemm_packed_splitk(act, mlp.down_proj.weight_packed, self._ksplit(mlp.down_proj.weight))
+        x, _ = ops.add_rmsnorm_splitk(parts, residual, self.norm.weight, self.norm.eps)
+        return x
 
 
 class Qwen3ForCausalLM(nn.Module):

@@ -72,7 +72,7 @@ def attn_workspace(device, batch: int, n_q_heads: int) -> torch.Tensor:
     need = lib.mi_paged_attn_decode_workspace(batch, n_q_heads)
     ws = _WORKSPACES.get(device)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)  # arrival counters start at zero
         _WORKSPACES[device] = ws
     return ws
 
@@ -233,6 +233,66 @@ def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
         out = torch.empty((*x.shape[:-1], N), dtype=_BF16, device=x.device)
     check(lib.mi_gemm_bf16_skinny(ptr(x), ptr(w), ptr(bias), ptr(out), M, N, K, stream()), "mi_gemm_bf16_skinny")
     return out
+
+
+def pack_weight(w, out=None) -> torch.Tensor:
+    """Fragment-native copy of a [N, K] weight for the decode GEMMs (same shape/bytes).
+    Pass the previous copy as `out` to refresh it in place (captured graphs keep its address)."""
+    require_gpu(w)
+    _bf16(w)
+    assert w.dim() == 2 and w.is_contiguous()
+    if out is None or out.shape != w.shape or out.device != w.device:
+        out = torch.empty_like(w)
+    check(lib.mi_pack_weight(ptr(w), ptr(out), w.shape[0], w.shape[1], stream()), "mi_pack_weight")
+    return out
+
+
+def gemm_packed(x, w_packed, bias=None, out=None, silu_mul: bool = False) -> torch.Tensor:
+    require_gpu(x, w_packed, bias)
+    _bf16(x, w_packed, bias)
+    assert x.is_contiguous() and w_packed.is_contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w_packed.shape[0]
+    assert w_packed.shape[1] == K
+    n_out = N // 2 if silu_mul else N
+    if out is None:
+        out = torch.empty((*x.shape[:-1], n_out), dtype=_BF16, device=x.device)
+    check(lib.mi_gemm_bf16_packed(ptr(x), ptr(w_packed), ptr(bias), ptr(out), M, N, K, int(silu_mul), stream()),
+          "mi_gemm_bf16_packed")
+    return out
+
+
+def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:
+    """fp32 partials [ksplit, M, N] of x @ w.T; consume with add_rmsnorm_splitk."""
+    require_gpu(x, w_packed)
+    _bf16(x, w_packed)
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w_packed.shape[0]
+    if out is None:
+        out = torch.empty((ksplit, M, N), dtype=torch.float32, device=x.device)
+    check(lib.mi_gemm_bf16_packed_splitk(ptr(x), ptr(w_packed), ptr(out), M, N, K, ksplit, stream()),
+          "mi_gemm_bf16_packed_splitk")
+    return out
+
+
+def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out=None):
+    require_gpu(partials, residual, w)
+    _bf16(residual, w)
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and residual.is_contiguous()
+    nsplit, cols = partials.shape[0], residual.shape[-1]
+    rows = residual.numel() // cols
+    if out is None:
+        out = torch.empty_like(residual)
+    if residual_out is None:
+        residual_out = torch.empty_like(residual)
+    check(
+        lib.mi_add_rmsnorm_splitk(ptr(partials), nsplit, ptr(residual), ptr(w), ptr(out), ptr(residual_out), rows,
+                                  cols, float(eps), stream()),
+        "mi_add_rmsnorm_splitk",
+    )
+    return out, residual_out
 
 
 def embedding(ids, w, vocab_start: int = 0, out=None) -> torch.Tensor:

@@ -41,6 +41,13 @@ def _route(model: nn.Module, name: str, tensor: torch.Tensor) -> None:
     getattr(param, "weight_loader", default_weight_loader)(param, tensor)
 
 
+def pack_model_weights(model: nn.Module) -> None:
+    """(Re)build the fragment-native weight copies of every linear layer that lives on a GPU."""
+    for m in model.modules():
+        if hasattr(m, "pack") and m.weight.is_cuda:
+            m.pack()
+
+
 def load_model(model: nn.Module, path: str, name_mapping=None) -> None:
     from safetensors import safe_open
 
@@ -55,6 +62,7 @@ def load_model(model: nn.Module, path: str, name_mapping=None) -> None:
                         tied.data_ptr() == model.model.embed_tokens.weight.data_ptr():
                     continue  # tied head: the embedding row is the weight
                 _route(model, target, f.get_tensor(name))
+    pack_model_weights(model)
 
 
 def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfloat16):
@@ -100,6 +108,7 @@ def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfl
 def init_synthetic_weights(model: nn.Module, hf_config, seed: int = 0, std: float = 0.02) -> None:
     for name, tensor in synthetic_state(hf_config, seed, std):
         _route(model, name, tensor)
+    pack_model_weights(model)
 
 
 def load_state_dict_packed(model: nn.Module, weights: dict) -> None:
@@ -118,3 +127,4 @@ def load_state_dict_packed(model: nn.Module, weights: dict) -> None:
             _route(model, name.replace("gate_up_proj", "up_proj"), up)
         else:
             _route(model, name, t)
+    pack_model_weights(model)

@@ -218,6 +218,43 @@ def test_gemm_skinny(ops, M, N, K):
         assert float(ye.float().abs().sum() - ye[3].float().abs().sum()) == 0.0
 
 
+def _pack_ref(w):
+    """host model of mi_pack_weight: [N/16][K/32][4 (g)][16 (r)][8]"""
+    N, K = w.shape
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
+@pytest.mark.parametrize("M", [1, 16, 32, 48, 64])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (256, 128), (32, 160)])
+def test_gemm_packed(ops, M, N, K):
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    wp = ops.pack_weight(w.to(DEV))
+    assert torch.equal(wp.cpu().view(torch.int16), _pack_ref(w).view(torch.int16))  # pure permutation
+    atol = K * 2.0 ** -22
+    assert_bf16_close(ops.gemm_packed(x.to(DEV), wp), oracle.linear(x, w), max_frac=2e-2, atol=atol)
+    assert_bf16_close(ops.gemm_packed(x.to(DEV), wp, b.to(DEV)), oracle.linear(x, w, b), max_frac=2e-2, atol=atol)
+    # fused SiluAndMul epilogue == gate_up GEMM followed by the activation kernel
+    want = oracle.silu_and_mul(oracle.linear(x, w))
+    got = ops.gemm_packed(x.to(DEV), wp, silu_mul=True)
+    # a 1-ulp flip of the gate (GEMM summation order) times |up| <= ~6: widen the near-zero atol
+    assert_bf16_close(got, want, max_ulp=2, max_frac=3e-2, atol=32 * atol)
+    # split-K partials + add_rmsnorm_splitk == GEMM + add_rmsnorm
+    r = torch.randn(M, N, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).bfloat16()
+    yo, ro = oracle.add_rms_norm(oracle.linear(x, w), r, nw, 1e-6)
+    for ks in (1, 2, 4):
+        if K % (32 * ks):
+            continue
+        parts = ops.gemm_packed_splitk(x.to(DEV), wp, ks)
+        y, r2 = ops.add_rmsnorm_splitk(parts, r.to(DEV), nw.to(DEV), 1e-6)
+        # x + residual may cancel: one bf16 ulp of |x| <= 4 (3.1e-2) is the absolute noise floor
+        assert_bf16_close(r2, ro, max_frac=2e-2, atol=4e-2)
+        assert_bf16_close(y, yo, max_ulp=2, max_frac=3e-2, atol=4e-2)
+
+
 def test_gemm_lm_head_shape(ops):
     g = torch.Generator().manual_seed(1)
     M, N, K = 32, 151936, 1024
@@ -225,6 +262,8 @@ def test_gemm_lm_head_shape(ops):
     w = (torch.randn(N, K, generator=g) * 0.02).bfloat16()
     y = ops.gemm_skinny(x.to(DEV), w.to(DEV)).cpu()
     ref = oracle.linear(x, w)
+    assert_bf16_close(y, ref, max_ulp=1, max_frac=2e-2, atol=1024 * 2.0 ** -22)
+    y = ops.gemm_packed(x.to(DEV), ops.pack_weight(w.to(DEV))).cpu()  # two row tiles per workgroup
     assert_bf16_close(y, ref, max_ulp=1, max_frac=2e-2, atol=1024 * 2.0 ** -22)
 
 

@@ -62,6 +62,18 @@ def main():
     t = timeit(lambda l: ops.paged_attn_decode(q, kc[l], vc[l], perm, ctxl, hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
     byt = B * 2 * ctx * hkv * 128 * 2
     res["paged_attn_decode(+merge)"] = {"us": t * 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
+    for c2 in (1040, 1100, 1170):  # ragged / growing contexts as in the timed bench window
+        ctx2 = torch.full((B,), c2, dtype=torch.int32, device=DEV)
+        nb2 = (c2 + bs - 1) // bs
+        perm2 = torch.randint(0, nblk, (B, nb2), generator=g).to(torch.int32).to(DEV)
+        t = timeit(lambda l: ops.paged_attn_decode(q, kc[l], vc[l], perm2, ctx2, hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
+        byt2 = B * 2 * c2 * hkv * 128 * 2
+        res[f"paged_attn_decode ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
+
+    if os.environ.get("KBENCH_ONLY") == "attn":
+        for k, v in res.items():
+            print(f"{k:32s} " + "  ".join(f"{a}={b:9.2f}" for a, b in v.items()))
+        return
 
     def gemm(name, N, K, M=32):
         ws_ = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(L if N < 100000 else 3)]
@@ -74,6 +86,29 @@ def main():
         # torch (hipBLASLt) comparison column
         t2 = timeit(lambda l: torch.nn.functional.linear(x, ws_[l]), n)
         res[name]["torch_us"] = t2 * 1e6
+        wp_ = [ops.pack_weight(w_) for w_ in ws_]
+        t3 = timeit(lambda l: ops.gemm_packed(x, wp_[l], out=y), n)
+        res[name]["packed_us"] = t3 * 1e6
+        if N <= 2048:  # row-parallel projections: split-K over workgroups + fused consumer
+            r = torch.randn(M, N, device=DEV).bfloat16()
+            nw = torch.ones(N, device=DEV).bfloat16()
+            for ks in (2, 4, 8):
+                if K % (32 * ks * 4):
+                    continue
+                parts = torch.empty(ks, M, N, dtype=torch.float32, device=DEV)
+                t4 = timeit(lambda l: ops.gemm_packed_splitk(x, wp_[l], ks, out=parts), n)
+                res[name][f"splitk{ks}_us"] = t4 * 1e6
+            t5 = timeit(lambda l: (ops.gemm_packed_splitk(x, wp_[l], 4, out=parts[:4] if parts.shape[0] >= 4 else parts),
+                                   ops.add_rmsnorm_splitk(parts[:4], r, nw, 1e-6, out=r, residual_out=r)), n)
+            res[name]["splitk4+addnorm_us"] = t5 * 1e6
+            t6 = timeit(lambda l: (ops.gemm_packed(x, wp_[l], out=y), ops.add_rmsnorm(y, r, nw, 1e-6, out=y, residual_out=r)), n)
+            res[name]["packed+addnorm_us"] = t6 * 1e6
+        if N == 6144:
+            so_ = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
+            t7 = timeit(lambda l: ops.gemm_packed(x, wp_[l], out=so_, silu_mul=True), n)
+            res[name]["packed_silu_fused_us"] = t7 * 1e6
+            t8 = timeit(lambda l: (ops.gemm_packed(x, wp_[l], out=y), ops.silu_mul(y, out=so_)), n)
+            res[name]["packed+silu_us"] = t8 * 1e6
 
     gemm("qkv 4096x1024", 4096, 1024)
     gemm("o 1024x2048", 1024, 2048)

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (kernel trace): per-kernel count / avg / min / max / total."""
+import sqlite3
+import sys
+
+
+def main(path, top=30):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    q = f"""select s.kernel_name, count(*), avg(d.end-d.start)/1000.0, min(d.end-d.start)/1000.0,
+            max(d.end-d.start)/1000.0, sum(d.end-d.start)/1000.0
+            from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name order by 6 desc limit {top}"""
+    rows = list(cur.execute(q))
+    total = sum(r[5] for r in cur.execute(f"select 0,0,0,0,0,sum(end-start)/1000.0 from {kd}"))
+    print(f"{'kernel':100s} {'calls':>7s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'total_us':>11s} {'%':>6s}")
+    for r in rows:
+        print(f"{r[0][:100]:100s} {r[1]:7d} {r[2]:9.2f} {r[3]:9.2f} {r[4]:9.2f} {r[5]:11.1f} {100 * r[5] / total:6.2f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 30)
