@@ -221,6 +221,21 @@ def main():
                           "unit": "GB/s", "frac": algo / elapsed / (HBM_PEAK * world),
                           "bytes_per_step": algo / args.steps},
     }
+    # device time of the captured decode step alone (graph replays back to back, HIP events):
+    # ms_per_step minus this is the host share of a step (scheduler, metadata, sampling, sync)
+    mr = llm.model_runner
+    bucket = mr._bucket_for(BATCH) if mr.graphs else None
+    if bucket is not None:
+        g = mr.graphs[bucket]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        result["step_roofline"]["graph_replay_ms"] = e0.elapsed_time(e1) / 20
     result["roofline"] = attention_roofline(llm, seqs) if world == 1 else None
     llm.exit()
     if world == 1 and not args.no_cpu_baseline:

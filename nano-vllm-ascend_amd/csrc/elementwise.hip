@@ -10,7 +10,7 @@ namespace mi {
 // RMSNorm / add+RMSNorm   (reference: layers/layernorm.py:16-38)
 //   LPR lanes cooperate on one row, each holding VPL vectors of 8 bf16.
 // ---------------------------------------------------------------------------
-template <int LPR, int VPL, bool ADD, bool PART>
+template <int LPR, int VPL, bool ADD, int PART>  // PART = number of split-K partials (0: x is bf16)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ part, int nsplit, int64_t x_outer_stride, int inner,
     const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
@@ -34,13 +34,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
     const int vec = sub + i * LPR;
     if (active && vec < nvec) {
       u32x4 raw;
-      if (PART) {
-        // x is the bf16 rounding of the split-K GEMM result: sum the fp32 partials in split order
-        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < nsplit; ++sp) {
+      if (PART > 0) {
+        // x is the bf16 rounding of the split-K GEMM result: all partial loads are issued first,
+        // then summed in split order
+        f32x4 plo[PART > 0 ? PART : 1], phi[PART > 0 ? PART : 1];
+#pragma unroll
+        for (int sp = 0; sp < PART; ++sp) {
           const float* pp = part + ((int64_t)sp * rows + row) * cols + vec * 8;
-          lo += *reinterpret_cast<const f32x4*>(pp);
-          hi += *reinterpret_cast<const f32x4*>(pp + 4);
+          plo[sp] = *reinterpret_cast<const f32x4*>(pp);
+          phi[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+        f32x4 lo = plo[0], hi = phi[0];
+#pragma unroll
+        for (int sp = 1; sp < PART; ++sp) {
+          lo += plo[sp];
+          hi += phi[sp];
         }
         raw = u32x4{pack_bf(lo[0], lo[1]), pack_bf(lo[2], lo[3]), pack_bf(hi[0], hi[1]), pack_bf(hi[2], hi[3])};
       } else {
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
   }
 }
 
-template <bool ADD, bool PART = false>
+template <bool ADD, int PART = 0>
 static int launch_rmsnorm(const uint16_t* x, const float* part, int nsplit, int64_t xs, int inner, const uint16_t* r,
                           const uint16_t* w, uint16_t* y, uint16_t* ro, int rows, int cols,
                           float eps, hipStream_t st) {
@@ -364,6 +372,56 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
   return (uint32_t)(z >> 32);
 }
 
+__device__ __forceinline__ float gumbel_key(float logit, float inv_t, uint64_t rkey, int col) {
+  // u in (0,1): 24 random bits, never 0 or 1
+  const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return logit * inv_t - logf(-logf(u));
+}
+
+// scan one row: 4 independent 16-byte loads per thread and iteration are issued before any compare
+template <bool NOISY>
+__device__ __forceinline__ void scan_row(const uint16_t* __restrict__ p, int vocab, float inv_t, uint64_t rkey,
+                                         float& best, int& best_i) {
+  const int nvec = vocab >> 3;
+  const int T = blockDim.x;
+  auto consider = [&](const u32x4& raw, int v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = v * 8 + 2 * j;
+      float k0 = lo_bf(raw[j]), k1 = hi_bf(raw[j]);
+      if (NOISY) {
+        k0 = gumbel_key(k0, inv_t, rkey, col);
+        k1 = gumbel_key(k1, inv_t, rkey, col + 1);
+      }
+      if (k0 > best || (k0 == best && col < best_i)) {
+        best = k0;
+        best_i = col;
+      }
+      if (k1 > best || (k1 == best && col + 1 < best_i)) {
+        best = k1;
+        best_i = col + 1;
+      }
+    }
+  };
+  int v = threadIdx.x;
+  for (; v + 3 * T < nvec; v += 4 * T) {
+    u32x4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + (v + u * T) * 8));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) consider(r[u], v + u * T);
+  }
+  for (; v < nvec; v += T) consider(*reinterpret_cast<const u32x4*>(p + v * 8), v);
+  for (int col = (nvec << 3) + threadIdx.x; col < vocab; col += T) {  // tail (< 8 columns)
+    float key = bf2f(p[col]);
+    if (NOISY) key = gumbel_key(key, inv_t, rkey, col);
+    if (key > best || (key == best && col < best_i)) {
+      best = key;
+      best_i = col;
+    }
+  }
+}
+
 template <bool SAMPLE>
 __global__ __launch_bounds__(1024) void pick_kernel(const uint16_t* __restrict__ logits,
                                                     int64_t row_stride,
@@ -382,36 +440,8 @@ __global__ __launch_bounds__(1024) void pick_kernel(const uint16_t* __restrict__
   const uint64_t rkey = seed * 0x9e3779b97f4a7c15ull + step * 0xd1342543de82ef95ull + (uint64_t)row * 0x2545f4914f6cdd1dull;
   float best = -INFINITY;
   int best_i = 0x7fffffff;
-  const int nvec = vocab >> 3;
-  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
-    float f[8];
-    load16(p + v * 8, f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float key = f[i];
-      const int col = v * 8 + i;
-      if (SAMPLE && noisy) {
-        // u in (0,1): 24 random bits, never 0 or 1
-        const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        key = key * inv_t - logf(-logf(u));
-      }
-      if (key > best || (key == best && col < best_i)) {
-        best = key;
-        best_i = col;
-      }
-    }
-  }
-  for (int col = (nvec << 3) + threadIdx.x; col < vocab; col += blockDim.x) {  // tail
-    float key = bf2f(p[col]);
-    if (SAMPLE && noisy) {
-      const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      key = key * inv_t - logf(-logf(u));
-    }
-    if (key > best || (key == best && col < best_i)) {
-      best = key;
-      best_i = col;
-    }
-  }
+  if (SAMPLE && noisy) scan_row<true>(p, vocab, inv_t, rkey, best, best_i);
+  else scan_row<false>(p, vocab, inv_t, rkey, best, best_i);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_xor(best, o, 64);
@@ -476,8 +506,20 @@ extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi
   if (!aligned16(partials) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
     return MI_EINVAL;
   if (rows == 0) return MI_OK;
-  return launch_rmsnorm<true, true>(nullptr, partials, nsplit, (int64_t)cols, 1, residual, w, y, residual_out, rows,
-                                    cols, eps, S(stream));
+#define SPLITK_CASE(NS)                                                                                       \
+  case NS:                                                                                                    \
+    return launch_rmsnorm<true, NS>(nullptr, partials, nsplit, (int64_t)cols, 1, residual, w, y, residual_out, rows, \
+                                    cols, eps, S(stream))
+  switch (nsplit) {
+    SPLITK_CASE(1);
+    SPLITK_CASE(2);
+    SPLITK_CASE(3);
+    SPLITK_CASE(4);
+    SPLITK_CASE(6);
+    SPLITK_CASE(8);
+    default: return MI_EUNSUPPORTED;
+  }
+#undef SPLITK_CASE
 }
 
 static int heads_grid(int64_t head_slots) { return (int)((head_slots * 8 + 255) / 256); }
