@@ -68,9 +68,13 @@ class ModelRunner:
         self.device = torch.device("cuda", local)
         torch.cuda.set_device(self.device)
         if self.world_size > 1 and not dist.is_initialized():
-            # backend "nccl" is RCCL on ROCm; rendezvous on the loopback interface
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{config.hccl_port}",
-                                    world_size=self.world_size, rank=rank, device_id=self.device)
+            # backend "nccl" is RCCL on ROCm; rendezvous on the loopback interface.
+            # MI355_DIST_BACKEND=gloo lets several ranks share one GPU (functional TP tests on a
+            # 1-GPU box; not capturable into graphs).
+            backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
+            kw = {"device_id": self.device} if backend == "nccl" else {}
+            dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{config.hccl_port}",
+                                    world_size=self.world_size, rank=rank, **kw)
         self.channel = StepChannel(config.hccl_port, self.world_size, rank) if self.world_size > 1 else None
 
         dtype = _torch_dtype_of(self.hf_config)
@@ -98,8 +102,16 @@ class ModelRunner:
         self._alloc_staging()
         self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
         self.graph_logits: dict[int, torch.Tensor] = {}
-        if config.use_graphs:
-            self.capture_decode_graphs()
+        if config.use_graphs and not (self.world_size > 1 and dist.get_backend() != "nccl"):
+            try:
+                self.capture_decode_graphs()
+            except Exception as e:  # e.g. a collective that refuses stream capture: run eagerly instead
+                import warnings
+
+                warnings.warn(f"hipGraph capture failed ({e!r}); decoding eagerly")
+                self.graphs.clear()
+                self.graph_logits.clear()
+                reset_context()
         if self.world_size > 1:
             dist.barrier()
 

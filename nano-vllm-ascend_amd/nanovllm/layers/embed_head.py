@@ -50,7 +50,13 @@ class ParallelLMHead(VocabParallelEmbedding):
             x = ops.gather_last_tokens(x, context.cu_seqlens_q)
         logits = linear_forward(x, self.weight, None, self.weight_packed)
         if self.tp_size > 1:  # vocab shards -> rank 0 (embed_head.py:62-65)
-            parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
-            dist.gather(logits, parts, 0)
-            logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
+            if dist.get_backend() == "nccl":
+                parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+                dist.gather(logits, parts, 0)
+                logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
+            else:  # gloo has no device-side gather: place the shard in a zero buffer and sum (tests only)
+                full = torch.zeros((logits.shape[0], self.num_embeddings), dtype=logits.dtype, device=logits.device)
+                full[:, self.vocab_start_idx:self.vocab_end_idx] = logits
+                dist.all_reduce(full)
+                logits = full if self.tp_rank == 0 else None
         return logits

@@ -1,0 +1,189 @@
+"""Tensor-parallel host logic on CPU: world_size-2 `gloo` process groups.
+Covers the N > 1 path without GPUs: sharded weight loaders, vocab-parallel masks, the
+row-parallel all-reduce identity (against the CPU oracle), and the rank-RPC channel."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, fn_name: str, out_q):
+    for p in (REPO, os.path.join(REPO, "nano-vllm-ascend_amd"), os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    try:
+        globals()[fn_name](rank, world, port)
+        out_q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        out_q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name: str, world: int = 2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+# ----------------------------------------------------------------------------- bodies (run in the ranks)
+def _body_sharded_layers(rank, world, port):
+    import oracle
+    from nanovllm.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
+    from nanovllm.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+
+    g = torch.Generator().manual_seed(0)  # same full tensors on every rank
+    H, hq, hkv, d, inter, vocab = 256, 4, 2, 128, 512, 1024
+    torch.set_default_dtype(torch.bfloat16)
+    qkv = QKVParallelLinear(H, d, hq, hkv)
+    o = RowParallelLinear(hq * d, H)
+    gu = MergedColumnParallelLinear(H, [inter, inter])
+    down = RowParallelLinear(inter, H)
+    emb = VocabParallelEmbedding(vocab, H)
+    head = ParallelLMHead(vocab, H)
+    torch.set_default_dtype(torch.float32)
+
+    def full(*shape):
+        return (torch.randn(*shape, generator=g) * 0.05).bfloat16()
+
+    wq, wk, wv = full(hq * d, H), full(hkv * d, H), full(hkv * d, H)
+    wo, wg, wu, wd, we = full(H, hq * d), full(inter, H), full(inter, H), full(H, inter), full(vocab, H)
+    for shard, w in (("q", wq), ("k", wk), ("v", wv)):
+        qkv.weight.weight_loader(qkv.weight, w, shard)
+    o.weight.weight_loader(o.weight, wo)
+    gu.weight.weight_loader(gu.weight, wg, 0)
+    gu.weight.weight_loader(gu.weight, wu, 1)
+    down.weight.weight_loader(down.weight, wd)
+    emb.weight.weight_loader(emb.weight, we)
+    head.weight.weight_loader(head.weight, we)
+
+    # shards are the Megatron slices of linear.py:54-153 / embed_head.py:27-32
+    hq_l, hkv_l = hq // world, hkv // world
+    assert torch.equal(qkv.weight.data[: hq_l * d], wq[rank * hq_l * d:(rank + 1) * hq_l * d])
+    assert torch.equal(qkv.weight.data[hq_l * d: (hq_l + hkv_l) * d], wk[rank * hkv_l * d:(rank + 1) * hkv_l * d])
+    assert torch.equal(qkv.weight.data[(hq_l + hkv_l) * d:], wv[rank * hkv_l * d:(rank + 1) * hkv_l * d])
+    assert torch.equal(o.weight.data, wo[:, rank * hq_l * d:(rank + 1) * hq_l * d])
+    il = inter // world
+    assert torch.equal(gu.weight.data[:il], wg[rank * il:(rank + 1) * il])
+    assert torch.equal(gu.weight.data[il:], wu[rank * il:(rank + 1) * il])
+    assert torch.equal(down.weight.data, wd[:, rank * il:(rank + 1) * il])
+    vl = vocab // world
+    assert torch.equal(emb.weight.data, we[rank * vl:(rank + 1) * vl])
+    assert (emb.vocab_start_idx, emb.vocab_end_idx) == (rank * vl, (rank + 1) * vl)
+
+    # column -> row parallel MLP: per-rank partial products summed over ranks == unsharded oracle
+    x = full(5, H)
+    part = oracle.linear(oracle.silu_and_mul(oracle.linear(x, gu.weight.data)), down.weight.data, keep_fp32=True)
+    dist.all_reduce(part)
+    want = oracle.linear(oracle.silu_and_mul(oracle.linear(x, torch.cat([wg, wu]))), wd, keep_fp32=True)
+    assert (part - want).abs().max().item() < 2e-2  # bf16 intermediates, different split of the K sum
+
+    # vocab-parallel embedding: masked partial rows sum to the full embedding (embed_head.py:34-42)
+    ids = torch.tensor([0, 1, vl - 1, vl, vocab - 1, 17, vl + 5])
+    y = oracle.embedding(ids, emb.weight.data, emb.vocab_start_idx).float()
+    dist.all_reduce(y)
+    assert torch.equal(y, we[ids].float())
+
+    # vocab-parallel head: gather of shards to rank 0 == full logits (embed_head.py:56-66)
+    h = full(3, H)
+    local = oracle.linear(h, head.weight.data)
+    parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, parts, 0)
+    if rank == 0:
+        assert torch.equal(torch.cat(parts, -1), oracle.linear(h, we))
+
+
+def _body_rpc_channel(rank, world, port):
+    from nanovllm.engine.rpc import StepChannel
+    from nanovllm.engine.sequence import Sequence
+    from nanovllm.sampling_params import SamplingParams
+
+    ch = StepChannel(port + 1, world, rank)
+    if rank == 0:
+        seqs = []
+        for i, n in enumerate((40, 7)):
+            s = Sequence(list(range(100 * i, 100 * i + n)), SamplingParams(temperature=0.5 + i, max_tokens=9),
+                         block_size=16)
+            s.block_table = list(range(3 * i, 3 * i + s.num_blocks))
+            seqs.append(s)
+        ch.send("run", seqs, True)
+        dist.barrier()
+        for s in seqs:
+            s.append_token(5)
+        ch.send("run", seqs, False)
+        dist.barrier()
+        ch.send("exit")
+        dist.barrier()
+    else:
+        method, seqs, is_prefill = ch.recv()
+        assert method == "run" and is_prefill and [len(s) for s in seqs] == [40, 7]
+        assert seqs[0].token_ids == list(range(40)) and seqs[1].block_table == [3]
+        assert seqs[1].temperature == 1.5 and seqs[0].num_blocks == 3 and seqs[0].last_block_num_tokens == 8
+        dist.barrier()
+        method, seqs, is_prefill = ch.recv()
+        assert method == "run" and not is_prefill and [len(s) for s in seqs] == [41, 8]
+        assert [s.last_token for s in seqs] == [5, 5]  # decode steps ship only the last token
+        dist.barrier()
+        method, seqs, _ = ch.recv()
+        assert method == "exit" and seqs == []
+        dist.barrier()
+    ch.close()
+
+
+def _body_replicated_scheduling(rank, world, port):
+    """Every rank can rebuild identical step metadata from the wire format (the reference's
+    multi-rank story: deterministic replicated bookkeeping, ut/test_multi_rank_block_manager.py)."""
+    import numpy as np
+
+    from nanovllm.engine import batch_meta
+    from nanovllm.engine.sequence import Sequence
+    from nanovllm.sampling_params import SamplingParams
+
+    s = Sequence(list(range(50)), SamplingParams(max_tokens=4), block_size=16)
+    s.block_table = [9, 4, 7, 2]
+    buf = np.array(s.to_wire(False), dtype=np.int64)
+    r, _ = Sequence.from_wire(buf, 0)
+    m = batch_meta.decode_meta([r])
+    mine = torch.tensor([int(m.input_ids[0]), int(m.positions[0]), int(m.context_lens[0]), *m.slot_mapping[0].tolist(),
+                         *m.block_tables[0].tolist()])
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    assert mine.tolist() == [49, 49, 50, 2, 1, 9, 4, 7, 2]
+
+
+# ----------------------------------------------------------------------------- tests
+def test_tp2_sharded_layers_match_oracle():
+    _run("_body_sharded_layers")
+
+
+def test_tp2_rpc_channel():
+    _run("_body_rpc_channel")
+
+
+def test_tp2_replicated_metadata():
+    _run("_body_replicated_scheduling")
