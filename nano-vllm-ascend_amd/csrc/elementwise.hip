@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void qk_rope_store_kernel(
     const int64_t* __restrict__ positions, const float* __restrict__ cos_sin,
     uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_out, uint16_t* __restrict__ k_cache,
     uint16_t* __restrict__ v_cache, const int32_t* __restrict__ slots, int slot_is_2d, int n_tokens,
-    int n_q_heads, int n_kv_heads, int block_size) {
+    int n_q_heads, int n_kv_heads, int block_size, int skip_v) {
   const int heads_per_token = MODE == 0 ? n_q_heads + 2 * n_kv_heads
                               : MODE == 1 ? n_q_heads + n_kv_heads
                                           : 2 * n_kv_heads;
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void qk_rope_store_kernel(
                         : kind == 1 ? ksrc + token * k_stride
                                     : vsrc + token * v_stride;
   src += hh * 128;
+  if (kind == 2 && skip_v) return;  // V goes through v_store_tiles_kernel (whole 8-lane group exits)
   float a[8], b[8];
   if (active) {
     load16(src + 8 * j, a);
@@ -288,6 +289,55 @@ __global__ __launch_bounds__(256) void qk_rope_store_kernel(
   const int tpb = block_size >> 4;
   if (kind == 1) store_k_head(k_cache, blk, off, hh, j, a, b, n_kv_heads, tpb);
   else store_v_head(v_cache, blk, off, hh, j, a, b, n_kv_heads, tpb);
+}
+
+// V scatter for many tokens (prefill): one workgroup per (16 consecutive tokens, kv head).  When the
+// 16 tokens fill one aligned cache tile (the common case: a sequence's tokens occupy consecutive
+// slots from a block boundary) the tile is transposed through LDS and written as one coalesced
+// 4 KiB run; otherwise it falls back to element scatter.  Pure copy either way.
+__global__ __launch_bounds__(128) void v_store_tiles_kernel(const uint16_t* __restrict__ vsrc, int64_t v_stride,
+                                                            uint16_t* __restrict__ v_cache,
+                                                            const int32_t* __restrict__ slots, int n_tokens,
+                                                            int n_kv_heads, int block_size) {
+  __shared__ uint16_t sm[16][128 + 8];
+  __shared__ int sm_slot[16];
+  const int t0 = blockIdx.x * 16, h = blockIdx.y, tid = threadIdx.x;
+  const int n_here = min(16, n_tokens - t0);
+  if (tid < 16) sm_slot[tid] = tid < n_here ? slots[t0 + tid] : -2;
+  // coalesced read of 16 rows x 256 B
+  for (int c = tid; c < 256; c += 128) {
+    const int tk = c >> 4, ch = c & 15;
+    u32x4 v = {0, 0, 0, 0};
+    if (tk < n_here) v = *reinterpret_cast<const u32x4*>(vsrc + (int64_t)(t0 + tk) * v_stride + h * 128 + ch * 8);
+    *reinterpret_cast<u32x4*>(&sm[tk][ch * 8]) = v;
+  }
+  __syncthreads();
+  const int s0 = sm_slot[0];
+  bool tile_ok = s0 >= 0 && (s0 & 15) == 0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) tile_ok = tile_ok && sm_slot[i] == s0 + i;
+  const int tpb = block_size >> 4;
+  if (tile_ok) {
+    uint16_t* tile = v_cache + kv_tile_base(s0 / block_size, h, s0 % block_size, n_kv_heads, tpb);
+    for (int oc = tid; oc < 256; oc += 128) {  // output chunk (jp, g4, n): 4 tokens x {d, d+16}
+      const int jp = oc >> 6, g4 = (oc >> 4) & 3, nn = oc & 15;
+      const int d0 = jp * 32 + nn;
+      u32x4 o;
+      o[0] = (uint32_t)sm[4 * g4 + 0][d0] | ((uint32_t)sm[4 * g4 + 1][d0] << 16);
+      o[1] = (uint32_t)sm[4 * g4 + 2][d0] | ((uint32_t)sm[4 * g4 + 3][d0] << 16);
+      o[2] = (uint32_t)sm[4 * g4 + 0][d0 + 16] | ((uint32_t)sm[4 * g4 + 1][d0 + 16] << 16);
+      o[3] = (uint32_t)sm[4 * g4 + 2][d0 + 16] | ((uint32_t)sm[4 * g4 + 3][d0 + 16] << 16);
+      *reinterpret_cast<u32x4*>(tile + oc * 8) = o;
+    }
+  } else {
+    for (int e = tid; e < 16 * 128; e += 128) {
+      const int tk = e >> 7, d = e & 127;
+      const int sl = sm_slot[tk];
+      if (sl < 0) continue;
+      uint16_t* tile = v_cache + kv_tile_base(sl / block_size, h, sl % block_size, n_kv_heads, tpb);
+      tile[v_tile_off(sl & 15, d)] = sm[tk][d];
+    }
+  }
 }
 
 // inverse of the scatter, for content checks: out[i][h*128+d] = cache[slot_flat[i]][h][d]
@@ -537,7 +587,7 @@ extern "C" int mi_rope(const int64_t* positions, const float* cos_sin, const mi_
   hipLaunchKernelGGL((qk_rope_store_kernel<1>), dim3(heads_grid(slots)), dim3(256), 0, S(stream), q,
                      q_row_stride, k, k_row_stride, nullptr, (int64_t)0, nullptr, nullptr, 0.f, positions,
                      cos_sin, q_out, k_out, nullptr, nullptr, nullptr, 0, n_tokens, n_q_heads, n_kv_heads,
-                     16);
+                     16, 0);
   return check_launch();
 }
 
@@ -550,9 +600,14 @@ static int store_common(const mi_bf16* k, const mi_bf16* v, int64_t ks, int64_t 
   if (!aligned16(k) || !aligned16(v) || !aligned16(kc) || !aligned16(vc)) return MI_EINVAL;
   if (n == 0) return MI_OK;
   const int64_t hs = (int64_t)n * 2 * n_kv_heads;
+  const int tiled_v = (!is2d && n >= 64) ? 1 : 0;
   hipLaunchKernelGGL((qk_rope_store_kernel<2>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), nullptr,
                      (int64_t)0, k, ks, v, vs, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, kc,
-                     vc, slots, is2d, n, 0, n_kv_heads, block_size);
+                     vc, slots, is2d, n, 0, n_kv_heads, block_size, tiled_v);
+  int rc = check_launch();
+  if (rc != MI_OK || !tiled_v) return rc;
+  hipLaunchKernelGGL(v_store_tiles_kernel, dim3((n + 15) / 16, n_kv_heads), dim3(128), 0, S(stream), v, vs, vc,
+                     slots, n, n_kv_heads, block_size);
   return check_launch();
 }
 
@@ -601,10 +656,16 @@ extern "C" int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride, 
   const int64_t hs = (int64_t)n_tokens * (n_q_heads + 2 * n_kv_heads);
   const mi_bf16* ksrc = qkv + (int64_t)n_q_heads * 128;
   const mi_bf16* vsrc = ksrc + (int64_t)n_kv_heads * 128;
+  // many tokens with flat slots (prefill): V is transposed tile-wise by its own kernel
+  const int tiled_v = (!slot_is_2d && n_tokens >= 64) ? 1 : 0;
   hipLaunchKernelGGL((qk_rope_store_kernel<0>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), qkv,
                      qkv_row_stride, ksrc, qkv_row_stride, vsrc, qkv_row_stride, q_w, k_w, eps, positions,
                      cos_sin, q_out, nullptr, k_cache, v_cache, slots, slot_is_2d, n_tokens, n_q_heads,
-                     n_kv_heads, block_size);
+                     n_kv_heads, block_size, tiled_v);
+  int rc = check_launch();
+  if (rc != MI_OK || !tiled_v) return rc;
+  hipLaunchKernelGGL(v_store_tiles_kernel, dim3((n_tokens + 15) / 16, n_kv_heads), dim3(128), 0, S(stream), vsrc,
+                     qkv_row_stride, v_cache, slots, n_tokens, n_kv_heads, block_size);
   return check_launch();
 }
 

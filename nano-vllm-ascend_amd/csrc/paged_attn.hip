@@ -284,15 +284,27 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------
-// prefill: grid (ceil(max_q_blocks / 4), n_kv_heads, n_seqs), 4 independent waves
+// prefill: grid (ceil(max_q / (8 * 16/G)), n_kv_heads, n_seqs), 8 waves
+//
+// A workgroup owns 8 consecutive query blocks of one (sequence, kv head) - 128 MFMA columns, i.e.
+// 128/G query tokens x G heads - and walks the sequence's KV chunks once: every 32-token chunk
+// (K0|K1|V0|V1 = 16 KiB, already in MFMA-fragment order in the paged cache) is fetched from
+// HBM/L2 ONCE per workgroup by all 512 threads (two coalesced 16-byte loads each) into a
+// double-buffered LDS image and read back by each wave as lane-linear ds_read_b128 fragments
+// (conflict-free).  Compared with one wave fetching its own chunk copies this cuts L2 traffic 8x and
+// makes the loop MFMA-bound.  Chunk c+1 is in flight in registers while chunk c is computed; one
+// barrier per chunk.  Waves whose query block lies beyond the chunk (causal) skip the math only.
 // ---------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
+__global__ __launch_bounds__(512) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ kv_lens, uint16_t* __restrict__ out,
     int n_q_heads, int n_kv_heads, int tpb, float scale_log2e) {
-  constexpr int TQ = 16 / G;
+  constexpr int TQ = 16 / G;        // query tokens per wave
+  constexpr int TQ_WG = 8 * TQ;     // per workgroup
+  __shared__ __attribute__((aligned(16))) uint16_t stage[2][4][2048];  // [buffer][K0,K1,V0,V1][tile]
+
   const int seq = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, n = lane & 15;
@@ -300,23 +312,26 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const int q_len = cu_q[seq + 1] - q_start;
   const int kv_len = kv_lens[seq];
   // heaviest (latest) query blocks are dispatched first
-  const int qblk = ((int)gridDim.x - 1 - (int)blockIdx.x) * 4 + wave;
-  const int qt0 = qblk * TQ;
-  if (qt0 >= q_len) return;
-  const int my_qt = qt0 + n / G, hn = n % G;
-  const bool valid = my_qt < q_len;
+  const int wg_qt0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * TQ_WG;
+  if (wg_qt0 >= q_len) return;  // uniform for the workgroup
   const int shift = kv_len - q_len;
+  const int wg_last_pos = shift + min(wg_qt0 + TQ_WG, q_len) - 1;
+  const int wg_chunks = (wg_last_pos + 32) >> 5, wg_tiles = (wg_last_pos + 16) >> 4;
+
+  const int qt0 = wg_qt0 + wave * TQ;
+  const bool wave_on = qt0 < q_len;
+  const int my_qt = qt0 + n / G, hn = n % G;
+  const bool valid = wave_on && my_qt < q_len;
   const int limit = valid ? shift + my_qt + 1 : 1;
-  const int last_pos = shift + min(qt0 + TQ, q_len) - 1;
-  const int n_chunks = (last_pos + 32) >> 5;
-  const int n_tiles = (last_pos + 16) >> 4;
+  const int wave_chunks = wave_on ? (shift + min(qt0 + TQ, q_len) - 1 + 32) >> 5 : 0;
 
   bf16x8 Q[4];
   {
-    const uint16_t* qp = q + (int64_t)(q_start + (valid ? my_qt : qt0)) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * g;
+    const int row = valid ? my_qt : wg_qt0;  // invalid columns read a valid row and are zeroed
+    const uint16_t* qp = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * g;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);  // invalid columns read row qt0 (valid)
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);
       if (!valid) v = u32x4{0, 0, 0, 0};
       Q[kk] = as_frag(v);
     }
@@ -326,11 +341,46 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // cooperative fetch: thread t moves bytes [16 t', 16 t'+16) and +2 KiB of piece t / 128
   const int32_t* table_row = block_table + (int64_t)seq * table_stride;
-  for (int c = 0; c < n_chunks; ++c) {
-    u32x4 K0[4], K1[4], V0[4], V1[4];
-    load_chunk(kc, vc, table_row, c, n_tiles, h, default_strides(n_kv_heads, tpb), tpb, lane, K0, K1, V0, V1);
-    attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, scale_log2e, g, m, l, acc);
+  const KvStrides st = default_strides(n_kv_heads, tpb);
+  const int piece = threadIdx.x >> 7;            // 0 K0, 1 K1, 2 V0, 3 V1
+  const int within = (threadIdx.x & 127) * 8;    // element offset of this thread's first 16 bytes
+  auto fetch = [&](int c, u32x4& r0, u32x4& r1) {
+    const int tile0 = 2 * c;
+    const int tile = (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
+    const int blk = table_row[tile / tpb];
+    const uint16_t* src = ((piece & 2) ? vc : kc) + (int64_t)blk * st.block + (int64_t)h * st.head +
+                          (int64_t)(tile % tpb) * st.tile + within;
+    r0 = *reinterpret_cast<const u32x4*>(src);
+    r1 = *reinterpret_cast<const u32x4*>(src + 1024);
+  };
+  auto stash = [&](int buf, const u32x4& r0, const u32x4& r1) {
+    *reinterpret_cast<u32x4*>(&stage[buf][piece][within]) = r0;
+    *reinterpret_cast<u32x4*>(&stage[buf][piece][within + 1024]) = r1;
+  };
+
+  u32x4 r0, r1;
+  fetch(0, r0, r1);
+  stash(0, r0, r1);
+  __syncthreads();
+  for (int c = 0; c < wg_chunks; ++c) {
+    const bool more = c + 1 < wg_chunks;
+    if (more) fetch(c + 1, r0, r1);  // in flight during this chunk's math
+    if (c < wave_chunks) {
+      const int buf = c & 1;
+      u32x4 K0[4], K1[4], V0[4], V1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        K0[i] = *reinterpret_cast<const u32x4*>(&stage[buf][0][i * 512 + lane * 8]);
+        K1[i] = *reinterpret_cast<const u32x4*>(&stage[buf][1][i * 512 + lane * 8]);
+        V0[i] = *reinterpret_cast<const u32x4*>(&stage[buf][2][i * 512 + lane * 8]);
+        V1[i] = *reinterpret_cast<const u32x4*>(&stage[buf][3][i * 512 + lane * 8]);
+      }
+      attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, scale_log2e, g, m, l, acc);
+    }
+    if (more) stash((c + 1) & 1, r0, r1);
+    __syncthreads();
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -455,13 +505,12 @@ extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, con
   if (!aligned16(out)) return MI_EINVAL;
   if (n_seqs == 0 || max_seqlen_q == 0) return MI_OK;
   const int G = n_q_heads / n_kv_heads;
-  const int tq = 16 / G;
-  const int q_blocks = (max_seqlen_q + tq - 1) / tq;
-  const dim3 grid((q_blocks + 3) / 4, n_kv_heads, n_seqs);
+  const int tq_wg = 8 * (16 / G);  // query tokens per workgroup
+  const dim3 grid((max_seqlen_q + tq_wg - 1) / tq_wg, n_kv_heads, n_seqs);
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = S(stream);
 #define LAUNCH_PRE(GG)                                                                                       \
-  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,      \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG>), grid, dim3(512), 0, st, q, q_row_stride, k_cache,      \
                      v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads, n_kv_heads, \
                      block_size / 16, sl2)
   switch (G) {

@@ -144,6 +144,32 @@ def test_kv_scatter_roundtrip(ops, block_size):
     assert torch.equal(to_logical(vc.cpu(), block_size, True).view(torch.int16), vc_o.view(torch.int16))
 
 
+@pytest.mark.parametrize("block_size", [16, 64])
+def test_kv_scatter_many_tokens_tiled_path(ops, block_size):
+    """>= 64 tokens with flat slots take the tile-transposing V path: aligned consecutive runs
+    (whole cache tiles), a run that starts mid-tile, a ragged tail, a skipped token and fully
+    random slots must all land bit-exactly."""
+    g = torch.Generator().manual_seed(block_size + 1)
+    hkv, nblk = 8, 40
+    T = 16 * 9 + 5
+    k = torch.randn(T, hkv, 128, generator=g).bfloat16()
+    v = torch.randn(T, hkv, 128, generator=g).bfloat16()
+    slots = torch.empty(T, dtype=torch.int32)
+    slots[0:64] = torch.arange(64) + 3 * block_size          # 4 aligned tiles
+    slots[64:96] = torch.arange(32) + 10 * block_size + 8     # consecutive but starting mid-tile
+    free = torch.arange(20 * block_size, 30 * block_size)
+    slots[96:] = free[torch.randperm(free.numel(), generator=g)[: T - 96]].to(torch.int32)  # random
+    slots[100] = -1
+    kc_o = torch.zeros(nblk, block_size, hkv, 128, dtype=torch.bfloat16)
+    vc_o = torch.zeros_like(kc_o)
+    oracle.kv_scatter(k, v, kc_o, vc_o, slots)
+    kc = torch.zeros(ops.kv_cache_shape(nblk, hkv, block_size), dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.reshape_and_cache(k.to(DEV), v.to(DEV), kc, vc, slots.to(DEV), hkv, block_size)
+    assert torch.equal(to_logical(kc.cpu(), block_size, False).view(torch.int16), kc_o.view(torch.int16))
+    assert torch.equal(to_logical(vc.cpu(), block_size, True).view(torch.int16), vc_o.view(torch.int16))
+
+
 def test_kv_scatter_golden(ops, golden_attention):
     g = golden_attention
     hq, hkv, d, bs, nblk = (int(v) for v in g["meta"])
@@ -158,9 +184,10 @@ def test_kv_scatter_golden(ops, golden_attention):
     assert int((to_logical(kc.cpu(), bs, False).reshape(-1, hkv * d) != 0).any(dim=1).sum()) == int(g["pre_cache_nonzero_rows"])
 
 
-def test_fused_qknorm_rope_store_equals_unfused(ops):
+@pytest.mark.parametrize("T_tokens", [37, 200])
+def test_fused_qknorm_rope_store_equals_unfused(ops, T_tokens):
     g = torch.Generator().manual_seed(77)
-    T, hq, hkv, bs, nblk = 37, 16, 8, 16, 8
+    T, hq, hkv, bs, nblk = T_tokens, 16, 8, 16, 24
     qkv = (torch.randn(T, (hq + 2 * hkv) * 128, generator=g) * 2).bfloat16().to(DEV)
     qw = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16().to(DEV)
     kw = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16().to(DEV)
