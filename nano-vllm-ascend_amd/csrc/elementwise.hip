@@ -3,6 +3,7 @@
 // point per reference rounding point (compiled with -ffp-contract=off so the
 // fp32 sequences match the reference's unfused torch ops bit for bit).
 #include "mi_common.hpp"
+#include "kv_store.hpp"
 
 namespace mi {
 
@@ -131,94 +132,6 @@ static int launch_rmsnorm(const uint16_t* x, const float* part, int nsplit, int6
 struct HeadSlot {
   int token, head, kind;  // kind 0 = q, 1 = k, 2 = v
 };
-
-__device__ __forceinline__ void load16(const uint16_t* p, float (&f)[8]) {
-  const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    f[2 * j] = lo_bf(raw[j]);
-    f[2 * j + 1] = hi_bf(raw[j]);
-  }
-}
-__device__ __forceinline__ u32x4 pack16(const float (&f)[8]) {
-  u32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = pack_bf(f[2 * j], f[2 * j + 1]);
-  return o;
-}
-
-// rms-normalise the 128 values held by 8 lanes (16 each) with weight w
-__device__ __forceinline__ void head_rmsnorm(float (&a)[8], float (&b)[8], const uint16_t* w, int j,
-                                             float eps) {
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += b[i] * b[i];
-  ss += __shfl_xor(ss, 1, 64);
-  ss += __shfl_xor(ss, 2, 64);
-  ss += __shfl_xor(ss, 4, 64);
-  const float rs = 1.0f / sqrtf(ss / 128.0f + eps);
-  float wa[8], wb[8];
-  load16(w + 8 * j, wa);
-  load16(w + 64 + 8 * j, wb);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    a[i] = rbf(rbf(a[i] * rs) * wa[i]);
-    b[i] = rbf(rbf(b[i] * rs) * wb[i]);
-  }
-}
-
-// NeoX rotation in fp32 (rotary_embedding.py:6-14): separate mul / sub / add
-__device__ __forceinline__ void head_rope(float (&a)[8], float (&b)[8], const float* cs, int j) {
-  const float4 c0 = *reinterpret_cast<const float4*>(cs + 8 * j);
-  const float4 c1 = *reinterpret_cast<const float4*>(cs + 8 * j + 4);
-  const float4 s0 = *reinterpret_cast<const float4*>(cs + 64 + 8 * j);
-  const float4 s1 = *reinterpret_cast<const float4*>(cs + 64 + 8 * j + 4);
-  const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-  const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float x1 = a[i], x2 = b[i];
-    a[i] = rbf(x1 * c[i] - x2 * s[i]);
-    b[i] = rbf(x2 * c[i] + x1 * s[i]);
-  }
-}
-
-__device__ __forceinline__ bool resolve_slot(const int32_t* slots, int slot_is_2d, int token,
-                                             int block_size, int64_t& blk, int& off) {
-  if (slot_is_2d) {
-    blk = slots[2 * token];
-    off = slots[2 * token + 1];
-    return blk >= 0 && off >= 0;
-  }
-  const int32_t s = slots[token];
-  if (s < 0) return false;
-  blk = s / block_size;
-  off = s % block_size;
-  return true;
-}
-
-__device__ __forceinline__ void store_k_head(uint16_t* k_cache, int64_t blk, int off, int h, int j,
-                                             const float (&a)[8], const float (&b)[8], int n_kv_heads,
-                                             int tpb) {
-  uint16_t* tile = k_cache + kv_tile_base(blk, h, off, n_kv_heads, tpb);
-  const int t = off & 15;
-  // chunk j: d = 8j ; chunk j+8: d = 64 + 8j
-  *reinterpret_cast<u32x4*>(tile + k_tile_off(t, 8 * j)) = pack16(a);
-  *reinterpret_cast<u32x4*>(tile + k_tile_off(t, 64 + 8 * j)) = pack16(b);
-}
-__device__ __forceinline__ void store_v_head(uint16_t* v_cache, int64_t blk, int off, int h, int j,
-                                             const float (&a)[8], const float (&b)[8], int n_kv_heads,
-                                             int tpb) {
-  uint16_t* tile = v_cache + kv_tile_base(blk, h, off, n_kv_heads, tpb);
-  const int t = off & 15;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    tile[v_tile_off(t, 8 * j + i)] = f2bf(a[i]);
-    tile[v_tile_off(t, 64 + 8 * j + i)] = f2bf(b[i]);
-  }
-}
 
 // MODE 0: fused norm+rope+store from packed qkv
 // MODE 1: rope only (q,k separate inputs -> contiguous outputs)

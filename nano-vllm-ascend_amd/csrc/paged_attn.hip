@@ -139,18 +139,27 @@ __device__ __forceinline__ void load_chunk_k(const uint16_t* __restrict__ cache,
 // ---------------------------------------------------------------------------
 // decode: grid (splits, n_kv_heads, batch), WAVES wavefronts per workgroup
 //
-// A workgroup owns one (sequence, kv head[, split]); its waves take the chunks of its range
-// round-robin and keep a running (max, sum, O) each; all 16 fragment loads of a chunk are issued
-// back to back (a software-pipelined variant that re-issued K/V loads mid-chunk spilled 50 VGPRs at
-// the 128-register budget of a 16-wave workgroup and measured 1.7x slower).  The waves are merged
-// through LDS; with one split per sequence (the batched
-// regime: batch * kv_heads >= ~128 workgroups) the workgroup writes the final bf16 row itself
-// and nothing else is launched.  With more splits (small batches) fp32 partials go to the
-// workspace and a tiny second kernel merges them.
-// The launch geometry is static (hipGraph); the work adapts to context_lens on the device.
+// A workgroup owns one (sequence, kv head[, split]).  The context is dealt to its waves in
+// contiguous runs of 16-token cache tiles (ceil(tiles / WAVES) each, so the slowest wave is at
+// most one tile - not one 32-token chunk - behind the mean); a wave walks its run two tiles per
+// MFMA chunk (plus a single-tile tail) with all 16 fragment loads of a chunk issued back to back
+// and keeps a running (max, sum, O).  (A software-pipelined variant that re-issued K/V loads
+// mid-chunk spilled 50 VGPRs at the 128-register budget of a 16-wave workgroup and measured 1.7x
+// slower.)  The waves are merged through LDS; with one split per sequence (the batched regime:
+// batch * kv_heads >= ~128 workgroups) the workgroup writes the final bf16 row itself and nothing
+// else is launched.  With more splits (small batches) fp32 partials go to the workspace and a tiny
+// second kernel merges them.  The launch geometry is static (hipGraph); the work adapts to
+// context_lens on the device.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int chunks_per_split(int n_chunks, int splits, int waves) {
-  return waves * ((n_chunks + waves * splits - 1) / (waves * splits));
+// load one chunk = tiles (t, t2); for a single-tile tail t2 == t (a cache hit) and the caller masks
+// the second half through the token limit - no branch, no zero fill
+__device__ __forceinline__ void load_tiles(const uint16_t* __restrict__ cache, const int32_t* __restrict__ table_row,
+                                           int t, int t2, int h, KvStrides st, int tpb, int lane,
+                                           u32x4 (&T0)[4], u32x4 (&T1)[4]) {
+  const int blk0 = table_row[t / tpb];
+  const int blk1 = table_row[t2 / tpb];
+  load_tile(cache + (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(t % tpb) * st.tile, lane, T0);
+  load_tile(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(t2 % tpb) * st.tile, lane, T1);
 }
 
 template <int G, int WAVES>
@@ -165,12 +174,13 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
 
   const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
   const int ctx = max(ctx_lens[b], 0);
-  const int n_chunks = (ctx + 31) >> 5, n_tiles = (ctx + 15) >> 4;
-  const int cps = chunks_per_split(n_chunks, splits, WAVES);
-  const int c0 = split * cps, c1 = min(n_chunks, c0 + cps);
+  const int n_tiles = (ctx + 15) >> 4;
+  // tiles per wave (equal for every wave of every split), this workgroup's and this wave's run
+  const int tpw = (n_tiles + WAVES * splits - 1) / (WAVES * splits);
+  const int wg_t0 = split * WAVES * tpw;
   const int64_t row0 = (int64_t)b * n_q_heads + h * G;  // first q head of this kv head
-  if (c0 >= n_chunks) {  // uniform for the workgroup: nothing to attend in this split
-    if (splits == 1) {   // empty context (graph padding row): the output row is zero
+  if (wg_t0 >= n_tiles) {  // uniform for the workgroup: nothing to attend in this split
+    if (splits == 1) {     // empty context (graph padding row): the output row is zero
       for (int idx = threadIdx.x; idx < G * 64; idx += WAVES * 64)
         *reinterpret_cast<uint32_t*>(out + row0 * 128 + 2 * idx) = 0u;
     } else {
@@ -185,35 +195,39 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, n = lane & 15;
   const int32_t* table_row = block_table + (int64_t)b * table_stride;
+  const int t0 = wg_t0 + wave * tpw, t1 = min(n_tiles, t0 + tpw);
 
   float m = -INFINITY, l = 0.f;
   f32x4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int c = c0 + wave;
-  if (c < c1) {
-    u32x4 K0[4], K1[4], V0[4], V1[4];
-    load_chunk_k(kc, table_row, c, n_tiles, h, kvs, tpb, lane, K0, K1);  // KV stream first ...
-    load_chunk_k(vc, table_row, c, n_tiles, h, kvs, tpb, lane, V0, V1);
-    bf16x8 Q[4];                                                          // ... then the (L2-resident) query
-    {
-      const uint16_t* qp = q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 + 8 * g;
+  const bool has_work = t0 < t1;
+  int t = t0;
+  u32x4 K0[4], K1[4], V0[4], V1[4];
+  if (has_work) {
+    const int t2 = t + 1 < t1 ? t + 1 : t;
+    load_tiles(kc, table_row, t, t2, h, kvs, tpb, lane, K0, K1);  // 16 fragment loads back to back
+    load_tiles(vc, table_row, t, t2, h, kvs, tpb, lane, V0, V1);
+  }
+  if (has_work) {
+    bf16x8 Q[4];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);  // n >= G reads head 0 (valid memory)
-        if (n >= G) v = u32x4{0, 0, 0, 0};
-        Q[kk] = as_frag(v);
-      }
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 +
+                                                8 * g + 32 * kk);  // n >= G reads head 0 (valid memory)
+      if (n >= G) v = u32x4{0, 0, 0, 0};
+      Q[kk] = as_frag(v);
     }
-    {
-      while (true) {
-        attend_chunk(K0, K1, V0, V1, Q, c * 32, ctx, scale_log2e, g, m, l, acc);
-        c += WAVES;
-        if (c >= c1) break;
-        load_chunk_k(kc, table_row, c, n_tiles, h, kvs, tpb, lane, K0, K1);
-        load_chunk_k(vc, table_row, c, n_tiles, h, kvs, tpb, lane, V0, V1);
-      }
+    while (true) {
+      // a single-tile chunk masks its (duplicate) second half through the token limit
+      const int lim = t + 1 < t1 ? ctx : min(ctx, (t + 1) * 16);
+      attend_chunk(K0, K1, V0, V1, Q, t * 16, lim, scale_log2e, g, m, l, acc);
+      t += 2;
+      if (t >= t1) break;
+      const int t2 = t + 1 < t1 ? t + 1 : t;
+      load_tiles(kc, table_row, t, t2, h, kvs, tpb, lane, K0, K1);
+      load_tiles(vc, table_row, t, t2, h, kvs, tpb, lane, V0, V1);
     }
   }
   l += __shfl_xor(l, 16, 64);
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     }
   }
   __syncthreads();
-  // merge the waves (wave 0 always has a chunk, so M is finite)
+  // merge the waves (wave 0 always has a tile, so M is finite)
   for (int idx = threadIdx.x; idx < G * 128; idx += WAVES * 64) {
     const int hn = idx >> 7, d = idx & 127;
     float M = sm_m[0][hn];
@@ -475,8 +489,8 @@ extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, cons
                                     const int32_t* context_lens, mi_bf16* out, void* workspace,
                                     size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
                                     int block_size, float scale, mi_stream stream) {
-  return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out, workspace,
-                     ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, 0,
+  return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out,
+                     workspace, ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, 0,
                      default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream);
 }
 
@@ -487,8 +501,8 @@ extern "C" int mi_paged_attn_decode_ex(const mi_bf16* q, int64_t q_row_stride, c
                                        size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
                                        int block_size, float scale, int num_splits, int64_t stride_block,
                                        int64_t stride_head, int64_t stride_tile, mi_stream stream) {
-  return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out, workspace,
-                     ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, num_splits,
+  return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out,
+                     workspace, ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, num_splits,
                      KvStrides{stride_block, stride_head, stride_tile}, stream);
 }
 
