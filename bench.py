@@ -137,8 +137,19 @@ def _attention_roofline(llm, seqs, iters):
     dur = s.elapsed_time(e) * 1e-3 / (iters * len(attn_mods))
     ctx_sum = int(sum(ctx_host))
     algo = ctx_sum * 2 * a0.num_kv_heads * 128 * 2  # K+V rows of every context token, bf16
-    return {"kernel": "paged_attn_decode_kernel+merge", "bound": "hbm", "achieved": algo / dur / 1e9,
-            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / dur / HBM_PEAK, "traffic": None,
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+    # gfx950 x2 read correction) of this same command, committed under profiles/; only quoted when
+    # the launch configuration matches the one that was profiled
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_attn_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc["batch"] == real and pmc["ctx_sum"] == ctx_sum:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"kernel": "paged_attn_decode_kernel", "bound": "hbm", "achieved": algo / dur / 1e9,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / dur / HBM_PEAK, "traffic": traffic,
             "bytes_per_launch": algo, "avg_launch_us": dur * 1e6, "launches_timed": iters * len(attn_mods)}
 
 
