@@ -1,0 +1,245 @@
+"""Unit tests of the CPU-side engine pieces, following the intent of the reference's ut/ suite
+(ut/test_block_manager.py, ut/test_multi_rank_block_manager.py, ut/test_scheduler.py) but derived
+from the reference CODE where its tests disagree with it (three ut/ cases assume a
+"len(seq)+1" convention that block_manager.py:99-118 does not implement)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from nanovllm.config import Config
+from nanovllm.engine import batch_meta
+from nanovllm.engine.block_manager import BlockManager
+from nanovllm.engine.scheduler import Scheduler
+from nanovllm.engine.sequence import FinishReason, Sequence, SequenceStatus
+from nanovllm.sampling_params import SamplingParams
+
+
+def seq(tokens, block_size=4, **sp):
+    return Sequence(list(tokens), SamplingParams(**sp), block_size=block_size)
+
+
+# ----------------------------------------------------------------------------- block manager
+def test_allocate_and_deallocate_counts():
+    bm = BlockManager(10, 4)
+    s = seq(range(10))  # 3 blocks
+    assert bm.can_allocate(s)
+    bm.allocate(s)
+    assert len(s.block_table) == 3 and len(bm.free_block_ids) == 7 and bm.used_block_ids == {0, 1, 2}
+    bm.deallocate(s)
+    assert s.block_table == [] and len(bm.free_block_ids) == 10 and not bm.used_block_ids
+    assert list(bm.free_block_ids)[-3:] == [2, 1, 0]  # released last-block-first (block_manager.py:90-97)
+
+
+def test_prefix_cache_hit_shares_full_blocks_only():
+    bm = BlockManager(10, 4)
+    a, b = seq([1, 2, 3, 4, 5, 6, 7, 8, 9]), seq([1, 2, 3, 4, 5, 6, 7, 8, 10])
+    bm.allocate(a)
+    bm.allocate(b)
+    assert a.block_table[:2] == b.block_table[:2] and a.block_table[2] != b.block_table[2]
+    assert (a.num_cached_tokens, b.num_cached_tokens) == (0, 8)
+    assert bm.blocks[a.block_table[0]].ref_count == 2
+    bm.deallocate(a)
+    assert bm.blocks[b.block_table[0]].ref_count == 1 and b.block_table[0] in bm.used_block_ids
+    # a divergent first block disables every later hit (block_manager.py:65,74-75)
+    c = seq([9, 2, 3, 4, 5, 6, 7, 8])
+    bm.allocate(c)
+    assert c.num_cached_tokens == 0 and not set(c.block_table) & set(b.block_table)
+
+
+def test_freed_block_is_revived_by_hash():
+    bm = BlockManager(6, 4)
+    a = seq([1, 2, 3, 4, 5])
+    bm.allocate(a)
+    first = a.block_table[0]
+    bm.deallocate(a)
+    b = seq([1, 2, 3, 4, 6])
+    bm.allocate(b)
+    assert b.block_table[0] == first and b.num_cached_tokens == 4  # revived, not re-taken from the head
+
+
+def test_can_append_and_may_append_follow_the_code_convention():
+    """len(seq) already counts the token whose KV this step writes (scheduler calls may_append after
+    the previous step's append_token)."""
+    bm = BlockManager(3, 4)
+    s = seq([1, 2, 3, 4])  # exactly one full block
+    bm.allocate(s)
+    assert bm.blocks[s.block_table[0]].hash != -1  # sealed at allocate
+    s.append_token(5)  # len 5 -> 5 % 4 == 1: this step needs a new block
+    assert bm.can_append(s)
+    bm.may_append(s)
+    assert len(s.block_table) == 2 and bm.blocks[s.block_table[1]].hash == -1
+    for t in (6, 7):
+        s.append_token(t)
+        bm.may_append(s)
+        assert len(s.block_table) == 2
+    s.append_token(8)  # len 8 -> 8 % 4 == 0: the tail block fills and is sealed with a chained hash
+    bm.may_append(s)
+    tail = bm.blocks[s.block_table[1]]
+    assert tail.hash == BlockManager.compute_hash([5, 6, 7, 8], bm.blocks[s.block_table[0]].hash)
+    assert bm.hash_to_block_id[tail.hash] == tail.block_id
+    # no free block left for a sequence that needs one
+    bm2 = BlockManager(1, 4)
+    s2 = seq([1, 2, 3, 4])
+    bm2.allocate(s2)
+    s2.append_token(9)
+    assert not bm2.can_append(s2)
+    s2.append_token(9)  # len 6: no block needed
+    assert bm2.can_append(s2)
+
+
+def test_two_managers_stay_identical_and_exhaustion_raises():
+    """Replicated bookkeeping is deterministic (the reference's whole multi-rank story)."""
+    managers = [BlockManager(8, 4), BlockManager(8, 4)]
+    tables = []
+    for bm in managers:
+        s1, s2 = seq(range(9)), seq(list(range(8)) + [99])
+        bm.allocate(s1)
+        bm.allocate(s2)
+        s1.append_token(7)
+        bm.may_append(s1)
+        tables.append((list(s1.block_table), list(s2.block_table), dict(bm.hash_to_block_id)))
+    assert tables[0] == tables[1]
+    bm = BlockManager(1, 4)
+    big = seq(range(9))
+    assert not bm.can_allocate(big)
+    with pytest.raises(IndexError):
+        bm.allocate(big)  # free list runs empty (ut/test_multi_rank_block_manager.py:71-81)
+
+
+# ----------------------------------------------------------------------------- scheduler
+def sched(**kw):
+    cfg = dict(max_num_seqs=4, max_num_batched_tokens=32, eos=99, num_kvcache_blocks=9, kvcache_block_size=4,
+               max_model_len=64)
+    cfg.update(kw)
+    return Scheduler(SimpleNamespace(**cfg))
+
+
+def test_prefill_first_and_token_budget():
+    sc = sched(max_num_batched_tokens=12)
+    a, b = seq(range(8)), seq(range(100, 108))
+    sc.add(a)
+    sc.add(b)
+    assert not sc.is_finished()
+    seqs, is_prefill = sc.schedule()
+    assert is_prefill and seqs == [a] and b in sc.waiting  # 8 + 8 > 12: head-of-line stop
+    assert a.status is SequenceStatus.RUNNING and len(sc.block_manager.free_block_ids) == 8 - 2
+    seqs, is_prefill = sc.schedule()
+    assert is_prefill and seqs == [b]  # prefill keeps priority over decoding a
+
+
+def test_decode_preempts_from_the_right_and_requeues_at_the_front():
+    sc = sched(num_kvcache_blocks=5)  # 4 usable blocks
+    a, b = seq(range(8), max_tokens=8), seq(range(50, 58), max_tokens=8)
+    sc.add(a)
+    sc.add(b)
+    seqs, _ = sc.schedule()
+    assert seqs == [a, b] and not sc.block_manager.free_block_ids
+    sc.postprocess(seqs, [1, 1])  # both now need a 3rd block, none is free
+    seqs, is_prefill = sc.schedule()
+    assert not is_prefill and seqs == [a]
+    assert b.status is SequenceStatus.WAITING and b.finish_reason is FinishReason.PREEMPTED
+    assert sc.waiting[0] is b and b.block_table == []
+    assert len(a.block_table) == 3
+
+
+def test_everything_preempted_returns_empty_decode_batch():
+    sc = sched(num_kvcache_blocks=3)  # 2 usable blocks
+    a = seq(range(8), max_tokens=4)
+    sc.add(a)
+    seqs, _ = sc.schedule()
+    sc.postprocess(seqs, [1])
+    seqs, is_prefill = sc.schedule()
+    assert seqs == [] and not is_prefill and sc.waiting[0] is a  # the runner must tolerate an empty batch
+
+
+def test_finish_conditions():
+    sc = sched(max_model_len=10)
+    a = seq(range(4), max_tokens=2)
+    b = seq(range(4), max_tokens=50)
+    c = seq(range(8), max_tokens=50)
+    d = seq(range(4), max_tokens=50, ignore_eos=True)
+    for s in (a, b, c, d):
+        sc.add(s)
+    seqs, _ = sc.schedule()
+    sc.postprocess(seqs, [5, 99, 5, 99])
+    assert b.is_finished and b.finish_reason is FinishReason.EOS and b not in sc.running
+    assert not d.is_finished  # EOS ignored
+    seqs, _ = sc.schedule()
+    assert seqs == [a, c, d]
+    sc.postprocess(seqs, [5, 5, 5])
+    assert a.finish_reason is FinishReason.LENGTH and a.num_completion_tokens == 2
+    assert c.finish_reason is FinishReason.LENGTH  # 8 + 2 == max_model_len
+    assert not d.is_finished and list(sc.running) == [d]
+    assert len(sc.block_manager.free_block_ids) == 8 - len(d.block_table)
+
+
+def test_abort_request():
+    sc = sched()
+    a = Sequence([1, 2, 3], SamplingParams(), request_id="r1", block_size=4)
+    b = Sequence([4, 5, 6], SamplingParams(), request_id="r2", block_size=4)
+    sc.add(a)
+    sc.add(b)
+    sc.schedule()
+    sc.abort_seq_group("r1")
+    assert a.finish_reason is FinishReason.ABORTED and list(sc.running) == [b] and a.block_table == []
+
+
+# ----------------------------------------------------------------------------- metadata / config / params
+def test_decode_meta_padding_matches_reference_layout():
+    a, b = seq(range(38), block_size=16), seq(range(43), block_size=16)
+    a.block_table, b.block_table = [0, 1, 2], [3, 4, 5]
+    m = batch_meta.decode_meta([a, b], pad_to=4, dummy_block=63, table_cols=8)
+    assert m.slot_mapping.tolist() == [[2, 5], [5, 10], [63, 0], [63, 0]]  # SURVEY.md §8c probe values
+    assert m.context_lens.tolist() == [38, 43, 0, 0] and m.positions.tolist() == [37, 42, 0, 0]
+    assert m.block_tables.shape == (4, 8) and m.block_tables[2:].tolist() == [[-1] * 8] * 2
+    assert m.block_tables.dtype == np.int32 and m.slot_mapping.dtype == np.int32 and m.input_ids.dtype == np.int64
+
+
+def test_sampling_params_and_config_validation(tmp_path):
+    with pytest.raises(AssertionError):
+        SamplingParams(temperature=0.0)  # as sampling_params.py:10-11
+    assert SamplingParams(greedy=True).temperature == 1.0
+    with pytest.raises(AssertionError):
+        Config(str(tmp_path / "missing"))
+    import json
+
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        architectures=["Qwen3ForCausalLM"], model_type="qwen3", hidden_size=128, num_hidden_layers=2,
+        num_attention_heads=2, num_key_value_heads=1, head_dim=128, intermediate_size=256, vocab_size=256,
+        max_position_embeddings=512, eos_token_id=7)))
+    cfg = Config(str(tmp_path), max_model_len=4096, max_num_batched_tokens=16384)
+    assert cfg.max_model_len == 512 and cfg.eos == 7 and cfg.use_graphs  # clamped to max_position_embeddings
+    with pytest.raises(AssertionError):
+        Config(str(tmp_path), kvcache_block_size=24)
+    with pytest.raises(AssertionError):
+        Config(str(tmp_path), tensor_parallel_size=9)
+    assert not Config(str(tmp_path), graph_mode="eager").use_graphs
+    assert Config(str(tmp_path), graph_mode="max-autotune").use_graphs  # reference alias
+
+
+def test_c_abi_exports_every_declared_symbol_and_rejects_bad_arguments():
+    """The library loads without a GPU; every header symbol is exported; argument validation happens
+    on the host (no compute calls here)."""
+    import ctypes
+    import re
+
+    from conftest import REPO
+    from nanovllm import _C
+
+    header = open(f"{REPO}/include/mi355_nanovllm.h").read()
+    declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", header)) - {"mi_bf16", "mi_stream"}
+    assert declared and declared == set(_C.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(_C.lib, name)
+    assert _C.lib.mi_rmsnorm(None, 0, None, None, 1, 1, 128, ctypes.c_float(1e-6), None) == -1  # MI_EINVAL
+    assert _C.lib.mi_gemm_bf16_skinny(1 << 20, 1 << 20, None, 1 << 20, 65, 16, 32, None) == -2  # M > 64
+    assert _C.lib.mi_paged_attn_decode_workspace(32, 16) == 32 * 16 * 16 * 130 * 4
+    assert b"unsupported" in _C.lib.mi_strerror(-2).lower() or b"not supported" in _C.lib.mi_strerror(-2).lower()
+    assert _C.lib.mi_kv_elem_offset(0, 5, 1, 37, 2, 16) == 1 * 2048 + (37 // 32) * 512 + (((37 % 32) // 8) * 16 + 5) * 8 + 37 % 8
+    with pytest.raises(_C.MiError):
+        import torch
+
+        from nanovllm import ops
+
+        ops.silu_mul(torch.zeros(2, 16, dtype=torch.bfloat16))  # CPU tensor: no fallback
