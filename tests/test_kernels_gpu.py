@@ -282,6 +282,21 @@ def test_gemm_packed(ops, M, N, K):
         assert_bf16_close(y, yo, max_ulp=2, max_frac=3e-2, atol=4e-2)
 
 
+@pytest.mark.parametrize("N,K", [(1280, 5120), (5120, 1024), (6400, 5120), (5120, 3200)])
+def test_gemm_packed_qwen3_32b_tp8_shapes(ops, N, K):
+    """per-rank projection shapes of BASELINE.json configs[2] (Qwen3-32B, TP=8): hidden 5120,
+    64 q / 8 kv heads, intermediate 25600"""
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(32, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16()
+    wp = ops.pack_weight(w.to(DEV))
+    atol = K * 2.0 ** -22
+    assert_bf16_close(ops.gemm_packed(x.to(DEV), wp), oracle.linear(x, w), max_frac=2e-2, atol=atol)
+    if N % 32 == 0:
+        assert_bf16_close(ops.gemm_packed(x.to(DEV), wp, silu_mul=True), oracle.silu_and_mul(oracle.linear(x, w)),
+                          max_ulp=2, max_frac=3e-2, atol=32 * atol)
+
+
 def test_gemm_lm_head_shape(ops):
     g = torch.Generator().manual_seed(1)
     M, N, K = 32, 151936, 1024
