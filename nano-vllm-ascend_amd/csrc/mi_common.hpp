@@ -17,16 +17,15 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ float bf2f(uint16_t h) {
   return __uint_as_float(static_cast<uint32_t>(h) << 16);
 }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<uint16_t>(u >> 16);
-}
+// float -> bf16 is the hardware conversion (v_cvt_pk_bf16_f32: round to nearest even, the
+// rule of c10::BFloat16) through the compiler's native __bf16 casts
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f)); }
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
-  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+  const bf16x2 v = {static_cast<__bf16>(lo), static_cast<__bf16>(hi)};
+  return __builtin_bit_cast(uint32_t, v);
 }
 // round a float to the nearest bf16 and return it as float
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }

@@ -33,19 +33,29 @@ __device__ __forceinline__ void load_tile(const uint16_t* __restrict__ tile, int
 
 // S^T = K . Q^T for one chunk, masked and scaled to the log2 domain.
 // `limit`: tokens with index < limit are visible to this lane's column.
+// `limit_all`: a wave-uniform lower bound of `limit` over the wave's columns.
 __device__ __forceinline__ void score_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4], const bf16x8 (&Q)[4],
-                                            int tok0, int limit, float scale_log2e, int g, float (&p)[8]) {
+                                            int tok0, int limit, int limit_all, float scale_log2e, int g,
+                                            float (&p)[8]) {
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K0[kk]), Q[kk], s0, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K1[kk]), Q[kk], s1, 0, 0, 0);
   }
-  const int t0 = tok0 + 4 * g;
+  if (tok0 + 32 <= limit_all) {  // wave-uniform: the whole chunk is visible to every column
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    p[r] = (t0 + r < limit) ? s0[r] * scale_log2e : -INFINITY;
-    p[4 + r] = (t0 + 16 + r < limit) ? s1[r] * scale_log2e : -INFINITY;
+    for (int r = 0; r < 4; ++r) {
+      p[r] = s0[r] * scale_log2e;
+      p[4 + r] = s1[r] * scale_log2e;
+    }
+  } else {
+    const int t0 = tok0 + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = (t0 + r < limit) ? s0[r] * scale_log2e : -INFINITY;
+      p[4 + r] = (t0 + 16 + r < limit) ? s1[r] * scale_log2e : -INFINITY;
+    }
   }
 }
 
@@ -57,24 +67,26 @@ __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0
   mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
   const float mn = fmaxf(m, mc);
   const bool dead = mn == -INFINITY;  // nothing visible for this column yet
-  const float alpha = dead ? 1.0f : exp2f(m - mn);
   const float ms = dead ? 0.0f : mn;
   float ps = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    p[i] = exp2f(p[i] - ms);
+    p[i] = __builtin_amdgcn_exp2f(p[i] - ms);  // v_exp_f32: arguments are <= 0, tiny results may flush to 0
     ps += p[i];
   }
-  l = l * alpha + ps;
-  m = mn;
+  if (__any(mn != m)) {  // some column's running maximum moved: rescale (rare after the first chunks)
+    const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m - mn);
+    l *= alpha;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+    for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+    m = mn;
+  }
+  l += ps;
   u32x4 ph, pl;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float h0 = rbf(p[2 * i]), h1 = rbf(p[2 * i + 1]);
-    ph[i] = (__float_as_uint(h0) >> 16) | (__float_as_uint(h1) & 0xffff0000u);
-    pl[i] = pack_bf(p[2 * i] - h0, p[2 * i + 1] - h1);
+    ph[i] = pack_bf(p[2 * i], p[2 * i + 1]);
+    pl[i] = pack_bf(p[2 * i] - lo_bf(ph[i]), p[2 * i + 1] - hi_bf(ph[i]));
   }
   const bf16x8 Ph = as_frag(ph), Pl = as_frag(pl);
 #pragma unroll
@@ -88,10 +100,10 @@ __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0
 
 __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
                                              const u32x4 (&V0)[4], const u32x4 (&V1)[4],
-                                             const bf16x8 (&Q)[4], int tok0, int limit, float scale_log2e,
-                                             int g, float& m, float& l, f32x4 (&acc)[8]) {
+                                             const bf16x8 (&Q)[4], int tok0, int limit, int limit_all,
+                                             float scale_log2e, int g, float& m, float& l, f32x4 (&acc)[8]) {
   float p[8];
-  score_chunk(K0, K1, Q, tok0, limit, scale_log2e, g, p);
+  score_chunk(K0, K1, Q, tok0, limit, limit_all, scale_log2e, g, p);
   accumulate_chunk(p, V0, V1, m, l, acc);
 }
 
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     while (true) {
       // a single-tile chunk masks its (duplicate) second half through the token limit
       const int lim = t + 1 < t1 ? ctx : min(ctx, (t + 1) * 16);
-      attend_chunk(K0, K1, V0, V1, Q, t * 16, lim, scale_log2e, g, m, l, acc);
+      attend_chunk(K0, K1, V0, V1, Q, t * 16, lim, lim, scale_log2e, g, m, l, acc);
       t += 2;
       if (t >= t1) break;
       const int t2 = t + 1 < t1 ? t + 1 : t;
@@ -338,6 +350,7 @@ __global__ __launch_bounds__(512) void paged_attn_prefill_kernel(
   const bool valid = wave_on && my_qt < q_len;
   const int limit = valid ? shift + my_qt + 1 : 1;
   const int wave_chunks = wave_on ? (shift + min(qt0 + TQ, q_len) - 1 + 32) >> 5 : 0;
+  const int limit_all = wave_on && qt0 + TQ <= q_len ? shift + qt0 + 1 : 0;  // earliest column of a full block
 
   bf16x8 Q[4];
   {
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(512) void paged_attn_prefill_kernel(
         V0[i] = *reinterpret_cast<const u32x4*>(&stage[buf][2][i * 512 + lane * 8]);
         V1[i] = *reinterpret_cast<const u32x4*>(&stage[buf][3][i * 512 + lane * 8]);
       }
-      attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, scale_log2e, g, m, l, acc);
+      attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, limit_all, scale_log2e, g, m, l, acc);
     }
     if (more) stash((c + 1) & 1, r0, r1);
     __syncthreads();
