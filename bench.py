@@ -107,6 +107,9 @@ def _attention_roofline(llm, seqs, iters):
     tables = torch.tensor([x.block_table + [-1] * (width - len(x.block_table)) for x in seqs],
                           dtype=torch.int32, device=dev)
     ctx = torch.tensor(ctx_host, dtype=torch.int32, device=dev)
+    if os.environ.get("BENCH_ATTN_RANDOM_TABLES"):  # experiment: same cache, scattered block ids
+        nblk = llm.config.num_kvcache_blocks
+        tables = torch.randperm(nblk - 1)[: real * width].to(torch.int32).view(real, width).to(dev)
     attn_mods = [m for m in mr.model.modules() if hasattr(m, "k_cache") and hasattr(m, "v_cache")]
     a0 = attn_mods[0]
     q = torch.randn(real, a0.num_heads * 128, device=dev).bfloat16()
@@ -187,7 +190,8 @@ def main():
     total_new = args.warmup + args.steps + 2
     blocks_needed = BATCH * ((PROMPT_LEN + total_new) // BLOCK + 2) + 64
     kw = dict(tensor_parallel_size=world, kvcache_block_size=BLOCK, max_num_seqs=BATCH, max_model_len=4096,
-              max_num_batched_tokens=16384, num_kvcache_blocks=max(blocks_needed, 4096), hccl_port=port + 1,
+              max_num_batched_tokens=16384,
+              num_kvcache_blocks=int(os.environ.get("BENCH_NBLK", max(blocks_needed, 4096))), hccl_port=port + 1,
               synthetic_seed=0, warmup=os.environ.get("BENCH_NO_WARMUP") is None,
               enforce_eager=os.environ.get("BENCH_EAGER") is not None)
     if rank != 0:
