@@ -96,3 +96,49 @@ def decode_meta(seqs: list[Sequence], pad_to: int | None = None, dummy_block: in
         slot[i, 1] = s.last_block_num_tokens - 1
     tables = block_table_matrix(seqs, rows=rows, cols=table_cols)
     return DecodeMeta(ids, pos, ctx, slot, tables, real)
+
+
+class DecodeStager:
+    """decode_meta() written in place into preallocated (pinned) arrays, with the block-table rows
+    updated incrementally: a row is rewritten only when another sequence - or the same sequence with
+    a rebuilt table (preemption + re-prefill bumps `table_gen`) - moves into it; otherwise only the
+    newly appended block ids are written.  Produces exactly decode_meta(seqs, pad_to=bucket, ...)."""
+
+    def __init__(self, ids, pos, ctx, slots, tables, temps=None):
+        self.ids, self.pos, self.ctx, self.slots, self.tables, self.temps = ids, pos, ctx, slots, tables, temps
+        self.tables[:] = -1
+        self._owner = [(-1, -1, 0)] * tables.shape[0]  # (seq_id, table_gen, entries written) per row
+
+    def fill(self, seqs: list[Sequence], bucket: int, dummy_block: int) -> None:
+        real = len(seqs)
+        ids, pos, ctx, slots, tables, owner = self.ids, self.pos, self.ctx, self.slots, self.tables, self._owner
+        for i, s in enumerate(seqs):
+            n = s.num_tokens
+            table = s.block_table
+            nb = len(table)
+            ids[i] = s.last_token
+            pos[i] = n - 1
+            ctx[i] = n
+            slots[i, 0] = table[-1]
+            slots[i, 1] = s.last_block_num_tokens - 1
+            if self.temps is not None:
+                self.temps[i] = 0.0 if s.greedy else s.temperature
+            sid, gen, written = owner[i]
+            if sid == s.seq_id and gen == s.table_gen and written <= nb:
+                if written < nb:
+                    tables[i, written:nb] = table[written:nb]
+            else:
+                row = tables[i]
+                row[:nb] = table
+                row[nb:] = -1
+            owner[i] = (s.seq_id, s.table_gen, nb)
+        if bucket > real:
+            ids[real:bucket] = 0
+            pos[real:bucket] = 0
+            ctx[real:bucket] = 0
+            slots[real:bucket, 0] = dummy_block
+            slots[real:bucket, 1] = 0
+            for i in range(real, bucket):
+                if owner[i][0] != -1:
+                    tables[i] = -1
+                    owner[i] = (-1, -1, 0)

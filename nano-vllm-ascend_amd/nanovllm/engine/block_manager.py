@@ -80,6 +80,7 @@ class BlockManager:
 
     def allocate(self, seq: Sequence) -> None:
         assert not seq.block_table
+        seq.table_gen = getattr(seq, "table_gen", 0) + 1  # a fresh table: cached device rows of it are stale
         bs, lookup = self.block_size, self.hash_to_block_id
         chain, missed = _NO_HASH, False
         for i in range(seq.num_blocks):

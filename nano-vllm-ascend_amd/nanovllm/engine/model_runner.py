@@ -199,45 +199,15 @@ class ModelRunner:
 
         self.dev = views(self.dev_stage)
         self.host = {k: t.numpy() for k, t in views(self.host_stage).items()}
-        self.host["tables"][:] = -1
-        self._row_owner = [(-1, 0)] * B  # (seq_id, blocks written) per table row
+        h = self.host
+        self.stager = batch_meta.DecodeStager(h["ids"], h["pos"], h["ctx"], h["slots"], h["tables"], h["temps"])
         self.tokens_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
         self.tokens_host = torch.zeros(B, dtype=torch.int64, pin_memory=True)
 
     def _fill_decode_stage(self, seqs: list[Sequence], bucket: int):
-        """Same values as batch_meta.decode_meta(seqs, pad_to=bucket, ...), written in place;
-        block-table rows are updated incrementally (a row changes by at most one entry per step)."""
-        h = self.host
-        real = len(seqs)
-        dummy = self.config.num_kvcache_blocks - 1
-        for i, s in enumerate(seqs):
-            n = s.num_tokens
-            h["ids"][i] = s.last_token
-            h["pos"][i] = n - 1
-            h["ctx"][i] = n
-            h["slots"][i, 0] = s.block_table[-1]
-            h["slots"][i, 1] = s.last_block_num_tokens - 1
-            h["temps"][i] = 0.0 if s.greedy else s.temperature
-            owner, written = self._row_owner[i]
-            nb = len(s.block_table)
-            if owner == s.seq_id and written <= nb:
-                if written < nb:
-                    h["tables"][i, written:nb] = s.block_table[written:nb]
-            else:
-                row = h["tables"][i]
-                row[:nb] = s.block_table
-                row[nb:] = -1
-            self._row_owner[i] = (s.seq_id, nb)
-        if bucket > real:
-            h["ids"][real:bucket] = 0
-            h["pos"][real:bucket] = 0
-            h["ctx"][real:bucket] = 0
-            h["slots"][real:bucket, 0] = dummy
-            h["slots"][real:bucket, 1] = 0
-            for i in range(real, bucket):
-                if self._row_owner[i][0] != -1:
-                    h["tables"][i] = -1
-                    self._row_owner[i] = (-1, 0)
+        """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the pinned
+        staging buffer (incremental block-table rows), then ONE async copy to the device."""
+        self.stager.fill(seqs, bucket, self.config.num_kvcache_blocks - 1)
         self.dev_stage.copy_(self.host_stage, non_blocking=True)
 
     # ------------------------------------------------------------------ metadata -> context

@@ -243,3 +243,46 @@ def test_c_abi_exports_every_declared_symbol_and_rejects_bad_arguments():
         from nanovllm import ops
 
         ops.silu_mul(torch.zeros(2, 16, dtype=torch.bfloat16))  # CPU tensor: no fallback
+
+
+def test_decode_stager_equals_decode_meta_under_preemption_and_churn():
+    """The incremental staging writer (what the runner uploads every step) must equal the plain
+    decode_meta() at every step of a run with tight memory: preemptions rebuild block tables,
+    finished sequences hand their rows to others."""
+    import random
+
+    rng = random.Random(3)
+    max_seqs, bs, cols, nblk = 6, 4, 16, 19
+    sc = sched(max_num_seqs=max_seqs, max_num_batched_tokens=64, num_kvcache_blocks=nblk, kvcache_block_size=bs,
+               max_model_len=cols * bs - 1)
+    stage = dict(ids=np.zeros(max_seqs, np.int64), pos=np.zeros(max_seqs, np.int64), ctx=np.zeros(max_seqs, np.int32),
+                 slots=np.zeros((max_seqs, 2), np.int32), tables=np.zeros((max_seqs, cols), np.int32))
+    stager = batch_meta.DecodeStager(**stage)
+    pending = [seq([rng.randrange(1, 90) for _ in range(rng.randrange(2, 14))], block_size=bs,
+                   max_tokens=rng.randrange(3, 25), ignore_eos=True) for _ in range(14)]
+    decode_steps = preemptions = 0
+    step = 0
+    while pending or not sc.is_finished():
+        if pending and step % 3 == 0:
+            sc.add(pending.pop())
+        step += 1
+        if sc.is_finished():
+            continue
+        before = {id(s): s.table_gen for s in sc.running}
+        seqs, is_prefill = sc.schedule()
+        if not seqs:
+            continue
+        if is_prefill:
+            preemptions += sum(1 for s in seqs if s.table_gen > 1)
+        else:
+            decode_steps += 1
+            bucket = next(b for b in (1, 2, 4, max_seqs) if b >= len(seqs))
+            stager.fill(seqs, bucket, nblk - 1)
+            want = batch_meta.decode_meta(seqs, pad_to=bucket, dummy_block=nblk - 1, table_cols=cols)
+            assert stage["ids"][:bucket].tolist() == want.input_ids.tolist()
+            assert stage["pos"][:bucket].tolist() == want.positions.tolist()
+            assert stage["ctx"][:bucket].tolist() == want.context_lens.tolist()
+            assert stage["slots"][:bucket].tolist() == want.slot_mapping.tolist()
+            assert stage["tables"][:bucket].tolist() == want.block_tables.tolist(), step
+        sc.postprocess(seqs, [rng.randrange(1, 90) for _ in seqs])
+    assert decode_steps > 30 and preemptions > 0  # the run did exercise re-prefill after preemption
