@@ -16,6 +16,12 @@ TINY = dict(QWEN3_0_6B, hidden_size=128, num_hidden_layers=2, num_attention_head
 MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
            bos_token_id=0)
 
+# BASELINE.json configs[2]: Qwen3-32B widths (hidden 5120, 64 q / 8 kv heads, intermediate 25600), cut to
+# 2 layers and a 4096 vocabulary so that the CPU oracle finishes in seconds
+QWEN3_32B_2L = dict(QWEN3_0_6B, hidden_size=5120, num_hidden_layers=2, num_attention_heads=64,
+                    num_key_value_heads=8, intermediate_size=25600, vocab_size=4096, max_position_embeddings=4096,
+                    tie_word_embeddings=False, eos_token_id=4095, bos_token_id=0)
+
 
 def make_model_dir(cfg: dict, root: str | None = None) -> str:
     d = tempfile.mkdtemp(prefix="mi355_model_", dir=root)

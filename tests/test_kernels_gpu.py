@@ -414,7 +414,7 @@ def test_prefill_attention_golden(ops, golden_attention):
     assert (out.float() - bf(g["pre_out"]).float()).abs().max().item() <= 3e-2
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (16, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (64, 8), (8, 1), (16, 1)])
 @pytest.mark.parametrize("block_size", [16, 256])
 def test_prefill_attention_random(ops, hq, hkv, block_size):
     gen = torch.Generator().manual_seed(hq + hkv + block_size)
