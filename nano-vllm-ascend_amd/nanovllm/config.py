@@ -45,6 +45,7 @@ class Config:
     device: str = "cuda"
     trust_remote_code: bool = False
     synthetic_seed: int = 0
+    prefix_aware_prefill: bool = True  # skip the tokens of cache-hit prefix blocks in prefill (False: recompute, as the reference)
 
     def __post_init__(self):
         assert os.path.isdir(self.model), f"model must be a directory with a HF config.json: {self.model}"

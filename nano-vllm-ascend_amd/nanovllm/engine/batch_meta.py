@@ -51,28 +51,45 @@ def block_table_matrix(seqs: list[Sequence], rows: int | None = None, cols: int 
     return out
 
 
-def prefill_meta(seqs: list[Sequence], block_size: int) -> PrefillMeta:
-    """Every token of every scheduled sequence is (re)computed — cached prefix blocks are
-    not skipped (model_runner.py:248-249) — and positions restart at 0 per sequence."""
-    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+def prefill_meta(seqs: list[Sequence], block_size: int, skip_cached: bool = False) -> PrefillMeta:
+    """skip_cached=False is the reference: every token of every scheduled sequence is (re)computed -
+    cached prefix blocks are not skipped (model_runner.py:248-249) - positions restart at 0.
+
+    skip_cached=True feeds only the tokens behind the leading cache hits
+    (`num_prefix_tokens`, whole blocks): queries start at that position, their K/V rows go to the
+    slots of the non-shared blocks, and attention reaches the shared prefix through the block
+    table (kv_lens stays the full length).  A fully cached prompt still computes its last token
+    (the logits row), without rewriting that token's shared KV row (slot -1)."""
+    full = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    if skip_cached:
+        skip = np.fromiter((min(s.num_prefix_tokens, len(s) - 1) for s in seqs), dtype=np.int64, count=len(seqs))
+    else:
+        skip = np.zeros(len(seqs), dtype=np.int64)
+    lens = full - skip
     cu = np.zeros(len(seqs) + 1, dtype=np.int32)
     np.cumsum(lens, out=cu[1:])
+    cu_k = np.zeros(len(seqs) + 1, dtype=np.int32)
+    np.cumsum(full, out=cu_k[1:])
     total = int(cu[-1])
     ids = np.empty(total, dtype=np.int64)
     pos = np.empty(total, dtype=np.int64)
     slots = np.empty(total, dtype=np.int32)
-    within = np.arange(int(lens.max()) if len(seqs) else 0, dtype=np.int64)
-    for s, a, n in zip(seqs, cu[:-1], lens):
-        a, n = int(a), int(n)
-        ids[a:a + n] = s.token_ids
-        pos[a:a + n] = within[:n]
+    within = np.arange(int(full.max()) if len(seqs) else 0, dtype=np.int64)
+    for s, a, n, k in zip(seqs, cu[:-1], lens, skip):
+        a, n, k = int(a), int(n), int(k)
+        w = within[k:k + n]
+        ids[a:a + n] = s.token_ids[k:k + n] if k else s.token_ids
+        pos[a:a + n] = w
         if s.block_table:
             table = np.asarray(s.block_table[: s.num_blocks], dtype=np.int64)
-            slots[a:a + n] = (table[within[:n] // block_size] * block_size + within[:n] % block_size)
+            slots[a:a + n] = table[w // block_size] * block_size + w % block_size
+            if skip_cached and k < s.num_prefix_tokens:  # recomputed only for its logits
+                slots[a:a + s.num_prefix_tokens - k] = -1
         else:
             slots[a:a + n] = -1
-    mx = int(lens.max()) if len(seqs) else 0
-    return PrefillMeta(ids, pos, cu, cu.copy(), mx, mx, slots, block_table_matrix(seqs), lens.astype(np.int32))
+    mq = int(lens.max()) if len(seqs) else 0
+    mk = int(full.max()) if len(seqs) else 0
+    return PrefillMeta(ids, pos, cu, cu_k, mq, mk, slots, block_table_matrix(seqs), full.astype(np.int32))
 
 
 def decode_meta(seqs: list[Sequence], pad_to: int | None = None, dummy_block: int = 0,

@@ -82,7 +82,7 @@ class BlockManager:
         assert not seq.block_table
         seq.table_gen = getattr(seq, "table_gen", 0) + 1  # a fresh table: cached device rows of it are stale
         bs, lookup = self.block_size, self.hash_to_block_id
-        chain, missed = _NO_HASH, False
+        chain, missed, hits = _NO_HASH, False, 0
         for i in range(seq.num_blocks):
             toks = seq.block(i)
             if self.non_cache_token_ids and not self.non_cache_token_ids.isdisjoint(toks):
@@ -95,7 +95,8 @@ class BlockManager:
                 hit_id = self.free_block_ids[0]
                 blk = self._take(hit_id)
             else:
-                seq.num_cached_tokens += bs
+                seq.num_cached_tokens += bs  # reporting counter: only ever grows (block_manager.py:79)
+                hits += 1
                 if hit_id in self.used_block_ids:
                     blk = self.blocks[hit_id]
                     blk.ref_count += 1
@@ -105,6 +106,10 @@ class BlockManager:
                 blk.update(chain, toks)
                 lookup[chain] = hit_id
             seq.block_table.append(hit_id)
+        # hits are always a leading run (after the first miss everything misses), and a hit block
+        # holds valid KV rows by the time this prefill's attention reads it: it was written by an
+        # earlier step, or is written earlier in the same forward pass by the sequence that owns it
+        seq.num_prefix_tokens = hits * bs
 
     def deallocate(self, seq: Sequence) -> None:
         for block_id in reversed(seq.block_table):
@@ -113,6 +118,7 @@ class BlockManager:
             if blk.ref_count == 0:
                 self._release(block_id)
         seq.block_table.clear()
+        seq.num_prefix_tokens = 0
 
     # -- decode ------------------------------------------------------------------------------------
     def can_append(self, seq: Sequence) -> bool:

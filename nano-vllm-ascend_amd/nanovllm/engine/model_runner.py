@@ -212,7 +212,7 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ metadata -> context
     def prepare_prefill(self, seqs: list[Sequence]):
-        m = batch_meta.prefill_meta(seqs, self.block_size)
+        m = batch_meta.prefill_meta(seqs, self.block_size, skip_cached=self.config.prefix_aware_prefill)
 
         def up(a):
             return torch.from_numpy(a).pin_memory().to(self.device, non_blocking=True)

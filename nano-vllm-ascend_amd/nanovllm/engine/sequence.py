@@ -31,7 +31,7 @@ class Sequence:
 
     __slots__ = ("block_size", "seq_id", "request_id", "status", "token_ids", "last_token", "num_tokens",
                  "num_prompt_tokens", "num_cached_tokens", "block_table", "temperature", "max_tokens",
-                 "ignore_eos", "greedy", "finish_reason", "arrival_time", "first_token_time", "table_gen")
+                 "ignore_eos", "greedy", "finish_reason", "arrival_time", "first_token_time", "table_gen", "num_prefix_tokens")
 
     def __init__(self, token_ids: list[int], sampling_params: SamplingParams | None = None,
                  request_id: str | None = None, block_size: int = 256, **_ignored_multimodal):
@@ -52,6 +52,7 @@ class Sequence:
         self.finish_reason = None
         self.arrival_time = 0.0
         self.first_token_time = 0.0
+        self.num_prefix_tokens = 0  # leading tokens whose KV rows the current block table already holds (cache hits)
         self.table_gen = 0  # bumped every time the block table is rebuilt (allocate after a preemption)
 
     # -- container protocol ------------------------------------------------------------------
@@ -106,7 +107,7 @@ class Sequence:
 
     # -- rank-RPC wire format -------------------------------------------------------------------
     # header: [seq_id, num_tokens, num_prompt_tokens, num_cached_tokens, block_size, n_blocks,
-    #          n_tokens_sent, temperature_bits, greedy, table_gen]; then block ids; then the token ids the
+    #          n_tokens_sent, temperature_bits, greedy, table_gen, num_prefix_tokens]; then block ids; then the token ids the
     # receiver needs (all of them for a prefill step, only the last one for a decode step).
     def to_wire(self, is_prefill: bool) -> list[int]:
         import struct
@@ -114,15 +115,16 @@ class Sequence:
         toks = self.token_ids if is_prefill else self.token_ids[-1:]
         tbits = struct.unpack("<q", struct.pack("<d", float(self.temperature)))[0]
         return [self.seq_id, self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_size,
-                len(self.block_table), len(toks), tbits, int(self.greedy), self.table_gen, *self.block_table, *toks]
+                len(self.block_table), len(toks), tbits, int(self.greedy), self.table_gen,
+                self.num_prefix_tokens, *self.block_table, *toks]
 
     @classmethod
     def from_wire(cls, buf, pos: int = 0) -> tuple["Sequence", int]:
         import struct
 
-        (seq_id, num_tokens, num_prompt, num_cached, block_size, n_blocks, n_toks, tbits, greedy, table_gen) = (
-            int(v) for v in buf[pos: pos + 10])
-        pos += 10
+        (seq_id, num_tokens, num_prompt, num_cached, block_size, n_blocks, n_toks, tbits, greedy, table_gen,
+         num_prefix) = (int(v) for v in buf[pos: pos + 11])
+        pos += 11
         s = object.__new__(cls)
         s.block_size, s.seq_id, s.request_id = block_size, seq_id, None
         s.status = SequenceStatus.RUNNING
@@ -136,7 +138,7 @@ class Sequence:
         s.num_tokens, s.num_prompt_tokens, s.num_cached_tokens = num_tokens, num_prompt, num_cached
         s.temperature = struct.unpack("<d", struct.pack("<q", tbits))[0]
         s.greedy = bool(greedy)
-        s.table_gen = table_gen
+        s.table_gen, s.num_prefix_tokens = table_gen, num_prefix
         s.max_tokens, s.ignore_eos, s.finish_reason = 0, True, None
         s.arrival_time = s.first_token_time = 0.0
         return s, pos

@@ -250,3 +250,54 @@ def test_decode_batch_above_64_rows_uses_library_gemm_path():
     big, small = run(128), run(8)
     same = sum(int(a == b) for x, y in zip(big, small) for a, b in zip(x, y))
     assert same >= 0.97 * 320, same  # different GEMM kernels: allow a few near-tie flips
+
+
+def test_prefix_aware_prefill_matches_full_recompute_oracle():
+    """prefill that skips cache-hit prefix blocks and attends to them through the
+    block table.  Three waves over a shared 96-token prefix (same-step sharing, sharing with a
+    running sequence, a fully cached prompt, revival of freed blocks after everything finished)
+    against the oracle, which recomputes every token as the reference does."""
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.engine import batch_meta
+
+    llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+              max_model_len=512, num_kvcache_blocks=80, warmup=False, synthetic_seed=11)
+    assert llm.config.prefix_aware_prefill
+    try:
+        oracle = _oracle_for(llm, MID, 11)
+        gen = torch.Generator().manual_seed(9)
+        rnd = lambda n: torch.randint(0, 4096, (n,), generator=gen).tolist()  # noqa: E731
+        prefix = rnd(96)
+        waves = [[prefix + rnd(20), prefix + rnd(3)],       # second shares blocks written in the same step
+                 [prefix + rnd(40), list(prefix)],          # shares with running sequences; fully cached prompt
+                 [prefix[:48] + rnd(10)]]                   # after all finished: revives freed blocks
+        sp = SamplingParams(max_tokens=5, ignore_eos=True, greedy=True)
+        worst, skipped, steps = 0.0, 0, 0
+        for w, wave in enumerate(waves):
+            for p in wave:
+                llm.add_request(p, sp)
+            budget = 3 if w == 0 else 1000  # wave 1 arrives while wave 0 is still decoding; wave 2 after all finished
+            while not llm.is_finished() and budget > 0:
+                budget -= 1
+                seqs, is_prefill = llm.scheduler.schedule()
+                if is_prefill:
+                    m = batch_meta.prefill_meta(seqs, 16)
+                    fed = batch_meta.prefill_meta(seqs, 16, skip_cached=True)
+                    skipped += len(m.input_ids) - len(fed.input_ids)
+                    want = oracle.prefill(torch.from_numpy(m.input_ids), torch.from_numpy(m.positions),
+                                          torch.from_numpy(m.cu_seqlens_q), torch.from_numpy(m.slot_mapping),
+                                          torch.from_numpy(m.block_tables), fp32_logits=True)
+                else:
+                    m = batch_meta.decode_meta(seqs)
+                    want = oracle.decode(torch.from_numpy(m.input_ids), torch.from_numpy(m.positions),
+                                         torch.from_numpy(m.slot_mapping), torch.from_numpy(m.context_lens),
+                                         torch.from_numpy(m.block_tables), fp32_logits=True)
+                llm.model_runner.call("run", seqs, is_prefill)
+                got = llm.model_runner.last_logits[: len(seqs)].float().cpu()
+                worst = max(worst, (got - want).abs().max().item())
+                llm.scheduler.postprocess(seqs, want.argmax(-1).tolist())
+                steps += 1
+        assert skipped == 96 + 96 + 95 + 48, skipped
+        assert worst <= 4e-2, worst
+    finally:
+        llm.exit()

@@ -286,3 +286,32 @@ def test_decode_stager_equals_decode_meta_under_preemption_and_churn():
             assert stage["tables"][:bucket].tolist() == want.block_tables.tolist(), step
         sc.postprocess(seqs, [rng.randrange(1, 90) for _ in seqs])
     assert decode_steps > 30 and preemptions > 0  # the run did exercise re-prefill after preemption
+
+
+def test_prefill_meta_skipping_cached_prefix_blocks():
+    """skip_cached=True: only the tokens behind the leading cache-hit blocks are fed; a fully cached
+    prompt keeps its last token (for the logits) but does not rewrite its shared KV row."""
+    bs = 4
+    bm = BlockManager(16, bs)
+    a = seq(list(range(10, 21)), block_size=bs)           # 11 tokens: 2 full blocks + 3
+    b = seq(list(range(10, 18)) + [7, 7, 7], block_size=bs)  # shares the 2 full blocks
+    c = seq(list(range(10, 18)), block_size=bs)           # exactly the 2 shared blocks
+    for s_ in (a, b, c):
+        bm.allocate(s_)
+    assert (a.num_prefix_tokens, b.num_prefix_tokens, c.num_prefix_tokens) == (0, 8, 8)
+    assert b.block_table[:2] == a.block_table[:2] == c.block_table
+    full = batch_meta.prefill_meta([a, b, c], bs)
+    m = batch_meta.prefill_meta([a, b, c], bs, skip_cached=True)
+    assert m.cu_seqlens_q.tolist() == [0, 11, 14, 15] and m.cu_seqlens_k.tolist() == [0, 11, 22, 30]
+    assert m.kv_lens.tolist() == [11, 11, 8] and (m.max_seqlen_q, m.max_seqlen_k) == (11, 11)
+    assert m.input_ids.tolist() == a.token_ids + [7, 7, 7] + [17]
+    assert m.positions.tolist() == list(range(11)) + [8, 9, 10] + [7]
+    assert m.slot_mapping[:11].tolist() == full.slot_mapping[:11].tolist()
+    assert m.slot_mapping[11:14].tolist() == full.slot_mapping[11 + 8:22].tolist()
+    assert m.slot_mapping[14:].tolist() == [-1]
+    assert (m.block_tables == full.block_tables).all()
+    # the reference's reporting counter keeps growing over a preemption; the prefix count does not
+    bm.deallocate(b)
+    assert b.num_prefix_tokens == 0
+    bm.allocate(b)
+    assert b.num_prefix_tokens == 8 and b.num_cached_tokens == 16
