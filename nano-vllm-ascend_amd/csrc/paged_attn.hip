@@ -187,11 +187,12 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
   const int ctx = max(ctx_lens[b], 0);
   const int n_tiles = (ctx + 15) >> 4;
-  // tiles per wave (equal for every wave of every split), this workgroup's and this wave's run
-  const int tpw = (n_tiles + WAVES * splits - 1) / (WAVES * splits);
-  const int wg_t0 = split * WAVES * tpw;
+  // the context is cut into chunks of two 16-token tiles (only the very last chunk may hold one);
+  // the chunks are dealt to the WAVES*splits waves as evenly as possible, each wave a contiguous run
+  const int n_chunks = (n_tiles + 1) >> 1, n_waves = WAVES * splits;
+  const int wg_c0 = split * WAVES * n_chunks / n_waves, wg_c1 = (split + 1) * WAVES * n_chunks / n_waves;
   const int64_t row0 = (int64_t)b * n_q_heads + h * G;  // first q head of this kv head
-  if (wg_t0 >= n_tiles) {  // uniform for the workgroup: nothing to attend in this split
+  if (wg_c0 >= wg_c1) {  // uniform for the workgroup: nothing to attend in this split
     if (splits == 1) {     // empty context (graph padding row): the output row is zero
       for (int idx = threadIdx.x; idx < G * 64; idx += WAVES * 64)
         *reinterpret_cast<uint32_t*>(out + row0 * 128 + 2 * idx) = 0u;
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, n = lane & 15;
   const int32_t* table_row = block_table + (int64_t)b * table_stride;
-  const int t0 = wg_t0 + wave * tpw, t1 = min(n_tiles, t0 + tpw);
+  const int vw = split * WAVES + wave;
+  const int t0 = 2 * (vw * n_chunks / n_waves), t1 = min(n_tiles, 2 * ((vw + 1) * n_chunks / n_waves));
 
   float m = -INFINITY, l = 0.f;
   f32x4 acc[8];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     }
   }
   __syncthreads();
-  // merge the waves (wave 0 always has a tile, so M is finite)
+  // merge the waves (at least one of them had a chunk, so M is finite; empty ones weigh exp2(-inf) = 0)
   for (int idx = threadIdx.x; idx < G * 128; idx += WAVES * 64) {
     const int hn = idx >> 7, d = idx & 127;
     float M = sm_m[0][hn];
