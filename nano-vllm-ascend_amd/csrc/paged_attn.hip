@@ -115,39 +115,6 @@ __host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb) {
   return KvStrides{(int64_t)n_kv_heads * tpb * MI_KV_TILE_ELEMS, (int64_t)tpb * MI_KV_TILE_ELEMS, MI_KV_TILE_ELEMS};
 }
 
-// Issue the 16 fragment loads of chunk `c` (tiles 2c, 2c+1).  `c` and the table row are
-// wave-uniform, so the two block ids come from scalar loads and all vector loads are issued
-// back to back with no wait in between.  A second tile past the end of the context is
-// redirected to the (valid) first tile; its scores are masked by `limit`, so its bytes never
-// reach the output (p == 0 exactly) and no branch or zero-fill is needed.
-__device__ __forceinline__ void load_chunk(const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
-                                           const int32_t* __restrict__ table_row, int c, int n_tiles, int h,
-                                           KvStrides st, int tpb, int lane, u32x4 (&K0)[4], u32x4 (&K1)[4],
-                                           u32x4 (&V0)[4], u32x4 (&V1)[4]) {
-  const int tile0 = 2 * c;
-  const int tile1 = (2 * c + 1 < n_tiles) ? 2 * c + 1 : tile0;
-  const int blk0 = table_row[tile0 / tpb];
-  const int blk1 = table_row[tile1 / tpb];
-  const int64_t base0 = (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(tile0 % tpb) * st.tile;
-  const int64_t base1 = (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(tile1 % tpb) * st.tile;
-  load_tile(kc + base0, lane, K0);
-  load_tile(kc + base1, lane, K1);
-  load_tile(vc + base0, lane, V0);
-  load_tile(vc + base1, lane, V1);
-}
-
-// one cache (K or V) of chunk `c`: 8 fragment loads
-__device__ __forceinline__ void load_chunk_k(const uint16_t* __restrict__ cache, const int32_t* __restrict__ table_row,
-                                             int c, int n_tiles, int h, KvStrides st, int tpb, int lane,
-                                             u32x4 (&T0)[4], u32x4 (&T1)[4]) {
-  const int tile0 = 2 * c;
-  const int tile1 = (2 * c + 1 < n_tiles) ? 2 * c + 1 : tile0;
-  const int blk0 = table_row[tile0 / tpb];
-  const int blk1 = table_row[tile1 / tpb];
-  load_tile(cache + (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(tile0 % tpb) * st.tile, lane, T0);
-  load_tile(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(tile1 % tpb) * st.tile, lane, T1);
-}
-
 // ---------------------------------------------------------------------------
 // decode: grid (splits, n_kv_heads, batch), WAVES wavefronts per workgroup
 //
@@ -312,35 +279,73 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------
-// prefill: grid (ceil(max_q / (8 * 16/G)), n_kv_heads, n_seqs), 8 waves
+// prefill: grid ceil(max_q / (4 * 32/G)) * n_kv_heads * n_seqs (XCD-aware order), 4 waves
 //
-// A workgroup owns 8 consecutive query blocks of one (sequence, kv head) - 128 MFMA columns, i.e.
-// 128/G query tokens x G heads - and walks the sequence's KV chunks once: every 32-token chunk
-// (K0|K1|V0|V1 = 16 KiB, already in MFMA-fragment order in the paged cache) is fetched from
-// HBM/L2 ONCE per workgroup by all 512 threads (two coalesced 16-byte loads each) into a
-// double-buffered LDS image and read back by each wave as lane-linear ds_read_b128 fragments
-// (conflict-free).  Compared with one wave fetching its own chunk copies this cuts L2 traffic 8x and
-// makes the loop MFMA-bound.  Chunk c+1 is in flight in registers while chunk c is computed; one
-// barrier per chunk.  Waves whose query block lies beyond the chunk (causal) skip the math only.
+// A workgroup owns 128 MFMA columns of one (sequence, kv head) - 128/G consecutive query tokens
+// x G heads, 32 columns per wave - and walks the sequence's KV chunks once.  Every 32-token chunk
+// (K0|K1|V0|V1 = 16 KiB of cache tiles) is fetched from HBM/L2 ONCE per workgroup by its 256
+// threads (four coalesced 16-byte loads each) into a double-buffered LDS image; chunk c+1 is in
+// flight in registers while chunk c is computed, one barrier per chunk.
+//
+// The math runs on v_mfma_f32_32x32x16_bf16 in the "swapped" form, keys on the M axis:
+//   S^T[32 keys][32 cols] = K . Q^T      (8 MFMAs over the 128 dims; the A operand is a
+//                                         ds_read_b128 of the cache tile as it is stored)
+//   O^T[128 dims][32 cols] += V^T . P^T  (4 dim blocks x 2 key steps; the A operand is two
+//                                         ds_read_b64 of the token-transposed V tile as stored)
+// so a lane holds, for ITS column, 16 of the chunk's 32 scores (the other 16 sit in lane^32):
+// the running max needs 15 in-lane fmax and ONE cross-lane exchange (v_permlane32_swap), the
+// running sum none until the end.  The contraction index of the second product is a key slot;
+// V's 8-byte pieces are picked so that slot order equals the order in which the scores already
+// sit in the lane's registers - P goes from the score registers into the B operand with no lane
+// movement at all.  P is split into bf16 hi + lo (two MFMAs) as in decode.
+// Four-wave workgroups leave two (independent, differently phased) workgroups per CU, so one
+// workgroup's softmax VALU work overlaps the other's MFMA phases.
+// The finished O tile is transposed through the (now idle) LDS stage and stored as whole rows.
 // ---------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(512) void paged_attn_prefill_kernel(
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// P as bf16 hi + lo (two MFMAs per product, fp32-softmax accuracy as in decode).  -DMI_PREFILL_SPLIT_P=0
+// drops the lo part: 118 vs 144 us at 16 x 1024 tokens, output error up to ~1.5 bf16 ulp instead of 0.5.
+#ifndef MI_PREFILL_SPLIT_P
+#define MI_PREFILL_SPLIT_P 1
+#endif
+
+// swap the upper half of `x` with the lower half of a copy: both halves then see (own, partner)
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int G, bool SPLIT_P>
+__global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ kv_lens, uint16_t* __restrict__ out,
-    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e) {
-  constexpr int TQ = 16 / G;        // query tokens per wave
-  constexpr int TQ_WG = 8 * TQ;     // per workgroup
-  __shared__ __attribute__((aligned(16))) uint16_t stage[2][4][2048];  // [buffer][K0,K1,V0,V1][tile]
+    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e, int n_qblocks, int n_pairs) {
+  constexpr int TQ = 32 / G;        // query tokens per wave
+  constexpr int TQ_WG = 4 * TQ;     // per workgroup
+  constexpr int NBUF = 3;           // LDS ring: chunk c is computed while c+1 and c+2 are landing
+  __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][4][2048];  // [buffer][K0,K1,V0,V1][tile]
 
-  const int seq = blockIdx.z, h = blockIdx.y;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All query blocks of one
+  // (sequence, kv head) re-read the same K/V tiles, so they are given ids that are equal mod 8:
+  // the pair's K/V (2 x 256 KiB per 1024 tokens) is then served by ONE XCD's L2 instead of being
+  // pulled into all eight.  id = ((pair / 8) * n_qblocks + qblock) * 8 + pair % 8.
+  const int pair = ((int)blockIdx.x / (8 * n_qblocks)) * 8 + ((int)blockIdx.x & 7);
+  const int qblock = ((int)blockIdx.x >> 3) % n_qblocks;
+  if (pair >= n_pairs) return;
+  const int seq = pair / n_kv_heads, h = pair % n_kv_heads;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, n = lane & 15;
+  const int hi = lane >> 5, n = lane & 31;
   const int q_start = cu_q[seq];
   const int q_len = cu_q[seq + 1] - q_start;
   const int kv_len = kv_lens[seq];
   // heaviest (latest) query blocks are dispatched first
-  const int wg_qt0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * TQ_WG;
+  const int wg_qt0 = (n_qblocks - 1 - qblock) * TQ_WG;
   if (wg_qt0 >= q_len) return;  // uniform for the workgroup
   const int shift = kv_len - q_len;
   const int wg_last_pos = shift + min(wg_qt0 + TQ_WG, q_len) - 1;
@@ -350,78 +355,150 @@ __global__ __launch_bounds__(512) void paged_attn_prefill_kernel(
   const bool wave_on = qt0 < q_len;
   const int my_qt = qt0 + n / G, hn = n % G;
   const bool valid = wave_on && my_qt < q_len;
-  const int limit = valid ? shift + my_qt + 1 : 1;
+  const int limit = valid ? shift + my_qt + 1 : 1;  // keys [0, limit) are visible to this lane's column
   const int wave_chunks = wave_on ? (shift + min(qt0 + TQ, q_len) - 1 + 32) >> 5 : 0;
   const int limit_all = wave_on && qt0 + TQ <= q_len ? shift + qt0 + 1 : 0;  // earliest column of a full block
 
-  bf16x8 Q[4];
+  bf16x8 Q[8];  // B operand of S^T = K . Q^T: column n, dims 16 kk + 8 hi .. +7
   {
     const int row = valid ? my_qt : wg_qt0;  // invalid columns read a valid row and are zeroed
-    const uint16_t* qp = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * g;
+    const uint16_t* qp = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * hi;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 32 * kk);
+    for (int kk = 0; kk < 8; ++kk) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * kk);
       if (!valid) v = u32x4{0, 0, 0, 0};
       Q[kk] = as_frag(v);
     }
   }
-  float m = -INFINITY, l = 0.f;
-  f32x4 acc[8];
+  float m = -INFINITY, l = 0.f;  // running max (log2 domain) and this lane's share of the running sum
+  f32x16 acc[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  // cooperative fetch: thread t moves bytes [16 t', 16 t'+16) and +2 KiB of piece t / 128
+  // cooperative fetch by LDS-DMA (global_load_lds_dwordx4): piece = wave (K0, K1, V0, V1), four
+  // 1 KiB rows of the 4 KiB cache tile per wave, each lane's 16 bytes landing at row + 16 * lane -
+  // the cache tile is copied as it is stored, no registers and no ds_write involved
   const int32_t* table_row = block_table + (int64_t)seq * table_stride;
   const KvStrides st = default_strides(n_kv_heads, tpb);
-  const int piece = threadIdx.x >> 7;            // 0 K0, 1 K1, 2 V0, 3 V1
-  const int within = (threadIdx.x & 127) * 8;    // element offset of this thread's first 16 bytes
-  auto fetch = [&](int c, u32x4& r0, u32x4& r1) {
+  const int piece = wave;
+  auto issue = [&](int c) {
+    c = min(c, wg_chunks - 1);  // past the end: re-load the last chunk into a buffer nobody reads (keeps vmcnt uniform)
     const int tile0 = 2 * c;
     const int tile = (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
     const int blk = table_row[tile / tpb];
     const uint16_t* src = ((piece & 2) ? vc : kc) + (int64_t)blk * st.block + (int64_t)h * st.head +
-                          (int64_t)(tile % tpb) * st.tile + within;
-    r0 = *reinterpret_cast<const u32x4*>(src);
-    r1 = *reinterpret_cast<const u32x4*>(src + 1024);
-  };
-  auto stash = [&](int buf, const u32x4& r0, const u32x4& r1) {
-    *reinterpret_cast<u32x4*>(&stage[buf][piece][within]) = r0;
-    *reinterpret_cast<u32x4*>(&stage[buf][piece][within + 1024]) = r1;
+                          (int64_t)(tile % tpb) * st.tile + lane * 8;
+    uint16_t* dst = &stage[c % NBUF][piece][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
+                                       (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
   };
 
-  u32x4 r0, r1;
-  fetch(0, r0, r1);
-  stash(0, r0, r1);
-  __syncthreads();
+  // LDS element offsets of this lane's operand pieces inside a tile
+  //   K (A of the first product): key n (tile n / 16, token n % 16), dims 16 kk + 8 hi .. +7
+  const int k_off = (hi * 16 + (n & 15)) * 8;                  // + (kk / 2) * 512 + (kk % 2) * 256
+  //   V (A of the second): dim 32 db + n, key slots {4 hi .. +3} and {8 + 4 hi .. +3} of tile s
+  const int v_off = (hi * 16 + (n & 15)) * 8 + (n >> 4) * 4;   // + db * 512 (+ 256 for the second piece)
+
+  issue(0);
+  issue(1);
   for (int c = 0; c < wg_chunks; ++c) {
-    const bool more = c + 1 < wg_chunks;
-    if (more) fetch(c + 1, r0, r1);  // in flight during this chunk's math
+    // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
+    // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    issue(c + 2);
     if (c < wave_chunks) {
-      const int buf = c & 1;
-      u32x4 K0[4], K1[4], V0[4], V1[4];
+      const int buf = c % NBUF;
+      const uint16_t* kt = &stage[buf][n >> 4][k_off];
+      f32x16 s;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        K0[i] = *reinterpret_cast<const u32x4*>(&stage[buf][0][i * 512 + lane * 8]);
-        K1[i] = *reinterpret_cast<const u32x4*>(&stage[buf][1][i * 512 + lane * 8]);
-        V0[i] = *reinterpret_cast<const u32x4*>(&stage[buf][2][i * 512 + lane * 8]);
-        V1[i] = *reinterpret_cast<const u32x4*>(&stage[buf][3][i * 512 + lane * 8]);
+      for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(kt + (kk >> 1) * 512 + (kk & 1) * 256);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), Q[kk], s, 0, 0, 0);
       }
-      attend_chunk(K0, K1, V0, V1, Q, c * 32, limit, limit_all, scale_log2e, g, m, l, acc);
-    }
-    if (more) stash((c + 1) & 1, r0, r1);
-    __syncthreads();
-  }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  if (!valid) return;
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  uint16_t* op = out + ((int64_t)(q_start + my_qt) * n_q_heads + h * G + hn) * 128 + 4 * g;
+      // register i of this lane: key c*32 + (i & 3) + 8 (i >> 2) + 4 hi
+      const int tok0 = c * 32 + 4 * hi;
+      if (tok0 - 4 * hi + 32 > limit_all) {  // wave-uniform: some column does not see the whole chunk
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    u32x2 o;
-    o[0] = pack_bf(acc[j][0] * inv, acc[j][1] * inv);
-    o[1] = pack_bf(acc[j][2] * inv, acc[j][3] * inv);
-    *reinterpret_cast<u32x2*>(op + 16 * j) = o;
+        for (int i = 0; i < 16; ++i)
+          if (tok0 + (i & 3) + 8 * (i >> 2) >= limit) s[i] = -INFINITY;
+      }
+      float mc = s[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mc = fmaxf(mc, s[i]);
+      mc = xor32_max(mc) * scale_log2e;  // scale > 0: the max commutes with it
+      const float mn = fmaxf(m, mc);     // finite from chunk 0 on: key 0 is visible to every column
+      if (__any(mn != m)) {  // some column's running maximum moved: rescale (rare after the first chunks)
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        l *= alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[j][i] *= alpha;
+        m = mn;
+      }
+      float p[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], scale_log2e, -m));
+        l += p[i];
+      }
+      u32x4 ph[2], pl[2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t hw = pack_bf(p[2 * i], p[2 * i + 1]);
+        ph[i >> 2][i & 3] = hw;
+        if (SPLIT_P) pl[i >> 2][i & 3] = pack_bf(p[2 * i] - lo_bf(hw), p[2 * i + 1] - hi_bf(hw));
+      }
+#pragma unroll
+      for (int sgm = 0; sgm < 2; ++sgm) {
+        const uint16_t* vt = &stage[buf][2 + sgm][v_off];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vt + db * 512);
+          const u32x2 a1 = *reinterpret_cast<const u32x2*>(vt + db * 512 + 256);
+          const u32x4 a = {a0[0], a0[1], a1[0], a1[1]};
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(ph[sgm]), acc[db], 0, 0, 0);
+          if (SPLIT_P)
+            acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(pl[sgm]), acc[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two padding loads
+  __syncthreads();
+  l = xor32_sum(l);
+  // O^T -> rows: each wave transposes its [128 dims][32 cols] tile through its 8 KiB quarter of the
+  // stage (all reads of the last chunk are behind the final barrier).  Column n's 256-byte row is
+  // XOR-swizzled in 8-byte pieces so that the 32 lanes of a write hit 32 different bank pairs.
+  uint16_t* tile = &stage[0][0][0] + wave * 4096;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int piece8 = db * 8 + i4 * 2 + hi;  // dims 4 piece8 .. +3  (= 32 db + 8 i4 + 4 hi)
+      u32x2 o;
+      o[0] = pack_bf(acc[db][4 * i4] * inv, acc[db][4 * i4 + 1] * inv);
+      o[1] = pack_bf(acc[db][4 * i4 + 2] * inv, acc[db][4 * i4 + 3] * inv);
+      *reinterpret_cast<u32x2*>(tile + n * 128 + ((piece8 ^ n) & 31) * 4) = o;
+    }
+  // same wave wrote and reads: LDS operations of a wave complete in order
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int col = it * 4 + (lane >> 4), d16 = lane & 15;  // 16 lanes store one 256-byte row
+    const int qt = qt0 + col / G;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + col * 128 + (((2 * d16) ^ col) & 31) * 4);
+    const u32x2 hh = *reinterpret_cast<const u32x2*>(tile + col * 128 + (((2 * d16 + 1) ^ col) & 31) * 4);
+    if (wave_on && qt < q_len) {
+      uint16_t* op = out + ((int64_t)(q_start + qt) * n_q_heads + h * G + col % G) * 128 + 8 * d16;
+      *reinterpret_cast<u32x4*>(op) = u32x4{lo[0], lo[1], hh[0], hh[1]};
+    }
   }
 }
 
@@ -534,14 +611,16 @@ extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, con
   if (!aligned16(out)) return MI_EINVAL;
   if (n_seqs == 0 || max_seqlen_q == 0) return MI_OK;
   const int G = n_q_heads / n_kv_heads;
-  const int tq_wg = 8 * (16 / G);  // query tokens per workgroup
-  const dim3 grid((max_seqlen_q + tq_wg - 1) / tq_wg, n_kv_heads, n_seqs);
+  const int tq_wg = 4 * (32 / G);  // query tokens per workgroup
+  const int n_qblocks = (max_seqlen_q + tq_wg - 1) / tq_wg, n_pairs = n_seqs * n_kv_heads;
+  const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8 * n_qblocks));
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = S(stream);
+  constexpr bool kSplitP = MI_PREFILL_SPLIT_P;
 #define LAUNCH_PRE(GG)                                                                                       \
-  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG>), grid, dim3(512), 0, st, q, q_row_stride, k_cache,      \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,      \
                      v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads, n_kv_heads, \
-                     block_size / 16, sl2)
+                     block_size / 16, sl2, n_qblocks, n_pairs)
   switch (G) {
     case 1: LAUNCH_PRE(1); break;
     case 2: LAUNCH_PRE(2); break;
