@@ -5,6 +5,7 @@ from the reference CODE where its tests disagree with it (three u
 from types import SimpleNamespace
 
 import numpy as np
+import torch
 import pytest
 
 from nanovllm.config import Config
@@ -315,3 +316,43 @@ def test_prefill_meta_skipping_cached_prefix_blocks():
     assert b.num_prefix_tokens == 0
     bm.allocate(b)
     assert b.num_prefix_tokens == 8 and b.num_cached_tokens == 16
+
+
+@pytest.mark.parametrize("tied", [True, False])
+def test_safetensors_checkpoint_lands_in_the_packed_parameters(tmp_path, tied):
+    """utils/loader.py:12-59 with qwen3.py:189-195's packed_modules_mapping: a HF Qwen3 checkpoint
+    written by transformers (safetensors) must land bit-equal in qkv_proj (rows q|k|v), gate_up_proj
+    (gate|up), the norms and the (tied or separate) head."""
+    from transformers import Qwen3Config
+    from transformers import Qwen3ForCausalLM as HfQwen3
+
+    from model_configs import TINY
+    from nanovllm.models.qwen3 import Qwen3ForCausalLM
+    from nanovllm.utils.loader import has_checkpoint, load_model
+
+    cfg = Qwen3Config(**{k: v for k, v in dict(TINY, tie_word_embeddings=tied).items()
+                         if k not in ("architectures", "model_type", "torch_dtype")})
+    torch.manual_seed(0)
+    hf = HfQwen3(cfg).to(torch.bfloat16)
+    hf.save_pretrained(str(tmp_path), safe_serialization=True)
+    assert has_checkpoint(str(tmp_path))
+    model = Qwen3ForCausalLM(cfg)
+    load_model(model, str(tmp_path))
+    sd = hf.state_dict()
+    for i, layer in enumerate(model.model.layers):
+        p = f"model.layers.{i}."
+        attn, mlp = layer.self_attn, layer.mlp
+        assert torch.equal(attn.qkv_proj.weight, torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"]))
+        assert torch.equal(mlp.gate_up_proj.weight,
+                           torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]]))
+        assert torch.equal(attn.o_proj.weight, sd[p + "self_attn.o_proj.weight"])
+        assert torch.equal(mlp.down_proj.weight, sd[p + "mlp.down_proj.weight"])
+        assert torch.equal(attn.q_norm.weight, sd[p + "self_attn.q_norm.weight"])
+        assert torch.equal(attn.k_norm.weight, sd[p + "self_attn.k_norm.weight"])
+        assert torch.equal(layer.input_layernorm.weight, sd[p + "input_layernorm.weight"])
+        assert torch.equal(layer.post_attention_layernorm.weight, sd[p + "post_attention_layernorm.weight"])
+    assert torch.equal(model.model.norm.weight, sd["model.norm.weight"])
+    assert torch.equal(model.model.embed_tokens.weight, sd["model.embed_tokens.weight"])
+    shared = model.lm_head.weight.data_ptr() == model.model.embed_tokens.weight.data_ptr()
+    assert shared == tied  # qwen3.py:204-205
+    assert torch.equal(model.lm_head.weight, sd["lm_head.weight"])
