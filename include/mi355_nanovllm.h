@@ -51,7 +51,8 @@ enum {
   MI_EINVAL        = -1, /* bad argument (null pointer, negative size, misaligned) */
   MI_EUNSUPPORTED  = -2, /* shape outside what the kernels are built for          */
   MI_EWORKSPACE    = -3, /* workspace too small                                   */
-  MI_ELAUNCH       = -4  /* hipLaunchKernel reported an error                     */
+  MI_ELAUNCH       = -4, /* hipLaunchKernel reported an error                     */
+  MI_ERUNTIME      = -5  /* a HIP runtime call (allocation, IPC) failed           */
 };
 
 #define MI_HEAD_DIM        128  /* the only head_dim compiled (all Qwen3 sizes)   */
@@ -249,6 +250,41 @@ int mi_argmax(const mi_bf16* logits, int64_t row_stride, int64_t* out,
 int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatures,
               int64_t* out, int rows, int vocab, uint64_t seed, uint64_t step,
               mi_stream stream);
+
+/* ---- tensor-parallel exchange over xGMI -----------------------------------
+ * Stands in for the HCCL all-reduce after every row-parallel projection and the
+ * vocab-parallel embedding (linear.py:152-153, embed_head.py:41-42).  One process
+ * per GPU; each rank owns one exchange REGION of uncached device memory that its
+ * peers map through HIP IPC.  A SUM all-reduce of <= max_bytes is ONE kernel:
+ * every workgroup pushes its slice of the local vector into slot [rank] of every
+ * peer's region (xGMI is point-to-point: 7 direct writes, no ring), publishes a
+ * per-slice epoch flag with a system-scope release, waits for the same slice's
+ * flags of all peers and sums the `world` slots in rank order in fp32 - so every
+ * rank gets bit-identical results and the launch needs no grid-wide sync, no
+ * host interaction, and is hipGraph-capturable (epochs live in device memory and
+ * advance on every launch or replay).  Slots are double-buffered by epoch parity.
+ * The three init-time calls below are the only entry points of this library that
+ * allocate or synchronise. */
+typedef struct mi_comm mi_comm;
+#define MI_COMM_MAX_WORLD   8
+#define MI_IPC_HANDLE_BYTES 64
+/* Bytes of one rank's region for vectors of up to max_bytes. */
+size_t mi_comm_region_bytes(int world, size_t max_bytes);
+/* Allocate + zero a region (hipExtMallocWithFlags, uncached) and export its IPC handle. */
+int mi_comm_region_alloc(size_t bytes, void** region, void* ipc_handle /*[MI_IPC_HANDLE_BYTES]*/);
+/* Map a peer's region from its IPC handle / unmap / free. */
+int mi_comm_region_open(const void* ipc_handle, void** region);
+int mi_comm_region_close(void* region);
+int mi_comm_region_free(void* region);
+/* regions[world]: regions[rank] is this rank's own allocation, the others are opened peers. */
+int mi_comm_create(int rank, int world, void* const* regions, size_t max_bytes, mi_comm** out);
+int mi_comm_destroy(mi_comm* comm);
+/* out[i] = sum over ranks of in[i]; n bf16 elements, n % 8 == 0, 2n <= max_bytes; in == out allowed.
+ * Every rank must issue the same sequence of calls.  A peer that does not show up within ~2 s
+ * raises the communicator's sticky timeout flag instead of hanging the GPU. */
+int mi_allreduce_sum_bf16(mi_comm* comm, const mi_bf16* in, mi_bf16* out, int64_t n, mi_stream stream);
+/* Copies the sticky timeout flag to *timed_out (synchronises the device). */
+int mi_comm_status(mi_comm* comm, int* timed_out);
 
 /* ---- host-side hashing (reference: engine/block_manager.py:38-44) --------- */
 /* xxh64 of `len` bytes with seed 0, optionally prefixed by the 8 little-endian

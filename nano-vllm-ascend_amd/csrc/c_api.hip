@@ -24,6 +24,7 @@ extern "C" const char* mi_strerror(int code) {
     case MI_EUNSUPPORTED: return "shape not supported by the compiled kernels";
     case MI_EWORKSPACE: return "workspace too small";
     case MI_ELAUNCH: return "kernel launch failed (see mi_last_launch_error)";
+    case MI_ERUNTIME: return "HIP runtime call failed (allocation / IPC)";
     default: return "unknown error code";
   }
 }

@@ -81,6 +81,15 @@ _SIGNATURES = {
     "mi_argmax": (c_int, [_p, c_int64, _p, c_int, c_int, _p]),
     "mi_sample": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_uint64, c_uint64, _p]),
     "mi_xxh64_chain": (c_uint64, [_p, c_size_t, c_int, c_uint64]),
+    "mi_comm_region_bytes": (c_size_t, [c_int, c_size_t]),
+    "mi_comm_region_alloc": (c_int, [c_size_t, ctypes.POINTER(_p), _p]),
+    "mi_comm_region_open": (c_int, [_p, ctypes.POINTER(_p)]),
+    "mi_comm_region_close": (c_int, [_p]),
+    "mi_comm_region_free": (c_int, [_p]),
+    "mi_comm_create": (c_int, [c_int, c_int, ctypes.POINTER(_p), c_size_t, ctypes.POINTER(_p)]),
+    "mi_comm_destroy": (c_int, [_p]),
+    "mi_allreduce_sum_bf16": (c_int, [_p, _p, _p, c_int64, _p]),
+    "mi_comm_status": (c_int, [_p, ctypes.POINTER(c_int)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -76,6 +76,14 @@ class ModelRunner:
             dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{config.hccl_port}",
                                     world_size=self.world_size, rank=rank, **kw)
         self.channel = StepChannel(config.hccl_port, self.world_size, rank) if self.world_size > 1 else None
+        self.xgmi = None
+        if self.world_size > 1:
+            from nanovllm.layers import parallel, xgmi_comm
+
+            rows = max(64, min(config.max_num_seqs, 512))  # decode-sized activations; prefill goes through RCCL
+            self.xgmi = xgmi_comm.create_if_enabled(rank, self.world_size, rows * self.hf_config.hidden_size * 2,
+                                                    self.device)
+            parallel.set_xgmi_comm(self.xgmi)
 
         dtype = _torch_dtype_of(self.hf_config)
         if dtype != torch.bfloat16:
@@ -123,6 +131,12 @@ class ModelRunner:
         if self.channel is not None:
             dist.barrier()
             self.channel.close()
+        if self.xgmi is not None:
+            from nanovllm.layers import parallel
+
+            parallel.set_xgmi_comm(None)
+            self.xgmi.close()
+            self.xgmi = None
         if self.world_size > 1 and dist.is_initialized():
             dist.destroy_process_group()
 

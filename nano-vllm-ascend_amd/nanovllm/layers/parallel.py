@@ -22,8 +22,24 @@ def divide(numerator: int, denominator: int) -> int:
     return numerator // denominator
 
 
+_xgmi = None  # layers/xgmi_comm.XgmiComm once the runner has set it up and its self-test passed
+
+
+def set_xgmi_comm(comm) -> None:
+    global _xgmi
+    _xgmi = comm
+
+
+def get_xgmi_comm():
+    return _xgmi
+
+
 def all_reduce_sum(t):
-    """C1/C2 of SURVEY.md §2.2: SUM over the TP ranks, in place."""
+    """C1/C2 of SURVEY.md §2.2: SUM over the TP ranks, in place.  Decode-sized bf16 vectors take
+    the one-shot xGMI kernel (mi_allreduce_sum_bf16, hipGraph-capturable, one launch); everything
+    else (prefill-sized activations) the RCCL all-reduce."""
     if tp_size() > 1:
+        if _xgmi is not None and _xgmi.fits(t):
+            return _xgmi.all_reduce(t)
         dist.all_reduce(t)
     return t

@@ -1,0 +1,134 @@
+"""One-shot SUM all-reduce over xGMI peer mappings (C ABI mi_comm_* / mi_allreduce_sum_bf16),
+the MI355X stand-in for the HCCL all-reduce of linear.py:152-153 and embed_head.py:41-42.
+
+Set-up (once per engine): every rank allocates an uncached exchange region, the 64-byte HIP IPC
+handles travel through the already initialised torch.distributed group, peers map each other's
+regions.  A self-test with integer-valued data (exact sums) decides - collectively - whether the
+path is used; if it fails on any rank, every rank keeps the RCCL all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import warnings
+
+import torch
+import torch.distributed as dist
+
+from nanovllm._C import check, lib, ptr, stream
+
+
+class XgmiComm:
+    def __init__(self, rank: int, world: int, max_bytes: int, device: torch.device):
+        self.rank, self.world, self.max_bytes, self.device = rank, world, int(max_bytes), device
+        self._peers: list[int] = []
+        self._own = ctypes.c_void_p()
+        self._comm = ctypes.c_void_p()
+        nbytes = lib.mi_comm_region_bytes(world, self.max_bytes)
+        handle = ctypes.create_string_buffer(64)
+        check(lib.mi_comm_region_alloc(nbytes, ctypes.byref(self._own), handle), "mi_comm_region_alloc")
+        handles: list = [None] * world
+        dist.all_gather_object(handles, handle.raw)
+        regions = []
+        for r in range(world):
+            if r == rank:
+                regions.append(self._own.value)
+            else:
+                p = ctypes.c_void_p()
+                check(lib.mi_comm_region_open(handles[r], ctypes.byref(p)), "mi_comm_region_open")
+                self._peers.append(p.value)
+                regions.append(p.value)
+        arr = (ctypes.c_void_p * world)(*regions)
+        check(lib.mi_comm_create(rank, world, arr, self.max_bytes, ctypes.byref(self._comm)), "mi_comm_create")
+        dist.barrier()  # every rank has mapped every region before the first push
+
+    def fits(self, t: torch.Tensor) -> bool:
+        return (t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous() and t.numel() % 8 == 0
+                and 0 < t.numel() * 2 <= self.max_bytes)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        check(lib.mi_allreduce_sum_bf16(self._comm, ptr(t), ptr(t), t.numel(), stream()), "mi_allreduce_sum_bf16")
+        return t
+
+    def timed_out(self) -> bool:
+        flag = ctypes.c_int(0)
+        check(lib.mi_comm_status(self._comm, ctypes.byref(flag)), "mi_comm_status")
+        return bool(flag.value)
+
+    def self_test(self) -> bool:
+        """Integer-valued inputs: the fp32 sum and its bf16 rounding are exact, so the expected
+        result is known without a second collective.  Covers the smallest and the largest vector,
+        consecutive launches (both epoch parities) and replay from a captured graph."""
+        ok = True
+        try:
+            for n in (8, 4096, self.max_bytes // 2):
+                idx = torch.arange(n, device=self.device, dtype=torch.int64)
+                for it in range(3):
+                    x = (((idx * 7 + (self.rank + it) * 3) % 17) - 8).to(torch.bfloat16)
+                    want = sum((((idx * 7 + (r + it) * 3) % 17) - 8) for r in range(self.world)).to(torch.bfloat16)
+                    self.all_reduce(x)
+                    ok = ok and bool(torch.equal(x, want))
+            idx = torch.arange(4096, device=self.device, dtype=torch.int64)
+            src = ((idx * 5 + self.rank) % 13 - 6).to(torch.bfloat16)
+            want = sum(((idx * 5 + r) % 13 - 6) for r in range(self.world)).to(torch.bfloat16)
+            buf = torch.empty_like(src)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                buf.copy_(src)
+                self.all_reduce(buf)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(3):  # three dependent launches per replay
+                    buf.copy_(src)
+                    self.all_reduce(buf)
+            for _ in range(2):
+                graph.replay()
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(buf, want))
+            ok = ok and not self.timed_out()
+        except Exception as e:  # noqa: BLE001 - any failure means "do not use this path"
+            warnings.warn(f"xGMI all-reduce self-test raised {e!r}")
+            ok = False
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                               device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        return bool(verdict.item())
+
+    def close(self) -> None:
+        if self._comm:
+            lib.mi_comm_destroy(self._comm)
+            self._comm = ctypes.c_void_p()
+        for p in self._peers:
+            lib.mi_comm_region_close(ctypes.c_void_p(p))
+        self._peers = []
+        if self._own:
+            lib.mi_comm_region_free(self._own)
+            self._own = ctypes.c_void_p()
+
+
+def create_if_enabled(rank: int, world: int, max_bytes: int, device: torch.device) -> XgmiComm | None:
+    """None when disabled by MI355_XGMI_ALLREDUCE=0, when set-up fails or when the self-test fails."""
+    if world < 2 or world > 8 or os.environ.get("MI355_XGMI_ALLREDUCE", "1") == "0":
+        return None
+    comm = None
+    try:
+        comm = XgmiComm(rank, world, max_bytes, device)
+        made = True
+    except Exception as e:  # noqa: BLE001
+        warnings.warn(f"xGMI all-reduce set-up failed ({e!r}); using the RCCL all-reduce")
+        made = False
+    agree = torch.tensor([1 if made else 0], dtype=torch.int32,
+                         device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    if not agree.item():
+        if comm is not None:
+            comm.close()
+        return None
+    if not comm.self_test():
+        if rank == 0:
+            warnings.warn("xGMI all-reduce self-test failed; using the RCCL all-reduce")
+        comm.close()
+        return None
+    return comm

@@ -171,6 +171,8 @@ def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch):
                   max_model_len=512, num_kvcache_blocks=64, enforce_eager=True, warmup=False, synthetic_seed=3,
                   tensor_parallel_size=tp, hccl_port=port)
         try:
+            if tp > 1:  # the decode-sized all-reduces go through the xGMI kernel (self-test passed at start-up)
+                assert llm.model_runner.xgmi is not None
             outs = llm.generate(prompts, sp, use_tqdm=False)
             return [o["token_ids"] for o in outs], llm.model_runner.last_logits.float().cpu()
         finally:

@@ -1,0 +1,72 @@
+"""mi_allreduce_sum_bf16 with several rank processes sharing cuda:0: HIP IPC mapping of the exchange
+regions, the per-slice flag protocol, both epoch parities, replay from a hipGraph.  (One GPU cannot
+show cross-device cache behaviour; the engine therefore re-runs XgmiComm.self_test on the real
+topology at start-up and falls back to RCCL when it fails.)"""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    from nanovllm.layers.xgmi_comm import XgmiComm
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = XgmiComm(rank, world, 1 << 20, dev)
+    try:
+        ok = comm.self_test()
+        # random values: the kernel sums the bf16 inputs in fp32 in rank order, one rounding at the end
+        g = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(32 * 1024, generator=g).bfloat16()
+        everyone = [None] * world
+        dist.all_gather_object(everyone, x)
+        acc = torch.zeros_like(x, dtype=torch.float32)
+        for t in everyone:
+            acc += t.float()
+        want = acc.bfloat16()
+        y = x.to(dev)
+        exact = True
+        for _ in range(5):  # alternating parities, same input
+            z = y.clone()
+            comm.all_reduce(z)
+            exact = exact and bool(torch.equal(z.cpu(), want))
+        out.put((rank, ok, exact, comm.timed_out()))
+    finally:
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_allreduce_ranks_sharing_one_gpu(world):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        for _ in range(world):
+            results.append(out.get(timeout=180))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    assert len(results) == world
+    for rank, ok, exact, timed_out in sorted(results):
+        assert ok, f"rank {rank}: self-test failed"
+        assert exact, f"rank {rank}: sum differs from the rank-ordered fp32 sum"
+        assert not timed_out, f"rank {rank}: a peer timed out"
