@@ -280,9 +280,19 @@ int mi_comm_region_free(void* region);
 int mi_comm_create(int rank, int world, void* const* regions, size_t max_bytes, mi_comm** out);
 int mi_comm_destroy(mi_comm* comm);
 /* out[i] = sum over ranks of in[i]; n bf16 elements, n % 8 == 0, 2n <= max_bytes; in == out allowed.
- * Every rank must issue the same sequence of calls.  A peer that does not show up within ~2 s
- * raises the communicator's sticky timeout flag instead of hanging the GPU. */
+ * Every rank must issue the same sequence of calls.  A peer that does not show up within about
+ * a minute raises the communicator's sticky timeout flag instead of hanging the GPU. */
 int mi_allreduce_sum_bf16(mi_comm* comm, const mi_bf16* in, mi_bf16* out, int64_t n, mi_stream stream);
+/* mi_allreduce_sum_bf16 over the ranks' x [rows, cols] followed by mi_add_rmsnorm(sum, residual, ...)
+ * in ONE launch (one wave per row: push, flag, wait, sum, add, normalise) - the row-parallel seam of
+ * qwen3.py:118-131 (o_proj / down_proj all-reduce, then the next layer norm).  Bit-identical to the
+ * two-call sequence.  rows <= 64, 512 <= cols <= 8192, cols % 8 == 0. */
+int mi_allreduce_add_rmsnorm(mi_comm* comm, const mi_bf16* x, const mi_bf16* residual,
+                             const mi_bf16* weight, mi_bf16* out, mi_bf16* residual_out,
+                             int rows, int cols, float eps, mi_stream stream);
+/* Polls (~1 us each) a workgroup waits for a peer before it gives up; default 2^26 (about a minute).
+ * Init-time call (synchronises the device). */
+int mi_comm_set_spin_limit(mi_comm* comm, uint32_t polls);
 /* Copies the sticky timeout flag to *timed_out (synchronises the device). */
 int mi_comm_status(mi_comm* comm, int* timed_out);
 

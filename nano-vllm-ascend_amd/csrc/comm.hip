@@ -1,11 +1,15 @@
 // One-shot SUM all-reduce over xGMI peer mappings (see include/mi355_nanovllm.h).
 //
 // Region of one rank (uncached device memory, mapped by every peer through HIP IPC):
-//   [0, 4096)            control: epoch[SLICES] u32, then the sticky timeout flag
-//   [4096, +flag bytes)  flags[parity 2][source rank world][SLICES] u32  (epoch of the last arrival)
+//   [0, 4096)            control: epoch u32, finished-workgroup counter u32, sticky timeout flag u32,
+//                        spin limit u32 (polls before a peer is declared missing)
+//   [4096, +flag bytes)  flags[parity 2][source rank world][MAX_SLICES] u32  (epoch of the last arrival)
 //   [..., +slot bytes)   slots[parity 2][source rank world][max_bytes]
-// A launch has SLICES workgroups; workgroup s owns elements [s*chunk, (s+1)*chunk) of the vector in
-// every phase, so the only cross-GPU dependency is per slice and is carried by flags[.][r][s].
+// A launch cuts the vector into slices (16 element ranges for the plain all-reduce, one row each for
+// the fused add+RMSNorm); workgroup s owns slice s in every phase, so the only cross-GPU dependency
+// is per slice and is carried by flags[.][r][s].  The epoch is one number per communicator: every
+// workgroup reads it when it starts, the last one to finish advances it - launches are stream
+// ordered, so the next launch (or graph replay) sees the new value.
 #include <stdlib.h>
 #include <string.h>
 
@@ -13,9 +17,10 @@
 
 namespace mi {
 
-constexpr int SLICES = 16;
+constexpr int SLICES = 16;       // workgroups of the plain all-reduce
+constexpr int MAX_SLICES = 64;   // flag slots per (parity, source): rows of the fused kernel
 constexpr size_t CTRL_BYTES = 4096;
-constexpr uint32_t SPIN_LIMIT = 1u << 22;  // polls of ~0.5 us each before a peer is declared missing
+constexpr uint32_t DEFAULT_SPIN_LIMIT = 1u << 26;  // polls of ~1 us each: about a minute
 
 struct CommPtrs {
   uint8_t* region[MI_COMM_MAX_WORLD];
@@ -27,58 +32,84 @@ struct Layout {
 static Layout layout(int world, size_t max_bytes) {
   Layout l;
   l.flags_off = CTRL_BYTES;
-  const size_t flag_bytes = ((size_t)2 * world * SLICES * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t flag_bytes = ((size_t)2 * world * MAX_SLICES * sizeof(uint32_t) + 255) / 256 * 256;
   l.slots_off = l.flags_off + flag_bytes;
   l.slot_stride = (max_bytes + 255) / 256 * 256;
   l.total = l.slots_off + (size_t)2 * world * l.slot_stride;
   return l;
 }
 
-__global__ __launch_bounds__(256) void allreduce_kernel(CommPtrs peers, int rank, int world, size_t flags_off,
-                                                        size_t slots_off, size_t slot_stride,
-                                                        const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                        int64_t n) {
+struct CommGeom {
+  CommPtrs peers;
+  int rank, world;
+  size_t flags_off, slots_off, slot_stride;
+};
+
+__device__ __forceinline__ uint32_t comm_epoch(const CommGeom& g) {
+  return *reinterpret_cast<const volatile uint32_t*>(g.peers.region[g.rank]) + 1;
+}
+__device__ __forceinline__ uint8_t* comm_slot(const CommGeom& g, int owner, uint32_t par, int source) {
+  return g.peers.region[owner] + g.slots_off + ((size_t)par * g.world + source) * g.slot_stride;
+}
+// After this workgroup's pushes: make them visible, publish slice `s` to every rank, wait for the same
+// slice of every source.  Lanes 0..world-1 of the first wave do the flag traffic.
+__device__ __forceinline__ void comm_publish_and_wait(const CommGeom& g, uint32_t e, int s, int tid, bool sync) {
+  __threadfence_system();  // the slice is visible at system scope before its flag
+  if (sync) __syncthreads();
+  if (tid < g.world) {
+    const uint32_t par = e & 1u;
+    uint32_t* theirs = reinterpret_cast<uint32_t*>(g.peers.region[tid] + g.flags_off) +
+                       ((size_t)par * g.world + g.rank) * MAX_SLICES + s;
+    __hip_atomic_store(theirs, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t* arrive = reinterpret_cast<const uint32_t*>(g.peers.region[g.rank] + g.flags_off) +
+                             ((size_t)par * g.world + tid) * MAX_SLICES + s;
+    const uint32_t limit = reinterpret_cast<const volatile uint32_t*>(g.peers.region[g.rank])[3];
+    uint32_t spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+      if (++spins > limit) {
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(g.peers.region[g.rank]) + 2, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (sync) __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope: the slot reads below are not served from a stale line
+}
+// One thread per workgroup, after its last slot read: the last workgroup of the launch advances the epoch.
+__device__ __forceinline__ void comm_finish(const CommGeom& g, uint32_t e, int n_workgroups) {
+  uint32_t* ctrl = reinterpret_cast<uint32_t*>(g.peers.region[g.rank]);
+  if (atomicAdd(ctrl + 1, 1u) == (uint32_t)n_workgroups - 1) {
+    ctrl[1] = 0;
+    __hip_atomic_store(ctrl, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void allreduce_kernel(CommGeom g, const uint16_t* __restrict__ in,
+                                                        uint16_t* __restrict__ out, int64_t n) {
   const int s = blockIdx.x, tid = threadIdx.x;
-  uint8_t* mine = peers.region[rank];
-  uint32_t* epoch = reinterpret_cast<uint32_t*>(mine) + s;
-  uint32_t* timeout_flag = reinterpret_cast<uint32_t*>(mine) + SLICES;
-  const uint32_t e = *epoch + 1;  // written only by this workgroup of the previous launch (stream order)
+  const uint32_t e = comm_epoch(g);
   const uint32_t par = e & 1u;
 
   const int64_t vecs = n / 8;  // 16-byte pieces
   const int64_t per = (vecs + SLICES - 1) / SLICES;
   const int64_t v0 = min(vecs, (int64_t)s * per), v1 = min(vecs, v0 + per);
 
-  // (a) push this slice into slot [par][rank] of every rank's region, the farthest peers first
-  for (int k = 1; k <= world; ++k) {
-    const int q = (rank + k) % world;
-    u32x4* dst = reinterpret_cast<u32x4*>(peers.region[q] + slots_off + ((size_t)par * world + rank) * slot_stride);
+  // (a) push this slice into slot [par][rank] of every rank's region, the next-higher rank first
+  for (int k = 1; k <= g.world; ++k) {
+    const int q = (g.rank + k) % g.world;
+    u32x4* dst = reinterpret_cast<u32x4*>(comm_slot(g, q, par, g.rank));
     for (int64_t v = v0 + tid; v < v1; v += 256) dst[v] = reinterpret_cast<const u32x4*>(in)[v];
   }
-  __threadfence_system();  // the slice is visible at system scope before its flag
-  __syncthreads();
-  // (b) publish, (c) wait for the same slice of every source
-  if (tid < world) {
-    uint32_t* theirs = reinterpret_cast<uint32_t*>(peers.region[tid] + flags_off) + ((size_t)par * world + rank) * SLICES + s;
-    __hip_atomic_store(theirs, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t* arrive = reinterpret_cast<const uint32_t*>(mine + flags_off) + ((size_t)par * world + tid) * SLICES + s;
-    uint32_t spins = 0;
-    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-      if (++spins > SPIN_LIMIT) {
-        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  __syncthreads();
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope: later slot reads are not served from a stale cache line
+  // (b) publish, (c) wait
+  comm_publish_and_wait(g, e, s, tid, true);
   // (d) sum the `world` slots in rank order
-  const uint8_t* slots = mine + slots_off + (size_t)par * world * slot_stride;
+  const uint8_t* slots = comm_slot(g, g.rank, par, 0);
   for (int64_t v = v0 + tid; v < v1; v += 256) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < world; ++r) {
-      const u32x4 x = reinterpret_cast<const u32x4*>(slots + (size_t)r * slot_stride)[v];
+    for (int r = 0; r < g.world; ++r) {
+      const u32x4 x = reinterpret_cast<const u32x4*>(slots + (size_t)r * g.slot_stride)[v];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc[2 * i] += lo_bf(x[i]);
@@ -90,7 +121,98 @@ __global__ __launch_bounds__(256) void allreduce_kernel(CommPtrs peers, int rank
     for (int i = 0; i < 4; ++i) y[i] = pack_bf(acc[2 * i], acc[2 * i + 1]);
     reinterpret_cast<u32x4*>(out)[v] = y;
   }
-  if (tid == 0) *epoch = e;
+  __syncthreads();
+  if (tid == 0) comm_finish(g, e, SLICES);
+}
+
+// all-reduce + residual add + RMSNorm in one launch: one wave per token row (decode: <= 64 rows).
+// The row's partial sums are pushed to every rank, summed in rank order in fp32 and rounded to bf16 -
+// exactly what allreduce_kernel leaves in memory - then the row goes through the arithmetic of
+// rmsnorm_kernel<64, VPL, ADD> (elementwise.hip; same operation order, this file is built with
+// -ffp-contract=off as well), so the result is bit-identical to the two-launch sequence.
+template <int VPL>
+__global__ __launch_bounds__(64) void allreduce_add_rmsnorm_kernel(
+    CommGeom g, const uint16_t* __restrict__ x, const uint16_t* __restrict__ residual,
+    const uint16_t* __restrict__ w, uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows,
+    int cols, float eps) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int nvec = cols >> 3;
+  const int64_t off = (int64_t)row * cols;
+  const uint32_t e = comm_epoch(g);
+  const uint32_t par = e & 1u;
+
+  u32x4 mine[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vec = lane + i * 64;
+    if (vec < nvec) mine[i] = *reinterpret_cast<const u32x4*>(x + off + vec * 8);
+  }
+  for (int k = 1; k <= g.world; ++k) {
+    const int q = (g.rank + k) % g.world;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(comm_slot(g, q, par, g.rank)) + off;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vec = lane + i * 64;
+      if (vec < nvec) *reinterpret_cast<u32x4*>(dst + vec * 8) = mine[i];
+    }
+  }
+  comm_publish_and_wait(g, e, row, lane, false);
+
+  const uint8_t* slots = comm_slot(g, g.rank, par, 0);
+  float v[VPL][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vec = lane + i * 64;
+    if (vec < nvec) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < g.world; ++r) {
+        const u32x4 p = *reinterpret_cast<const u32x4*>(
+            reinterpret_cast<const uint16_t*>(slots + (size_t)r * g.slot_stride) + off + vec * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += lo_bf(p[j]);
+          acc[2 * j + 1] += hi_bf(p[j]);
+        }
+      }
+      const u32x4 rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
+      u32x4 ro;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t sum_bf = pack_bf(acc[2 * j], acc[2 * j + 1]);  // the all-reduce's bf16 result
+        const float a = lo_bf(sum_bf) + lo_bf(rr[j]);
+        const float b = hi_bf(sum_bf) + hi_bf(rr[j]);
+        ro[j] = pack_bf(a, b);
+        v[i][2 * j] = a;
+        v[i][2 * j + 1] = b;
+        ss += a * a;
+        ss += b * b;
+      }
+      *reinterpret_cast<u32x4*>(residual_out + off + vec * 8) = ro;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rs = 1.0f / sqrtf(ss / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vec = lane + i * 64;
+    if (vec < nvec) {
+      const u32x4 wr = *reinterpret_cast<const u32x4*>(w + vec * 8);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = rbf(v[i][2 * j] * rs) * lo_bf(wr[j]);
+        const float b = rbf(v[i][2 * j + 1] * rs) * hi_bf(wr[j]);
+        o[j] = pack_bf(a, b);
+      }
+      *reinterpret_cast<u32x4*>(y + off + vec * 8) = o;
+    }
+  }
+  if (lane == 0) comm_finish(g, e, rows);
 }
 
 }  // namespace mi
@@ -102,6 +224,7 @@ struct mi_comm {
   size_t max_bytes;
   Layout lay;
   CommPtrs ptrs;
+  CommGeom geom() const { return CommGeom{ptrs, rank, world, lay.flags_off, lay.slots_off, lay.slot_stride}; }
 };
 
 extern "C" size_t mi_comm_region_bytes(int world, size_t max_bytes) {
@@ -114,6 +237,12 @@ extern "C" int mi_comm_region_alloc(size_t bytes, void** region, void* ipc_handl
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) return MI_ERUNTIME;
   if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(p);
+    return MI_ERUNTIME;
+  }
+  const uint32_t limit = DEFAULT_SPIN_LIMIT;
+  if (hipMemcpy(static_cast<uint8_t*>(p) + 3 * sizeof(uint32_t), &limit, sizeof(limit), hipMemcpyHostToDevice) !=
+      hipSuccess) {
     (void)hipFree(p);
     return MI_ERUNTIME;
   }
@@ -180,15 +309,45 @@ extern "C" int mi_allreduce_sum_bf16(mi_comm* comm, const mi_bf16* in, mi_bf16* 
   if (n % 8 || (size_t)n * 2 > comm->max_bytes) return MI_EUNSUPPORTED;
   if (!aligned16(in) || !aligned16(out)) return MI_EINVAL;
   if (n == 0) return MI_OK;
-  hipLaunchKernelGGL(allreduce_kernel, dim3(SLICES), dim3(256), 0, S(stream), comm->ptrs, comm->rank, comm->world,
-                     comm->lay.flags_off, comm->lay.slots_off, comm->lay.slot_stride, in, out, n);
+  hipLaunchKernelGGL(allreduce_kernel, dim3(SLICES), dim3(256), 0, S(stream), comm->geom(), in, out, n);
   return check_launch();
+}
+
+extern "C" int mi_allreduce_add_rmsnorm(mi_comm* comm, const mi_bf16* x, const mi_bf16* residual,
+                                        const mi_bf16* weight, mi_bf16* out, mi_bf16* residual_out, int rows,
+                                        int cols, float eps, mi_stream stream) {
+  if (!comm || !x || !residual || !weight || !out || !residual_out || rows < 0 || cols <= 0) return MI_EINVAL;
+  if (rows > MAX_SLICES || cols % 8 || cols < 512 || cols > 8192 || (size_t)rows * cols * 2 > comm->max_bytes)
+    return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(residual) || !aligned16(weight) || !aligned16(out) || !aligned16(residual_out))
+    return MI_EINVAL;
+  if (rows == 0) return MI_OK;
+  const int nvec = cols / 8;
+  hipStream_t st = S(stream);
+#define LAUNCH_ARN(V)                                                                                           \
+  hipLaunchKernelGGL((allreduce_add_rmsnorm_kernel<V>), dim3(rows), dim3(64), 0, st, comm->geom(), x, residual, \
+                     weight, out, residual_out, rows, cols, eps)
+  if (nvec <= 64) LAUNCH_ARN(1);
+  else if (nvec <= 128) LAUNCH_ARN(2);
+  else if (nvec <= 256) LAUNCH_ARN(4);
+  else if (nvec <= 512) LAUNCH_ARN(8);
+  else LAUNCH_ARN(16);
+#undef LAUNCH_ARN
+  return check_launch();
+}
+
+extern "C" int mi_comm_set_spin_limit(mi_comm* comm, uint32_t polls) {
+  if (!comm || polls == 0) return MI_EINVAL;
+  if (hipMemcpy(comm->ptrs.region[comm->rank] + 3 * sizeof(uint32_t), &polls, sizeof(polls), hipMemcpyHostToDevice) !=
+      hipSuccess)
+    return MI_ERUNTIME;
+  return MI_OK;
 }
 
 extern "C" int mi_comm_status(mi_comm* comm, int* timed_out) {
   if (!comm || !timed_out) return MI_EINVAL;
   uint32_t v = 0;
-  if (hipMemcpy(&v, comm->ptrs.region[comm->rank] + SLICES * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost) !=
+  if (hipMemcpy(&v, comm->ptrs.region[comm->rank] + 2 * sizeof(uint32_t), sizeof(v), hipMemcpyDeviceToHost) !=
       hipSuccess)
     return MI_ERUNTIME;
   *timed_out = (int)v;

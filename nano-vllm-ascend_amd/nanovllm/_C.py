@@ -89,6 +89,8 @@ _SIGNATURES = {
     "mi_comm_create": (c_int, [c_int, c_int, ctypes.POINTER(_p), c_size_t, ctypes.POINTER(_p)]),
     "mi_comm_destroy": (c_int, [_p]),
     "mi_allreduce_sum_bf16": (c_int, [_p, _p, _p, c_int64, _p]),
+    "mi_allreduce_add_rmsnorm": (c_int, [_p, _p, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
+    "mi_comm_set_spin_limit": (c_int, [_p, ctypes.c_uint32]),
     "mi_comm_status": (c_int, [_p, ctypes.POINTER(c_int)]),
 }
 

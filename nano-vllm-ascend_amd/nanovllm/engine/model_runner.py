@@ -77,6 +77,7 @@ class ModelRunner:
                                     world_size=self.world_size, rank=rank, **kw)
         self.channel = StepChannel(config.hccl_port, self.world_size, rank) if self.world_size > 1 else None
         self.xgmi = None
+        self._steps_run = 0
         if self.world_size > 1:
             from nanovllm.layers import parallel, xgmi_comm
 
@@ -134,7 +135,10 @@ class ModelRunner:
         if self.xgmi is not None:
             from nanovllm.layers import parallel
 
-            parallel.set_xgmi_comm(None)
+            try:
+                self._check_xgmi()
+            finally:
+                parallel.set_xgmi_comm(None)
             self.xgmi.close()
             self.xgmi = None
         if self.world_size > 1 and dist.is_initialized():
@@ -313,5 +317,14 @@ class ModelRunner:
             self.tokens_host[:real].copy_(self.tokens_dev[:real], non_blocking=True)
             torch.cuda.current_stream().synchronize()
             tokens = self.tokens_host[:real].tolist()
+        self._steps_run += 1
+        if self.xgmi is not None and self._steps_run % 64 == 1:
+            self._check_xgmi()
         reset_context()
         return tokens
+
+    def _check_xgmi(self):
+        """The exchange kernel gives up on a peer after ~1 minute instead of hanging the GPU; what it
+        returned then is not a sum.  Surface that as an error (checked every 64 steps and at exit)."""
+        if self.xgmi is not None and self.xgmi.timed_out():
+            raise RuntimeError(f"rank {self.rank}: xGMI all-reduce timed out waiting for a peer; results are invalid")

@@ -50,6 +50,18 @@ class XgmiComm:
         check(lib.mi_allreduce_sum_bf16(self._comm, ptr(t), ptr(t), t.numel(), stream()), "mi_allreduce_sum_bf16")
         return t
 
+    def fits_rows(self, rows: int, cols: int) -> bool:
+        return 0 < rows <= 64 and 512 <= cols <= 8192 and cols % 8 == 0 and rows * cols * 2 <= self.max_bytes
+
+    def allreduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, w: torch.Tensor, eps: float):
+        """sum over ranks of x, + residual, RMSNorm: one launch (mi_allreduce_add_rmsnorm)."""
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        out, residual_out = torch.empty_like(x), torch.empty_like(x)
+        check(lib.mi_allreduce_add_rmsnorm(self._comm, ptr(x), ptr(residual), ptr(w), ptr(out), ptr(residual_out),
+                                           rows, cols, float(eps), stream()), "mi_allreduce_add_rmsnorm")
+        return out, residual_out
+
     def timed_out(self) -> bool:
         flag = ctypes.c_int(0)
         check(lib.mi_comm_status(self._comm, ctypes.byref(flag)), "mi_comm_status")
@@ -61,6 +73,16 @@ class XgmiComm:
         consecutive launches (both epoch parities) and replay from a captured graph."""
         ok = True
         try:
+            # a broken topology must not cost a minute per launch: ~4 s patience while testing, and the
+            # first (tiny) exchange decides whether the rest is attempted at all
+            torch.cuda.synchronize()
+            check(lib.mi_comm_set_spin_limit(self._comm, 1 << 22), "mi_comm_set_spin_limit")
+            dist.barrier()
+            probe = torch.full((8,), float(self.rank + 1), dtype=torch.bfloat16, device=self.device)
+            self.all_reduce(probe)
+            first = not self.timed_out() and bool((probe == self.world * (self.world + 1) / 2).all())
+            if not self._agree(first):  # every rank stops here together
+                raise RuntimeError("first exchange failed")
             for n in (8, 4096, self.max_bytes // 2):
                 idx = torch.arange(n, device=self.device, dtype=torch.int64)
                 for it in range(3):
@@ -88,9 +110,13 @@ class XgmiComm:
                 torch.cuda.synchronize()
                 ok = ok and bool(torch.equal(buf, want))
             ok = ok and not self.timed_out()
+            check(lib.mi_comm_set_spin_limit(self._comm, 1 << 26), "mi_comm_set_spin_limit")
         except Exception as e:  # noqa: BLE001 - any failure means "do not use this path"
             warnings.warn(f"xGMI all-reduce self-test raised {e!r}")
             ok = False
+        return self._agree(ok)
+
+    def _agree(self, ok: bool) -> bool:
         verdict = torch.tensor([1 if ok else 0], dtype=torch.int32,
                                device=self.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN)

@@ -9,6 +9,8 @@ mi_qknorm_rope_store, whose rounding points are identical (tests require equal b
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -18,7 +20,7 @@ from nanovllm.layers.attention import Attention
 from nanovllm.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
 from nanovllm.layers.layernorm import RMSNorm
 from nanovllm.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
-from nanovllm.layers.parallel import all_reduce_sum, tp_size
+from nanovllm.layers.parallel import all_reduce_sum, get_xgmi_comm, tp_size
 from nanovllm.layers.rotary_embedding import get_rope
 from nanovllm.utils.context import get_context
 
@@ -182,22 +184,30 @@ class Qwen3Model(nn.Module):
           add+RMSNorm (summing the previous projection's split-K partials) -> packed qkv GEMM ->
           q/k-norm+RoPE+KV-store -> paged attention -> split-K o_proj -> add+RMSNorm ->
           packed gate_up GEMM with the SwiGLU epilogue -> split-K down_proj.
-        With tensor parallelism the two row-parallel projections produce bf16 partial sums that are
-        all-reduced over the ranks (linear.py:149-153) before the plain add+RMSNorm.
+        With tensor parallelism the two row-parallel projections produce bf16 partial sums; the
+        all-reduce over the ranks (linear.py:149-153) and the following add+RMSNorm are ONE launch over
+        xGMI (mi_allreduce_add_rmsnorm), or RCCL all-reduce + add+RMSNorm when that path is off.
         Rounding points are those of the module-by-module path (tests require equal results up to
         fp32 summation order)."""
         tp = tp_size()
         h = self.embed_tokens(input_ids)
         residual, parts = None, None
 
+        xgmi = get_xgmi_comm() if tp > 1 else None
+        fused_seam = (xgmi is not None and xgmi.fits_rows(h.shape[0], h.shape[1])
+                      and os.environ.get("MI355_XGMI_FUSED", "1") != "0")
+
         def row_parallel(x, lin):
             if tp == 1:
                 return ops.gemm_packed_splitk(x, lin.weight_packed, self._ksplit(lin.weight))
-            return all_reduce_sum(ops.gemm_packed(x, lin.weight_packed))
+            y = ops.gemm_packed(x, lin.weight_packed)  # this rank's bf16 partial sums
+            return y if fused_seam else all_reduce_sum(y)
 
         def add_norm(y, res, ln):
             if tp == 1:
                 return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps)
+            if fused_seam:  # all-reduce over xGMI + add + RMSNorm in one launch
+                return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
             return ops.add_rmsnorm(y, res, ln.weight, ln.eps)
 
         for layer in self.layers:

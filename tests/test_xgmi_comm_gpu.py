@@ -37,7 +37,19 @@ def _worker(rank, world, port, out):
             z = y.clone()
             comm.all_reduce(z)
             exact = exact and bool(torch.equal(z.cpu(), want))
-        out.put((rank, ok, exact, comm.timed_out()))
+        # fused all-reduce + add + RMSNorm == all-reduce kernel followed by mi_add_rmsnorm, bit for bit
+        from nanovllm import ops
+
+        fused_ok = True
+        for rows, cols in ((1, 1024), (32, 1024), (64, 1024), (7, 5120), (5, 512)):
+            g2 = torch.Generator().manual_seed(rows * 10000 + cols)  # same residual / weight on every rank
+            res = torch.randn(rows, cols, generator=g2).bfloat16().to(dev)
+            w = (1 + 0.1 * torch.randn(cols, generator=g2)).bfloat16().to(dev)
+            part = torch.randn(rows, cols, generator=torch.Generator().manual_seed(7 * rank + rows)).bfloat16().to(dev)
+            want_y, want_r = ops.add_rmsnorm(comm.all_reduce(part.clone()), res, w, 1e-6)
+            got_y, got_r = comm.allreduce_add_rmsnorm(part, res, w, 1e-6)
+            fused_ok = fused_ok and bool(torch.equal(got_y, want_y)) and bool(torch.equal(got_r, want_r))
+        out.put((rank, ok, exact and fused_ok, comm.timed_out()))
     finally:
         dist.barrier()
         comm.close()
