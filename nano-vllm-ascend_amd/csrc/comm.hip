@@ -5,8 +5,8 @@
 //                        spin limit u32 (polls before a peer is declared missing)
 //   [4096, +flag bytes)  flags[parity 2][source rank world][MAX_SLICES] u32  (epoch of the last arrival)
 //   [..., +slot bytes)   slots[parity 2][source rank world][max_bytes]
-// A launch cuts the vector into slices (16 element ranges for the plain all-reduce, one row each for
-// the fused add+RMSNorm); workgroup s owns slice s in every phase, so the only cross-GPU dependency
+// A launch cuts the vector into slices (up to 64 element ranges for the plain all-reduce, one row each
+// for the fused add+RMSNorm), one single-wave workgroup per slice; workgroup s owns slice s in every phase, so the only cross-GPU dependency
 // is per slice and is carried by flags[.][r][s].  The epoch is one number per communicator: every
 // workgroup reads it when it starts, the last one to finish advances it - launches are stream
 // ordered, so the next launch (or graph replay) sees the new value.
@@ -17,7 +17,6 @@
 
 namespace mi {
 
-constexpr int SLICES = 16;       // workgroups of the plain all-reduce
 constexpr int MAX_SLICES = 64;   // flag slots per (parity, source): rows of the fused kernel
 constexpr size_t CTRL_BYTES = 4096;
 constexpr uint32_t DEFAULT_SPIN_LIMIT = 1u << 26;  // polls of ~1 us each: about a minute
@@ -86,27 +85,28 @@ __device__ __forceinline__ void comm_finish(const CommGeom& g, uint32_t e, int n
   }
 }
 
-__global__ __launch_bounds__(256) void allreduce_kernel(CommGeom g, const uint16_t* __restrict__ in,
-                                                        uint16_t* __restrict__ out, int64_t n) {
-  const int s = blockIdx.x, tid = threadIdx.x;
+// plain all-reduce: one wave per slice (same shape as the fused kernel below: a wave pushes, flags,
+// waits and reduces its own 16-byte pieces, no workgroup barrier anywhere)
+__global__ __launch_bounds__(64) void allreduce_kernel(CommGeom g, const uint16_t* in, uint16_t* out, int64_t n) {
+  const int s = blockIdx.x, lane = threadIdx.x, n_slices = gridDim.x;
   const uint32_t e = comm_epoch(g);
   const uint32_t par = e & 1u;
 
   const int64_t vecs = n / 8;  // 16-byte pieces
-  const int64_t per = (vecs + SLICES - 1) / SLICES;
+  const int64_t per = (vecs + n_slices - 1) / n_slices;
   const int64_t v0 = min(vecs, (int64_t)s * per), v1 = min(vecs, v0 + per);
 
   // (a) push this slice into slot [par][rank] of every rank's region, the next-higher rank first
-  for (int k = 1; k <= g.world; ++k) {
-    const int q = (g.rank + k) % g.world;
-    u32x4* dst = reinterpret_cast<u32x4*>(comm_slot(g, q, par, g.rank));
-    for (int64_t v = v0 + tid; v < v1; v += 256) dst[v] = reinterpret_cast<const u32x4*>(in)[v];
+  for (int64_t v = v0 + lane; v < v1; v += 64) {
+    const u32x4 x = reinterpret_cast<const u32x4*>(in)[v];
+    for (int k = 1; k <= g.world; ++k)
+      reinterpret_cast<u32x4*>(comm_slot(g, (g.rank + k) % g.world, par, g.rank))[v] = x;
   }
   // (b) publish, (c) wait
-  comm_publish_and_wait(g, e, s, tid, true);
+  comm_publish_and_wait(g, e, s, lane, false);
   // (d) sum the `world` slots in rank order
   const uint8_t* slots = comm_slot(g, g.rank, par, 0);
-  for (int64_t v = v0 + tid; v < v1; v += 256) {
+  for (int64_t v = v0 + lane; v < v1; v += 64) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < g.world; ++r) {
       const u32x4 x = reinterpret_cast<const u32x4*>(slots + (size_t)r * g.slot_stride)[v];
@@ -121,8 +121,7 @@ __global__ __launch_bounds__(256) void allreduce_kernel(CommGeom g, const uint16
     for (int i = 0; i < 4; ++i) y[i] = pack_bf(acc[2 * i], acc[2 * i + 1]);
     reinterpret_cast<u32x4*>(out)[v] = y;
   }
-  __syncthreads();
-  if (tid == 0) comm_finish(g, e, SLICES);
+  if (lane == 0) comm_finish(g, e, n_slices);
 }
 
 // all-reduce + residual add + RMSNorm in one launch: one wave per token row (decode: <= 64 rows).
@@ -309,7 +308,10 @@ extern "C" int mi_allreduce_sum_bf16(mi_comm* comm, const mi_bf16* in, mi_bf16* 
   if (n % 8 || (size_t)n * 2 > comm->max_bytes) return MI_EUNSUPPORTED;
   if (!aligned16(in) || !aligned16(out)) return MI_EINVAL;
   if (n == 0) return MI_OK;
-  hipLaunchKernelGGL(allreduce_kernel, dim3(SLICES), dim3(256), 0, S(stream), comm->geom(), in, out, n);
+  const int64_t vecs = n / 8;
+  int slices = (int)((vecs + 127) / 128);  // ~2 KiB per wave, at most MAX_SLICES waves
+  if (slices > MAX_SLICES) slices = MAX_SLICES;
+  hipLaunchKernelGGL(allreduce_kernel, dim3(slices), dim3(64), 0, S(stream), comm->geom(), in, out, n);
   return check_launch();
 }
 
