@@ -240,7 +240,7 @@ def main():
     # ms_per_step minus this is the host share of a step (scheduler, metadata, sampling, sync)
     mr = llm.model_runner
     bucket = mr._bucket_for(BATCH) if mr.graphs else None
-    if bucket is not None:
+    if bucket is not None and world == 1:  # with TP the graph holds exchanges: rank 0 must not replay it alone
         g = mr.graphs[bucket]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g.replay()
