@@ -176,9 +176,16 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     port = int(os.environ.get("MASTER_PORT", "29500"))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
+        torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank))))
+        # BENCH_DIST_BACKEND=gloo: functional run of this N > 1 flow with the ranks sharing one GPU
+        # (eager decode, not a measurement); the driver's runs use RCCL ("nccl"), one GPU per rank
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     tmp = os.environ.get("TMPDIR", "/tmp")
     model_dir = os.path.join(tmp, f"mi355_qwen3_0p6b_{port}")
     if rank == 0:
