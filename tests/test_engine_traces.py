@@ -1,6 +1,6 @@
 """Scheduler / BlockManager / Sequence / step-metadata parity: replay the request
-streams of tests/golden/engine_traces.json (recorded from the reference's own
-classes by tools/gen_golden.py) through this package's host code and require
+streams of tests/golden/engine_traces.json and engine_traces_fuzz.json (recorded from the
+reference's own classes by tools/gen_golden.py) through this package's host code and require
 every index it produces to be identical.  CPU only."""
 import json
 import os
@@ -19,13 +19,15 @@ from nanovllm.sampling_params import SamplingParams
 
 with open(os.path.join(GOLDEN, "engine_traces.json")) as f:
     SCENARIOS = json.load(f)
+with open(os.path.join(GOLDEN, "engine_traces_fuzz.json")) as f:  # 14 seeded random streams, tight memory
+    FUZZ = json.load(f)
 
 
 def fake_token(seq, step):  # the deterministic stand-in sampler of tools/gen_golden.py
     return (sum(seq.token_ids[-4:]) * 31 + 7 * step + len(seq)) % 1000 + 1
 
 
-@pytest.mark.parametrize("sc", SCENARIOS, ids=[s["name"] for s in SCENARIOS])
+@pytest.mark.parametrize("sc", SCENARIOS + FUZZ, ids=[s["name"] for s in SCENARIOS + FUZZ])
 def test_trace_replay(sc):
     c = sc["config"]
     cfg = SimpleNamespace(max_num_seqs=c["max_num_seqs"], max_num_batched_tokens=c["max_num_batched_tokens"],

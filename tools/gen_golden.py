@@ -340,6 +340,37 @@ def gen_engine():
         json.dump(scenarios, f, separators=(",", ":"))
 
 
+def gen_engine_fuzz(n_scenarios=14):
+    """Seeded random request streams under tight memory (shared prefixes, preemption + re-prefill,
+    revival of freed blocks, staggered arrivals, EOS hits, graph-padded or eager metadata)."""
+    out = []
+    for seed in range(n_scenarios):
+        rng = random.Random(1000 + seed)
+        bs = rng.choice([4, 4, 16])
+        max_num_seqs = rng.randrange(2, 6)
+        longest = rng.choice([5, 9, 14]) * bs // 4 + rng.randrange(0, bs)
+        prefixes = [[rng.randrange(1, 900) for _ in range(bs * rng.randrange(1, 3))] for _ in range(2)]
+        arrivals = []
+        for _ in range(rng.randrange(5, 10)):
+            body = [rng.randrange(1, 900) for _ in range(rng.randrange(1, max(2, longest)))]
+            toks = (rng.choice(prefixes) + body) if rng.random() < 0.55 else body
+            toks = toks[: longest + bs]
+            arrivals.append((rng.randrange(0, 12), toks, rng.randrange(2, 18), rng.random() < 0.7))
+        max_model_len = (max(len(a[1]) for a in arrivals) + 20 + bs - 1) // bs * bs
+        need_one = (max(len(a[1]) + a[2] for a in arrivals) + bs - 1) // bs + 1
+        nblk = max(need_one + 1, rng.randrange(need_one, 3 * need_one)) + 1  # tight: forces preemption often
+        budget = max(max_model_len, rng.choice([32, 64, 128]))
+        out.append(run_scenario(f"fuzz{seed}_b{bs}", bs, nblk, max_num_seqs, budget, max_model_len, arrivals,
+                                padded=rng.random() < 0.4, eos=rng.choice([-1, 500, 250])))
+    with open(os.path.join(OUT, "engine_traces_fuzz.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    pre = sum(1 for sc in out if len([i for r in sc["steps"] if r["is_prefill"] for i in r["seqs"]]) >
+              len({i for r in sc["steps"] if r["is_prefill"] for i in r["seqs"]}))
+    hits = sum(1 for sc in out if any(sum(r["num_cached_tokens"]) > 0 for r in sc["steps"]))
+    print(f"fuzz scenarios: {len(out)}, with preemption: {pre}, with prefix hits: {hits}, "
+          f"steps: {sum(len(sc['steps']) for sc in out)}")
+
+
 # --------------------------------------------------------------------------- E. tiny model
 def gen_tiny_model():
     from transformers import Qwen3Config
@@ -435,11 +466,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # fixed reduction order for reproducible fixtures
     import_reference()
-    gen_hashes()
-    gen_layers()
-    gen_attention()
-    gen_engine()
-    gen_tiny_model()
+    only = sys.argv[1:]  # e.g. `gen_golden.py engine_fuzz` regenerates one fixture
+    for name, fn in (("hashes", gen_hashes), ("layers", gen_layers), ("attention", gen_attention),
+                     ("engine", gen_engine), ("engine_fuzz", gen_engine_fuzz), ("tiny_model", gen_tiny_model)):
+        if not only or name in only:
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f"{f}: {os.path.getsize(os.path.join(OUT, f))} B")
 
