@@ -253,6 +253,98 @@ __global__ __launch_bounds__(128) void v_store_tiles_kernel(const uint16_t* __re
   }
 }
 
+// Prefill form of the fused q/k-norm + RoPE + KV store: one workgroup per (16 consecutive tokens,
+// kv head) handles that head's K rows, V rows and its G query heads.  16 groups of 8 lanes, one token
+// each, run the same per-head arithmetic as qk_rope_store_kernel (bit-identical results); K and V
+// are assembled as whole 4 KiB cache tiles in LDS and leave as one coalesced run when the 16 tokens
+// fill an aligned tile (always, for a sequence that starts on a block boundary) - the per-token form
+// writes each K row as sixteen 16-byte pieces 256 bytes apart.  Q rows go to q_out (contiguous rows).
+__global__ __launch_bounds__(128) void qkv_prefill_store_kernel(
+    const uint16_t* __restrict__ qkv, int64_t row_stride, const uint16_t* __restrict__ q_w,
+    const uint16_t* __restrict__ k_w, float eps, const int64_t* __restrict__ positions,
+    const float* __restrict__ cos_sin, uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
+    uint16_t* __restrict__ v_cache, const int32_t* __restrict__ slots, int n_tokens, int n_q_heads,
+    int n_kv_heads, int block_size) {
+  __shared__ __attribute__((aligned(16))) uint16_t k_img[2048];  // the K tile as stored
+  __shared__ __attribute__((aligned(16))) uint16_t sm[16][128 + 8];
+  __shared__ int sm_slot[16];
+  const int t0 = blockIdx.x * 16, h = blockIdx.y, tid = threadIdx.x;
+  const int tk = tid >> 3, j = tid & 7;
+  const int n_here = min(16, n_tokens - t0);
+  const int G = n_q_heads / n_kv_heads;
+  const bool live = tk < n_here;
+  const int token = live ? t0 + tk : t0;  // idle groups shadow a valid token (shuffles stay defined)
+  if (tid < 16) sm_slot[tid] = tid < n_here ? slots[t0 + tid] : -2;
+  const uint16_t* row = qkv + (int64_t)token * row_stride;
+  const float* cs = cos_sin + positions[token] * 128;
+
+  // ---- K: norm + RoPE, into the tile image
+  float a[8], b[8];
+  load16(row + (n_q_heads + h) * 128 + 8 * j, a);
+  load16(row + (n_q_heads + h) * 128 + 64 + 8 * j, b);
+  if (k_w != nullptr) head_rmsnorm(a, b, k_w, j, eps);
+  head_rope(a, b, cs, j);
+  *reinterpret_cast<u32x4*>(&k_img[k_tile_off(tk, 8 * j)]) = pack16(a);
+  *reinterpret_cast<u32x4*>(&k_img[k_tile_off(tk, 64 + 8 * j)]) = pack16(b);
+  // ---- V: plain rows into the transpose buffer
+  const uint16_t* vrow = row + (n_q_heads + n_kv_heads + h) * 128;
+  {
+    u32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+    if (live) {
+      v0 = *reinterpret_cast<const u32x4*>(vrow + 8 * j);
+      v1 = *reinterpret_cast<const u32x4*>(vrow + 64 + 8 * j);
+    }
+    *reinterpret_cast<u32x4*>(&sm[tk][8 * j]) = v0;
+    *reinterpret_cast<u32x4*>(&sm[tk][64 + 8 * j]) = v1;
+  }
+  __syncthreads();
+  const int s0 = sm_slot[0];
+  bool tile_ok = s0 >= 0 && (s0 & 15) == 0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) tile_ok = tile_ok && sm_slot[i] == s0 + i;
+  const int tpb = block_size >> 4;
+  if (tile_ok) {
+    const int64_t base = kv_tile_base(s0 / block_size, h, s0 % block_size, n_kv_heads, tpb);
+    for (int oc = tid; oc < 256; oc += 128) {
+      *reinterpret_cast<u32x4*>(k_cache + base + oc * 8) = *reinterpret_cast<const u32x4*>(&k_img[oc * 8]);
+      const int jp = oc >> 6, g4 = (oc >> 4) & 3, nn = oc & 15;  // V chunk: 4 tokens x {d, d+16}
+      const int d0 = jp * 32 + nn;
+      u32x4 o;
+      o[0] = (uint32_t)sm[4 * g4 + 0][d0] | ((uint32_t)sm[4 * g4 + 1][d0] << 16);
+      o[1] = (uint32_t)sm[4 * g4 + 2][d0] | ((uint32_t)sm[4 * g4 + 3][d0] << 16);
+      o[2] = (uint32_t)sm[4 * g4 + 0][d0 + 16] | ((uint32_t)sm[4 * g4 + 1][d0 + 16] << 16);
+      o[3] = (uint32_t)sm[4 * g4 + 2][d0 + 16] | ((uint32_t)sm[4 * g4 + 3][d0 + 16] << 16);
+      *reinterpret_cast<u32x4*>(v_cache + base + oc * 8) = o;
+    }
+  } else if (live) {  // ragged: per-token scatter (negative slots are skipped)
+    const int sl = sm_slot[tk];
+    if (sl >= 0) {
+      const int64_t blk = sl / block_size;
+      const int off = sl % block_size;
+      store_k_head(k_cache, blk, off, h, j, a, b, n_kv_heads, tpb);
+      uint16_t* tile = v_cache + kv_tile_base(blk, h, off, n_kv_heads, tpb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        tile[v_tile_off(off & 15, 8 * j + i)] = sm[tk][8 * j + i];
+        tile[v_tile_off(off & 15, 64 + 8 * j + i)] = sm[tk][64 + 8 * j + i];
+      }
+    }
+  }
+  // ---- Q: the G heads of this kv head (output rows are contiguous: coalesced as they are)
+  for (int g = 0; g < G; ++g) {
+    const int hq = h * G + g;
+    load16(row + hq * 128 + 8 * j, a);
+    load16(row + hq * 128 + 64 + 8 * j, b);
+    if (q_w != nullptr) head_rmsnorm(a, b, q_w, j, eps);
+    head_rope(a, b, cs, j);
+    if (live) {
+      uint16_t* dst = q_out + ((int64_t)token * n_q_heads + hq) * 128;
+      *reinterpret_cast<u32x4*>(dst + 8 * j) = pack16(a);
+      *reinterpret_cast<u32x4*>(dst + 64 + 8 * j) = pack16(b);
+    }
+  }
+}
+
 // inverse of the scatter, for content checks: out[i][h*128+d] = cache[slot_flat[i]][h][d]
 __global__ __launch_bounds__(256) void kv_gather_kernel(const uint16_t* __restrict__ cache, int is_v,
                                                         const int32_t* __restrict__ slot_flat, int n,
@@ -569,16 +661,17 @@ extern "C" int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride, 
   const int64_t hs = (int64_t)n_tokens * (n_q_heads + 2 * n_kv_heads);
   const mi_bf16* ksrc = qkv + (int64_t)n_q_heads * 128;
   const mi_bf16* vsrc = ksrc + (int64_t)n_kv_heads * 128;
-  // many tokens with flat slots (prefill): V is transposed tile-wise by its own kernel
-  const int tiled_v = (!slot_is_2d && n_tokens >= 64) ? 1 : 0;
+  if (!slot_is_2d && n_tokens >= 64) {  // many tokens with flat slots (prefill): whole cache tiles per workgroup
+    if (n_q_heads % n_kv_heads) return MI_EUNSUPPORTED;
+    hipLaunchKernelGGL(qkv_prefill_store_kernel, dim3((n_tokens + 15) / 16, n_kv_heads), dim3(128), 0, S(stream),
+                       qkv, qkv_row_stride, q_w, k_w, eps, positions, cos_sin, q_out, k_cache, v_cache, slots,
+                       n_tokens, n_q_heads, n_kv_heads, block_size);
+    return check_launch();
+  }
   hipLaunchKernelGGL((qk_rope_store_kernel<0>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), qkv,
                      qkv_row_stride, ksrc, qkv_row_stride, vsrc, qkv_row_stride, q_w, k_w, eps, positions,
                      cos_sin, q_out, nullptr, k_cache, v_cache, slots, slot_is_2d, n_tokens, n_q_heads,
-                     n_kv_heads, block_size, tiled_v);
-  int rc = check_launch();
-  if (rc != MI_OK || !tiled_v) return rc;
-  hipLaunchKernelGGL(v_store_tiles_kernel, dim3((n_tokens + 15) / 16, n_kv_heads), dim3(128), 0, S(stream), vsrc,
-                     qkv_row_stride, v_cache, slots, n_tokens, n_kv_heads, block_size);
+                     n_kv_heads, block_size, 0);
   return check_launch();
 }
 

@@ -221,6 +221,43 @@ def test_fused_qknorm_rope_store_equals_unfused(ops, T_tokens):
     assert torch.equal(kc3.view(torch.int16), kc4.view(torch.int16)) and torch.equal(vc3.view(torch.int16), vc4.view(torch.int16))
 
 
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (4, 4)])
+def test_fused_qknorm_rope_store_prefill_tiles(ops, hq, hkv):
+    """>= 64 tokens with flat slots: one workgroup per (16 tokens, kv head) assembles whole K / V cache
+    tiles.  Slot layout as a prefill produces it (consecutive runs from block boundaries) plus a run
+    that starts mid-tile, skipped tokens (-1) and a ragged tail; must equal the per-token kernel."""
+    g = torch.Generator().manual_seed(5 + hq)
+    bs, nblk = 16, 40
+    runs = [(3 * bs, 64), (9 * bs + 5, 36), (14 * bs, 32), (20 * bs, 45), (25 * bs + 15, 20)]  # (first slot, tokens)
+    slot_list = [s0 + i for s0, n in runs for i in range(n)]
+    T = len(slot_list)
+    slots = torch.tensor(slot_list, dtype=torch.int32)
+    slots[70] = -1
+    slots[130:133] = -1
+    slots = slots.to(DEV)
+    qkv = (torch.randn(T, (hq + 2 * hkv) * 128, generator=g) * 2).bfloat16().to(DEV)
+    qw = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16().to(DEV)
+    kw = (1 + 0.2 * torch.randn(128, generator=g)).bfloat16().to(DEV)
+    pos = torch.randint(0, 4096, (T,), generator=g).to(DEV)
+    table = oracle.build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    fill = torch.full(ops.kv_cache_shape(nblk, hkv, bs), 7.0, dtype=torch.bfloat16, device=DEV)
+    # reference: the same op through its per-token kernel (2-D slots never take the tile kernel)
+    s2 = torch.stack([torch.div(slots, bs, rounding_mode="floor"), slots % bs], 1).to(torch.int32)
+    s2[slots < 0] = -1
+    kc1, vc1 = fill.clone(), fill.clone()
+    q1 = ops.qknorm_rope_store(qkv, qw, kw, 1e-6, pos, table, kc1, vc1, s2.contiguous(), hq, hkv, bs)
+    kc2, vc2 = fill.clone(), fill.clone()
+    q2 = ops.qknorm_rope_store(qkv, qw, kw, 1e-6, pos, table, kc2, vc2, slots, hq, hkv, bs)
+    assert torch.equal(q2.view(torch.int16), q1.view(torch.int16))
+    assert torch.equal(kc1.view(torch.int16), kc2.view(torch.int16))
+    assert torch.equal(vc1.view(torch.int16), vc2.view(torch.int16))
+    assert not torch.equal(kc2.view(torch.int16), fill.view(torch.int16))
+    # and the oracle for q (norm is last-bit sensitive -> ulp tolerance)
+    q_view = qkv[:, : hq * 128].view(T, hq, 128)
+    qo = oracle.apply_rope(pos.cpu(), oracle.rms_norm(q_view.cpu(), qw.cpu(), 1e-6), table.cpu())
+    assert_bf16_close(q2.cpu().view(T, hq, 128), qo)
+
+
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
 @pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (256, 128), (512, 160), (16, 32)])
