@@ -444,10 +444,10 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
       }
       float p[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], scale_log2e, -m));
-        l += p[i];
-      }
+      for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], scale_log2e, -m));
+      // four independent partial sums instead of one 16-deep dependent add chain
+      l += ((p[0] + p[4]) + (p[8] + p[12])) + ((p[1] + p[5]) + (p[9] + p[13])) +
+           (((p[2] + p[6]) + (p[10] + p[14])) + ((p[3] + p[7]) + (p[11] + p[15])));
       u32x4 ph[2], pl[2];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
