@@ -302,6 +302,11 @@ int mi_comm_status(mi_comm* comm, int* timed_out);
  * BlockManager.compute_hash.  The reference calls the third-party `xxhash`
  * package (pyproject.toml:17, unpinned); this is XXH64 as published. */
 uint64_t mi_xxh64_chain(const void* data, size_t len, int has_prefix, uint64_t prefix);
+/* out[i] = chained hash of block i of `n_blocks` consecutive full blocks of int64 token ids
+ * (block 0 chained to `prefix` when has_prefix): BlockManager.allocate's loop (block_manager.py:62-71)
+ * in one call. */
+int mi_xxh64_chain_blocks(const int64_t* tokens, int n_blocks, int block_size, int has_prefix,
+                          uint64_t prefix, uint64_t* out);
 
 #ifdef __cplusplus
 }

@@ -128,3 +128,16 @@ extern "C" uint64_t mi_xxh64_chain(const void* data, size_t len, int has_prefix,
   h ^= h >> 32;
   return h;
 }
+
+// The chained hashes of n_blocks consecutive full blocks in one call (BlockManager.allocate hashes
+// every full block of a prompt: 64 calls per 1024-token sequence otherwise).
+extern "C" int mi_xxh64_chain_blocks(const int64_t* tokens, int n_blocks, int block_size, int has_prefix,
+                                     uint64_t prefix, uint64_t* out) {
+  if (n_blocks < 0 || block_size <= 0 || (n_blocks > 0 && (!tokens || !out))) return MI_EINVAL;
+  for (int i = 0; i < n_blocks; ++i) {
+    prefix = mi_xxh64_chain(tokens + (size_t)i * block_size, (size_t)block_size * sizeof(int64_t), has_prefix, prefix);
+    has_prefix = 1;
+    out[i] = prefix;
+  }
+  return MI_OK;
+}

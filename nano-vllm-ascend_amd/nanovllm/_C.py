@@ -81,6 +81,7 @@ _SIGNATURES = {
     "mi_argmax": (c_int, [_p, c_int64, _p, c_int, c_int, _p]),
     "mi_sample": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_uint64, c_uint64, _p]),
     "mi_xxh64_chain": (c_uint64, [_p, c_size_t, c_int, c_uint64]),
+    "mi_xxh64_chain_blocks": (c_int, [_p, c_int, c_int, c_int, c_uint64, _p]),
     "mi_comm_region_bytes": (c_size_t, [c_int, c_size_t]),
     "mi_comm_region_alloc": (c_int, [c_size_t, ctypes.POINTER(_p), _p]),
     "mi_comm_region_open": (c_int, [_p, ctypes.POINTER(_p)]),
@@ -151,6 +152,21 @@ def require_gpu(*tensors: torch.Tensor) -> None:
                 "mi355_nanovllm kernels only run on a HIP device; got a "
                 f"{t.device} tensor (there is no CPU fallback)"
             )
+
+
+def xxh64_chain_blocks(token_ids, n_blocks: int, block_size: int, prefix: int = -1) -> list[int]:
+    """Chained hashes of the first n_blocks full blocks of token_ids (one C call)."""
+    from array import array
+
+    if n_blocks <= 0:
+        return []
+    toks = array("q", token_ids[: n_blocks * block_size])
+    out = (c_uint64 * n_blocks)()
+    addr, _ = toks.buffer_info()
+    check(lib.mi_xxh64_chain_blocks(addr, n_blocks, block_size, int(prefix != -1),
+                                    0 if prefix == -1 else prefix & 0xFFFFFFFFFFFFFFFF, out),
+          "mi_xxh64_chain_blocks")
+    return list(out)
 
 
 def xxh64_chain(data: bytes, prefix: int = -1) -> int:

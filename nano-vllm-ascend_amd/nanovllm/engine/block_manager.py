@@ -20,7 +20,7 @@ from __future__ import annotations
 from array import array
 from collections import deque
 
-from nanovllm._C import xxh64_chain
+from nanovllm._C import xxh64_chain, xxh64_chain_blocks
 from nanovllm.engine.sequence import Sequence
 
 _NO_HASH = -1
@@ -82,30 +82,37 @@ class BlockManager:
         assert not seq.block_table
         seq.table_gen = getattr(seq, "table_gen", 0) + 1  # a fresh table: cached device rows of it are stale
         bs, lookup = self.block_size, self.hash_to_block_id
-        chain, missed, hits = _NO_HASH, False, 0
+        missed, hits = False, 0
+        hashes = xxh64_chain_blocks(seq.token_ids, len(seq) // bs, bs)  # the whole chain in one C call
+        blocks, free, used, table = self.blocks, self.free_block_ids, self.used_block_ids, seq.block_table
+        guard = self.non_cache_token_ids
         for i in range(seq.num_blocks):
             toks = seq.block(i)
-            if self.non_cache_token_ids and not self.non_cache_token_ids.isdisjoint(toks):
+            if guard and not guard.isdisjoint(toks):
                 missed = True
-            chain = self.compute_hash(toks, chain) if len(toks) == bs else _NO_HASH
-            hit_id = lookup.get(chain, -1)
-            if hit_id == -1 or self.blocks[hit_id].token_ids != toks:
-                missed = True
-            if missed:
-                hit_id = self.free_block_ids[0]
-                blk = self._take(hit_id)
+            chain = hashes[i] if len(toks) == bs else _NO_HASH
+            if not missed:
+                hit_id = lookup.get(chain, -1)
+                if hit_id == -1 or blocks[hit_id].token_ids != toks:
+                    missed = True
+            if missed:  # take the head of the free list (same as _take(free[0]), without the search)
+                hit_id = free.popleft()
+                blk = blocks[hit_id]
+                assert blk.ref_count == 0
+                blk.ref_count, blk.hash, blk.token_ids = 1, _NO_HASH, []
+                used.add(hit_id)
             else:
                 seq.num_cached_tokens += bs  # reporting counter: only ever grows (block_manager.py:79)
                 hits += 1
-                if hit_id in self.used_block_ids:
-                    blk = self.blocks[hit_id]
+                if hit_id in used:
+                    blk = blocks[hit_id]
                     blk.ref_count += 1
                 else:  # freed but not yet recycled: revive it
                     blk = self._take(hit_id)
             if chain != _NO_HASH:
-                blk.update(chain, toks)
+                blk.hash, blk.token_ids = chain, toks
                 lookup[chain] = hit_id
-            seq.block_table.append(hit_id)
+            table.append(hit_id)
         # hits are always a leading run (after the first miss everything misses), and a hit block
         # holds valid KV rows by the time this prefill's attention reads it: it was written by an
         # earlier step, or is written earlier in the same forward pass by the sequence that owns it

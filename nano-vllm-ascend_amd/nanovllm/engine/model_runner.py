@@ -221,6 +221,10 @@ class ModelRunner:
         self.stager = batch_meta.DecodeStager(h["ids"], h["pos"], h["ctx"], h["slots"], h["tables"], h["temps"])
         self.tokens_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
         self.tokens_host = torch.zeros(B, dtype=torch.int64, pin_memory=True)
+        # prefill metadata staging: ids + positions (8 B) + slots (4 B) per token, per-sequence vectors, tables
+        nbytes = cfg.max_num_batched_tokens * 20 + B * (W + 4) * 4 + 4096
+        self.prefill_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.prefill_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def _fill_decode_stage(self, seqs: list[Sequence], bucket: int):
         """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the pinned
@@ -230,16 +234,34 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ metadata -> context
     def prepare_prefill(self, seqs: list[Sequence]):
+        """prefill_meta() packed into ONE pinned staging buffer and uploaded with ONE async copy (the
+        reference issues seven pinned allocations + copies, model_runner.py:271-290).  The buffer is
+        reused every step: a step ends with the sampler's stream sync, so the previous upload is done."""
         m = batch_meta.prefill_meta(seqs, self.block_size, skip_cached=self.config.prefix_aware_prefill)
+        arrays = (m.input_ids, m.positions, m.slot_mapping, m.cu_seqlens_q, m.cu_seqlens_k, m.kv_lens,
+                  np.ascontiguousarray(m.block_tables))
+        offs, off = [], 0
+        for a in arrays:
+            offs.append(off)
+            off += (a.nbytes + 15) // 16 * 16
+        if off > self.prefill_host.numel():  # grow (rare: sized for max_num_batched_tokens up front)
+            self.prefill_host = torch.empty(off * 2, dtype=torch.uint8, pin_memory=True)
+            self.prefill_dev = torch.empty(off * 2, dtype=torch.uint8, device=self.device)
+        host = self.prefill_host.numpy()
+        for a, o in zip(arrays, offs):
+            host[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        self.prefill_dev[:off].copy_(self.prefill_host[:off], non_blocking=True)
 
-        def up(a):
-            return torch.from_numpy(a).pin_memory().to(self.device, non_blocking=True)
+        def dev(i, dtype, shape=None):
+            a = arrays[i]
+            t = self.prefill_dev[offs[i]:offs[i] + a.nbytes].view(dtype)
+            return t if shape is None else t.view(shape)
 
-        set_context(True, cu_seqlens_q=up(m.cu_seqlens_q), cu_seqlens_k=up(m.cu_seqlens_k),
-                    max_seqlen_q=m.max_seqlen_q, max_seqlen_k=m.max_seqlen_k, slot_mapping=up(m.slot_mapping),
-                    context_lens=None, block_tables=up(m.block_tables), block_size=self.block_size,
-                    kv_lens=up(m.kv_lens))
-        return up(m.input_ids), up(m.positions)
+        set_context(True, cu_seqlens_q=dev(3, torch.int32), cu_seqlens_k=dev(4, torch.int32),
+                    max_seqlen_q=m.max_seqlen_q, max_seqlen_k=m.max_seqlen_k, slot_mapping=dev(2, torch.int32),
+                    context_lens=None, block_tables=dev(6, torch.int32, tuple(m.block_tables.shape)),
+                    block_size=self.block_size, kv_lens=dev(5, torch.int32))
+        return dev(0, torch.int64), dev(1, torch.int64)
 
     def prepare_decode(self, seqs: list[Sequence], bucket: int | None = None):
         """Eager decode uses the same staging buffers with bucket == real batch."""
