@@ -1,4 +1,5 @@
-"""TP=2 on one GPU (gloo): fused xGMI seam vs all-reduce kernel + add_rmsnorm vs gloo all-reduce."""
+"""TP=2 engine run on one GPU (ranks over gloo): logits of the fused xGMI seam, the all-reduce kernel +
+add_rmsnorm, and the gloo all-reduce against the TP=1 run."""
 import os
 import socket
 import sys
