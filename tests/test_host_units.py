@@ -356,3 +356,27 @@ def test_safetensors_checkpoint_lands_in_the_packed_parameters(tmp_path, tied):
     shared = model.lm_head.weight.data_ptr() == model.model.embed_tokens.weight.data_ptr()
     assert shared == tied  # qwen3.py:204-205
     assert torch.equal(model.lm_head.weight, sd["lm_head.weight"])
+
+
+def test_chained_block_hashes_in_one_call_equal_the_per_block_chain():
+    import random
+    from array import array
+
+    from nanovllm._C import lib, xxh64_chain, xxh64_chain_blocks
+
+    rng = random.Random(1)
+    for bs, n_tokens in ((4, 11), (16, 64), (16, 1030), (256, 700)):
+        toks = [rng.randrange(0, 151936) for _ in range(n_tokens)]
+        want, prev = [], -1
+        for i in range(n_tokens // bs):
+            prev = xxh64_chain(array("q", toks[i * bs:(i + 1) * bs]).tobytes(), prev)
+            want.append(prev)
+        assert xxh64_chain_blocks(toks, n_tokens // bs, bs) == want
+        assert BlockManager.compute_hash(toks[:bs]) == (want[0] if want else BlockManager.compute_hash(toks[:bs]))
+    assert xxh64_chain_blocks([1, 2, 3], 0, 4) == []
+    assert lib.mi_xxh64_chain_blocks(None, 2, 4, 0, 0, None) == -1  # MI_EINVAL
+    # the communicator entry points validate before touching the device
+    assert lib.mi_comm_region_bytes(0, 1024) == 0 and lib.mi_comm_region_bytes(9, 1024) == 0
+    assert lib.mi_comm_region_bytes(8, 65536) > 2 * 8 * 65536
+    assert lib.mi_comm_create(0, 2, None, 1024, None) == -1
+    assert lib.mi_allreduce_sum_bf16(None, None, None, 8, None) == -1
