@@ -200,6 +200,7 @@ def main():
               max_num_batched_tokens=16384,
               num_kvcache_blocks=int(os.environ.get("BENCH_NBLK", max(blocks_needed, 4096))), hccl_port=port + 1,
               synthetic_seed=0, warmup=os.environ.get("BENCH_NO_WARMUP") is None,
+              quantization=os.environ.get("BENCH_QUANT") or None,  # "fp8": side experiment, never the default line
               enforce_eager=os.environ.get("BENCH_EAGER") is not None)
     if rank != 0:
         run_worker(model_dir, **kw)
@@ -236,7 +237,8 @@ def main():
         "config": {"workload": "Qwen3-0.6B bf16 paged decode under hipGraph, bs=32, 1024-token prompts, "
                                "block_size=16 (BASELINE.json configs[1])",
                    "batch": BATCH, "prompt_len": PROMPT_LEN, "ctx_first": ctx0 + 1, "ctx_last": ctx1,
-                   "block_size": BLOCK, "parallelism": f"tp{world}", "greedy": True},
+                   "block_size": BLOCK, "parallelism": f"tp{world}", "greedy": True,
+                   **({"weights": os.environ["BENCH_QUANT"]} if os.environ.get("BENCH_QUANT") else {})},
         "ttft_p50_ms": statistics.median(ttft) * 1e3, "ttft_max_ms": ttft[-1] * 1e3,
         "prefill_steps": prefill_steps,
         "step_roofline": {"bound": "hbm", "achieved": algo / elapsed / 1e9, "peak": HBM_PEAK / 1e9 * world,

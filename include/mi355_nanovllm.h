@@ -251,6 +251,20 @@ int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatur
               int64_t* out, int rows, int vocab, uint64_t seed, uint64_t step,
               mi_stream stream);
 
+/* ---- fp8 (e4m3) weights, bf16 activations (BASELINE.json configs[4]) --------
+ * No reference semantics exist (the reference is bf16 only): y = x @ (w_q * scale[:, None])^T with
+ * w_q OCP e4m3 values and one fp32 scale per weight row (output feature).  Decode GEMMs are bound
+ * by the weight stream, not by MFMA rate, so the weights are dequantised to bf16 in registers
+ * (exact) and multiplied on the bf16 MFMA: the activations are not quantised and the only error is
+ * the weight quantisation.  Same shapes, epilogues and split-K partials as the bf16 entry points;
+ * additionally K % 64 == 0.  w_q [N, K] row-major bytes -> mi_pack_weight_fp8 ->
+ * [N/16][K/64][64 lanes][16 bytes] (a lane's 16 bytes = its A fragments of two 32-deep k-steps). */
+int mi_pack_weight_fp8(const uint8_t* w_q, uint8_t* w_packed, int N, int K, mi_stream stream);
+int mi_gemm_fp8w_packed(const mi_bf16* x, const uint8_t* w_packed, const float* scale, mi_bf16* y,
+                        int M, int N, int K, int epilogue, mi_stream stream);
+int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
+                               float* partials, int M, int N, int K, int ksplit, mi_stream stream);
+
 /* ---- tensor-parallel exchange over xGMI -----------------------------------
  * Stands in for the HCCL all-reduce after every row-parallel projection and the
  * vocab-parallel embedding (linear.py:152-153, embed_head.py:41-42).  One process

@@ -27,10 +27,11 @@ namespace mi {
 
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
 
-template <int MT, int RT, int WAVES, int STEPS, bool PACKED, int EPI, bool BIAS>
+// WF: weight format - 0 row-major bf16, 1 fragment-native bf16, 2 fragment-native fp8 (e4m3) + per-row scale
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-    uint16_t* __restrict__ y, float* __restrict__ part, int M, int N, int K) {
+    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][RT*MT][256]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -52,12 +53,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // per-lane weight pointers.  fp8: [N/16][K/64][64 lanes][16 bytes] - a lane's 16 bytes are the A
+  // fragments of TWO consecutive 32-deep k-steps (8 e4m3 values each), dequantised to bf16 in registers
+  // (exact: e4m3 fits bf16); the per-row scale is applied to the fp32 sums in the epilogue.
   const uint16_t* wp[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t)
-    wp[t] = PACKED ? w + ((int64_t)tile[t] * ktiles + (kbeg >> 5)) * 512 + lane * 8
-                   : w + (int64_t)(tile[t] * 16 + r) * K + kbeg + 8 * g;
-  constexpr int WSTEP = PACKED ? 512 : 32;  // elements between consecutive k-steps
+    wp[t] = WF == 2   ? w + (((int64_t)tile[t] * (K >> 6) + (kbeg >> 6)) * 1024 + lane * 16) / 2
+            : WF == 1 ? w + ((int64_t)tile[t] * ktiles + (kbeg >> 5)) * 512 + lane * 8
+                      : w + (int64_t)(tile[t] * 16 + r) * K + kbeg + 8 * g;
+  constexpr int WSTEP = WF == 1 ? 512 : 32;  // elements between consecutive k-steps (bf16 formats)
   // B fragment of column tile m: lane (g, c) <- x[16 m + c][k + 32 s + 8 g .. +8].  Rows >= M are
   // clamped to row M-1: MFMA output columns are independent, the duplicates are never stored.
   const uint16_t* xp[MT];
@@ -67,15 +72,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   for (int k = 0; k < kslice; k += 32 * STEPS) {
     u32x4 a[RT][STEPS], bfrag[MT][STEPS];
     // every load of the block is issued before the first MFMA: no branches, no waits in between
+    if (WF == 2) {
+      static_assert(WF != 2 || STEPS % 2 == 0, "an fp8 fragment load covers two k-steps");
+      u32x4 raw[RT][(STEPS + 1) / 2];
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s)
-        a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 5) + s) * WSTEP));
+        for (int s2 = 0; s2 < STEPS / 2; ++s2)
+          raw[t][s2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 6) + s2) * 512));
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+        for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          const uint32_t lo = raw[t][s >> 1][2 * (s & 1)], hi = raw[t][s >> 1][2 * (s & 1) + 1];
+          const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+          const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+          a[t][s] = u32x4{pack_bf(f0[0], f0[1]), pack_bf(f1[0], f1[1]), pack_bf(f2[0], f2[1]), pack_bf(f3[0], f3[1])};
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+          a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 5) + s) * WSTEP));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
 #pragma unroll
@@ -104,6 +132,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
         const f32x4 u = *reinterpret_cast<const f32x4*>(red + (((wv * RT + tt) * MT + m) * 64 + l) * 4);
         s += u;
       }
+      if (WF == 2) s *= *reinterpret_cast<const f32x4*>(scale + tile[tt] * 16 + 4 * (l >> 4));  // per weight row
       return s;
     };
     const int row = 16 * m + (l & 15);
@@ -165,36 +194,39 @@ struct GemmArgs {
   float* part;
   int M, N, K, ksplit;
   hipStream_t st;
+  const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
 };
 
-template <int MT, int RT, int WAVES, int STEPS, bool PACKED, int EPI>
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
 static void launch(const GemmArgs& a) {
   const size_t lds = (size_t)WAVES * RT * MT * 256 * sizeof(float);
   const int tiles = a.N / 16;
   const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
   if (a.bias && EPI == EPI_NONE)
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, PACKED, EPI, true>), grid, dim3(WAVES * 64), lds,
-                       a.st, a.x, a.w, a.bias, a.y, a.part, a.M, a.N, a.K);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, PACKED, EPI, false>), grid, dim3(WAVES * 64), lds,
-                       a.st, a.x, a.w, a.bias, a.y, a.part, a.M, a.N, a.K);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K);
 }
 
 // choose STEPS (k-steps in flight per wave and iteration) from the K-slice and the register budget
-template <int MT, int RT, int WAVES, bool PACKED, int EPI>
+template <int MT, int RT, int WAVES, int WF, int EPI>
 static bool try_waves(const GemmArgs& a) {
   if (a.K % (a.ksplit * WAVES)) return false;
   const int kslice = a.K / (a.ksplit * WAVES);
   constexpr int FRAGS = MT + RT;  // fragments (4 VGPRs each) per k-step
   constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 6 ? 4 : 2);
-  if (MAXS >= 8 && kslice % 256 == 0) return launch<MT, RT, WAVES, 8, PACKED, EPI>(a), true;
-  if (MAXS >= 4 && kslice % 128 == 0) return launch<MT, RT, WAVES, 4, PACKED, EPI>(a), true;
-  if (kslice % 64 == 0) return launch<MT, RT, WAVES, 2, PACKED, EPI>(a), true;
-  if (kslice % 32 == 0) return launch<MT, RT, WAVES, 1, PACKED, EPI>(a), true;
+  if (MAXS >= 8 && kslice % 256 == 0) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
+  if (MAXS >= 4 && kslice % 128 == 0) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
+  if (kslice % 64 == 0) return launch<MT, RT, WAVES, 2, WF, EPI>(a), true;
+  if constexpr (WF != 2) {  // an fp8 fragment load spans 64 k
+    if (kslice % 32 == 0) return launch<MT, RT, WAVES, 1, WF, EPI>(a), true;
+  }
   return false;
 }
 
-template <int MT, int RT, bool PACKED, int EPI>
+template <int MT, int RT, int WF, int EPI>
 static int pick_waves(const GemmArgs& a) {
   // Few row tiles (small N): spread K over many waves so that every CU holds loads in flight -
   // K-slices of 128 (four 1 KiB fragment loads per row tile and wave) when K allows;
@@ -203,35 +235,35 @@ static int pick_waves(const GemmArgs& a) {
   const int kper = a.K / a.ksplit;
   bool ok = false;
   if (wgs >= 2048) {
-    ok = try_waves<MT, RT, 4, PACKED, EPI>(a) || try_waves<MT, RT, 2, PACKED, EPI>(a);
+    ok = try_waves<MT, RT, 4, WF, EPI>(a) || try_waves<MT, RT, 2, WF, EPI>(a);
   } else if (kper % 128 == 0) {
     switch (kper / 128) {
-      case 1: ok = try_waves<MT, RT, 1, PACKED, EPI>(a); break;
-      case 2: ok = try_waves<MT, RT, 2, PACKED, EPI>(a); break;
-      case 3: ok = try_waves<MT, RT, 3, PACKED, EPI>(a); break;
-      case 4: ok = try_waves<MT, RT, 4, PACKED, EPI>(a); break;
-      case 6: ok = try_waves<MT, RT, 6, PACKED, EPI>(a); break;
-      case 8: ok = try_waves<MT, RT, 8, PACKED, EPI>(a); break;
-      case 12: ok = try_waves<MT, RT, 12, PACKED, EPI>(a); break;
-      case 16: ok = try_waves<MT, RT, 16, PACKED, EPI>(a); break;
-      case 24: ok = try_waves<MT, RT, 12, PACKED, EPI>(a); break;
-      case 32: ok = try_waves<MT, RT, 16, PACKED, EPI>(a); break;
+      case 1: ok = try_waves<MT, RT, 1, WF, EPI>(a); break;
+      case 2: ok = try_waves<MT, RT, 2, WF, EPI>(a); break;
+      case 3: ok = try_waves<MT, RT, 3, WF, EPI>(a); break;
+      case 4: ok = try_waves<MT, RT, 4, WF, EPI>(a); break;
+      case 6: ok = try_waves<MT, RT, 6, WF, EPI>(a); break;
+      case 8: ok = try_waves<MT, RT, 8, WF, EPI>(a); break;
+      case 12: ok = try_waves<MT, RT, 12, WF, EPI>(a); break;
+      case 16: ok = try_waves<MT, RT, 16, WF, EPI>(a); break;
+      case 24: ok = try_waves<MT, RT, 12, WF, EPI>(a); break;
+      case 32: ok = try_waves<MT, RT, 16, WF, EPI>(a); break;
       default: break;
     }
   }
-  if (!ok) ok = try_waves<MT, RT, 8, PACKED, EPI>(a) || try_waves<MT, RT, 4, PACKED, EPI>(a) ||
-                try_waves<MT, RT, 2, PACKED, EPI>(a) || try_waves<MT, RT, 1, PACKED, EPI>(a);
+  if (!ok) ok = try_waves<MT, RT, 8, WF, EPI>(a) || try_waves<MT, RT, 4, WF, EPI>(a) ||
+                try_waves<MT, RT, 2, WF, EPI>(a) || try_waves<MT, RT, 1, WF, EPI>(a);
   if (!ok) return MI_EUNSUPPORTED;
   return check_launch();
 }
 
-template <int RT, bool PACKED, int EPI>
+template <int RT, int WF, int EPI>
 static int pick_mt(const GemmArgs& a) {
   switch ((a.M + 15) / 16) {
-    case 1: return pick_waves<1, RT, PACKED, EPI>(a);
-    case 2: return pick_waves<2, RT, PACKED, EPI>(a);
-    case 3: return pick_waves<3, RT, PACKED, EPI>(a);
-    default: return pick_waves<4, RT, PACKED, EPI>(a);
+    case 1: return pick_waves<1, RT, WF, EPI>(a);
+    case 2: return pick_waves<2, RT, WF, EPI>(a);
+    case 3: return pick_waves<3, RT, WF, EPI>(a);
+    default: return pick_waves<4, RT, WF, EPI>(a);
   }
 }
 
@@ -252,7 +284,7 @@ extern "C" int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_
   if (rc != MI_OK) return rc;
   if (bias && !aligned16(bias)) return MI_EINVAL;
   if (M == 0) return MI_OK;
-  return pick_mt<1, false, EPI_NONE>(GemmArgs{x, w, bias, y, nullptr, M, N, K, 1, S(stream)});
+  return pick_mt<1, 0, EPI_NONE>(GemmArgs{x, w, bias, y, nullptr, M, N, K, 1, S(stream)});
 }
 
 extern "C" int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream) {
@@ -274,10 +306,10 @@ extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, co
   if (epilogue == 1 && (bias || N % 32)) return MI_EUNSUPPORTED;
   if (M == 0) return MI_OK;
   const GemmArgs a{x, w_packed, bias, y, nullptr, M, N, K, 1, S(stream)};
-  if (epilogue == 1) return pick_mt<2, true, EPI_SILU>(a);
+  if (epilogue == 1) return pick_mt<2, 1, EPI_SILU>(a);
   // two row tiles per workgroup halve the x traffic per weight byte once there are plenty of tiles
-  if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, true, EPI_NONE>(a);
-  return pick_mt<1, true, EPI_NONE>(a);
+  if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, 1, EPI_NONE>(a);
+  return pick_mt<1, 1, EPI_NONE>(a);
 }
 
 extern "C" int mi_gemm_bf16_packed_splitk(const mi_bf16* x, const mi_bf16* w_packed, float* partials, int M, int N,
@@ -286,5 +318,67 @@ extern "C" int mi_gemm_bf16_packed_splitk(const mi_bf16* x, const mi_bf16* w_pac
   if (rc != MI_OK) return rc;
   if (ksplit < 1 || ksplit > 16 || K % (32 * ksplit)) return MI_EUNSUPPORTED;
   if (M == 0) return MI_OK;
-  return pick_mt<1, true, EPI_PARTIAL>(GemmArgs{x, w_packed, nullptr, nullptr, partials, M, N, K, ksplit, S(stream)});
+  return pick_mt<1, 1, EPI_PARTIAL>(GemmArgs{x, w_packed, nullptr, nullptr, partials, M, N, K, ksplit, S(stream)});
+}
+
+// ---- fp8 (e4m3) weights, bf16 activations ----------------------------------------------------------
+namespace mi {
+// dst[((tn * K/64 + tk) * 64 + lane) * 16 + 8 h + e] = src[(16 tn + lane % 16) * K + 64 tk + 32 h + 8 (lane / 16) + e]
+__global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const uint8_t* __restrict__ src,
+                                                              uint8_t* __restrict__ dst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+  const int64_t total = (int64_t)N * K / 16;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const int64_t frag = idx >> 6;
+  const int ktiles = K >> 6;
+  const int tk = frag % ktiles;
+  const int64_t tn = frag / ktiles;
+  const uint8_t* row = src + (tn * 16 + (lane & 15)) * K + tk * 64 + (lane >> 4) * 8;
+  u32x4 v;
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(row), hi = *reinterpret_cast<const u32x2*>(row + 32);
+  v[0] = lo[0];
+  v[1] = lo[1];
+  v[2] = hi[0];
+  v[3] = hi[1];
+  *reinterpret_cast<u32x4*>(dst + idx * 16) = v;
+}
+}  // namespace mi
+
+extern "C" int mi_pack_weight_fp8(const uint8_t* w_q, uint8_t* w_packed, int N, int K, mi_stream stream) {
+  if (!w_q || !w_packed || N <= 0 || K <= 0) return MI_EINVAL;
+  if (N % 16 || K % 64) return MI_EUNSUPPORTED;
+  if (!aligned16(w_q) || !aligned16(w_packed)) return MI_EINVAL;
+  const int64_t chunks = (int64_t)N * K / 16;
+  hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, S(stream), w_q,
+                     w_packed, N, K);
+  return check_launch();
+}
+
+extern "C" int mi_gemm_fp8w_packed(const mi_bf16* x, const uint8_t* w_packed, const float* scale, mi_bf16* y, int M,
+                                   int N, int K, int epilogue, mi_stream stream) {
+  int rc = check_gemm(x, w_packed, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (!scale || !aligned16(scale)) return MI_EINVAL;
+  if (K % 64) return MI_EUNSUPPORTED;
+  if (epilogue != 0 && epilogue != 1) return MI_EINVAL;
+  if (epilogue == 1 && N % 32) return MI_EUNSUPPORTED;
+  if (M == 0) return MI_OK;
+  GemmArgs a{x, reinterpret_cast<const uint16_t*>(w_packed), nullptr, y, nullptr, M, N, K, 1, S(stream)};
+  a.scale = scale;
+  if (epilogue == 1) return pick_mt<2, 2, EPI_SILU>(a);
+  if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, 2, EPI_NONE>(a);
+  return pick_mt<1, 2, EPI_NONE>(a);
+}
+
+extern "C" int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
+                                          float* partials, int M, int N, int K, int ksplit, mi_stream stream) {
+  int rc = check_gemm(x, w_packed, partials, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (!scale || !aligned16(scale)) return MI_EINVAL;
+  if (ksplit < 1 || ksplit > 16 || K % (64 * ksplit)) return MI_EUNSUPPORTED;
+  if (M == 0) return MI_OK;
+  GemmArgs a{x, reinterpret_cast<const uint16_t*>(w_packed), nullptr, nullptr, partials, M, N, K, ksplit, S(stream)};
+  a.scale = scale;
+  return pick_mt<1, 2, EPI_PARTIAL>(a);
 }

@@ -82,6 +82,9 @@ _SIGNATURES = {
     "mi_sample": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_uint64, c_uint64, _p]),
     "mi_xxh64_chain": (c_uint64, [_p, c_size_t, c_int, c_uint64]),
     "mi_xxh64_chain_blocks": (c_int, [_p, c_int, c_int, c_int, c_uint64, _p]),
+    "mi_pack_weight_fp8": (c_int, [_p, _p, c_int, c_int, _p]),
+    "mi_gemm_fp8w_packed": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_gemm_fp8w_packed_splitk": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
     "mi_comm_region_bytes": (c_size_t, [c_int, c_size_t]),
     "mi_comm_region_alloc": (c_int, [c_size_t, ctypes.POINTER(_p), _p]),
     "mi_comm_region_open": (c_int, [_p, ctypes.POINTER(_p)]),

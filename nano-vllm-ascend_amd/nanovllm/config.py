@@ -45,6 +45,7 @@ class Config:
     device: str = "cuda"
     trust_remote_code: bool = False
     synthetic_seed: int = 0
+    quantization: str | None = None  # "fp8": e4m3 weights + per-row scales for the decode GEMMs (no reference counterpart)
     prefix_aware_prefill: bool = True  # skip the tokens of cache-hit prefix blocks in prefill (False: recompute, as the reference)
 
     def __post_init__(self):
@@ -52,6 +53,7 @@ class Config:
         assert self.kvcache_block_size % 16 == 0
         assert 1 <= self.tensor_parallel_size <= 8
         assert self.graph_mode in {m.value for m in GraphMode}, self.graph_mode
+        assert self.quantization in (None, "fp8"), self.quantization
         if self.hf_config is None:
             from transformers import AutoConfig
 

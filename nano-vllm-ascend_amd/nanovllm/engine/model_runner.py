@@ -89,6 +89,9 @@ class ModelRunner:
         dtype = _torch_dtype_of(self.hf_config)
         if dtype != torch.bfloat16:
             raise NotImplementedError(f"the gfx950 kernels are bf16; checkpoint dtype is {dtype}")
+        from nanovllm.layers.linear import set_weight_quantization
+
+        set_weight_quantization(config.quantization)
         prev = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:

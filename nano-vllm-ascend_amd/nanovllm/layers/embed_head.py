@@ -6,7 +6,7 @@ import torch.distributed as dist
 from torch import nn
 
 from nanovllm import ops
-from nanovllm.layers.linear import can_pack, linear_forward
+from nanovllm.layers.linear import pack_for_decode, linear_forward
 from nanovllm.layers.parallel import all_reduce_sum, tp_rank, tp_size
 from nanovllm.utils.context import get_context
 
@@ -42,7 +42,7 @@ class ParallelLMHead(VocabParallelEmbedding):
         self.weight_packed = None
 
     def pack(self) -> None:
-        self.weight_packed = ops.pack_weight(self.weight.data, self.weight_packed) if can_pack(self.weight.data) else None
+        self.weight_packed = pack_for_decode(self.weight.data, self.weight_packed)
 
     def forward(self, x: torch.Tensor):
         context = get_context()

@@ -19,6 +19,9 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
                    packed: torch.Tensor | None = None) -> torch.Tensor:
     rows = x.numel() // x.shape[-1]
     if rows <= ops.SKINNY_MAX_M and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0:
+        if isinstance(packed, ops.Fp8Weight):  # the fp8 GEMM has no bias operand
+            y = ops.gemm_packed(x, packed)
+            return y if bias is None else y.add_(bias)
         if packed is not None:
             return ops.gemm_packed(x, packed, bias)
         return ops.gemm_skinny(x, weight, bias)
@@ -28,6 +31,29 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
 
 def can_pack(weight: torch.Tensor) -> bool:
     return weight.is_cuda and weight.dim() == 2 and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0
+
+
+_QUANTIZATION: str | None = None  # set by the runner from Config.quantization before weights are packed
+
+
+def set_weight_quantization(mode: str | None) -> None:
+    assert mode in (None, "fp8"), mode
+    global _QUANTIZATION
+    _QUANTIZATION = mode
+
+
+def pack_for_decode(weight: torch.Tensor, previous):
+    """The decode-GEMM copy of a (sharded) weight: fragment-native bf16, or - Config.quantization == "fp8" -
+    fragment-native e4m3 + per-row scale.  In fp8 mode the bf16 parameter itself is replaced by the
+    dequantised values, so the prefill (library GEMM) and anything tied to it see the same model."""
+    if not can_pack(weight):
+        return None
+    if _QUANTIZATION == "fp8" and weight.shape[1] % 64 == 0:
+        packed = ops.pack_weight_fp8(weight, previous if isinstance(previous, ops.Fp8Weight) else None)
+        q, scale = ops.quantize_fp8(weight)
+        weight.copy_(ops.dequantize_fp8(q, scale).to(weight.dtype))
+        return packed
+    return ops.pack_weight(weight, previous if isinstance(previous, torch.Tensor) else None)
 
 
 class LinearBase(nn.Module):
@@ -48,7 +74,7 @@ class LinearBase(nn.Module):
     def pack(self) -> None:
         """Build the fragment-native copy of the (already sharded) weight that the decode GEMMs
         stream (mi_pack_weight); call again after the weight changes."""
-        self.weight_packed = ops.pack_weight(self.weight.data, self.weight_packed) if can_pack(self.weight.data) else None
+        self.weight_packed = pack_for_decode(self.weight.data, self.weight_packed)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError

@@ -247,10 +247,49 @@ def pack_weight(w, out=None) -> torch.Tensor:
     return out
 
 
+class Fp8Weight:
+    """Fragment-native e4m3 copy of a [N, K] weight plus one fp32 scale per row (mi_pack_weight_fp8)."""
+    __slots__ = ("data", "scale", "shape")
+
+    def __init__(self, data: torch.Tensor, scale: torch.Tensor, shape):
+        self.data, self.scale, self.shape = data, scale, tuple(shape)
+
+
+FP8_MAX = 448.0  # largest finite OCP e4m3 value
+
+
+def quantize_fp8(w: torch.Tensor):
+    """Per-row symmetric quantisation: (uint8 view of e4m3 [N, K], fp32 scale [N]).  The scale is a
+    power of two (row maximum lands in [128, 256) of e4m3's +-448): e4m3 is a floating-point format, so a
+    power-of-two scale costs no precision, and scaling by it is exact - CPU and GPU produce the same bytes."""
+    wf = w.float()
+    _, exp = torch.frexp(wf.abs().amax(dim=1))          # amax = m * 2^exp, m in [0.5, 1)
+    exp = torch.where(wf.abs().amax(dim=1) > 0, exp, torch.zeros_like(exp))
+    scale = torch.ldexp(torch.ones_like(wf[:, 0]), exp - 8)
+    q = torch.ldexp(wf, (8 - exp)[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def dequantize_fp8(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q_u8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+def pack_weight_fp8(w, out: Fp8Weight | None = None) -> Fp8Weight:
+    """Quantise a bf16 [N, K] weight and lay it out for mi_gemm_fp8w_packed (refreshes `out` in place)."""
+    require_gpu(w)
+    assert w.dim() == 2 and w.is_contiguous() and w.shape[0] % 16 == 0 and w.shape[1] % 64 == 0
+    q, scale = quantize_fp8(w)
+    if out is None or out.shape != tuple(w.shape) or out.data.device != w.device:
+        out = Fp8Weight(torch.empty_like(q), torch.empty_like(scale), w.shape)
+    out.scale.copy_(scale)
+    check(lib.mi_pack_weight_fp8(ptr(q), ptr(out.data), w.shape[0], w.shape[1], stream()), "mi_pack_weight_fp8")
+    return out
+
+
 def gemm_packed(x, w_packed, bias=None, out=None, silu_mul: bool = False) -> torch.Tensor:
-    require_gpu(x, w_packed, bias)
-    _bf16(x, w_packed, bias)
-    assert x.is_contiguous() and w_packed.is_contiguous()
+    require_gpu(x, bias)
+    _bf16(x, bias)
+    assert x.is_contiguous()
     K = x.shape[-1]
     M = x.numel() // K
     N = w_packed.shape[0]
@@ -258,6 +297,14 @@ def gemm_packed(x, w_packed, bias=None, out=None, silu_mul: bool = False) -> tor
     n_out = N // 2 if silu_mul else N
     if out is None:
         out = torch.empty((*x.shape[:-1], n_out), dtype=_BF16, device=x.device)
+    if isinstance(w_packed, Fp8Weight):
+        assert bias is None
+        check(lib.mi_gemm_fp8w_packed(ptr(x), ptr(w_packed.data), ptr(w_packed.scale), ptr(out), M, N, K,
+                                      int(silu_mul), stream()), "mi_gemm_fp8w_packed")
+        return out
+    require_gpu(w_packed)
+    _bf16(w_packed)
+    assert w_packed.is_contiguous()
     check(lib.mi_gemm_bf16_packed(ptr(x), ptr(w_packed), ptr(bias), ptr(out), M, N, K, int(silu_mul), stream()),
           "mi_gemm_bf16_packed")
     return out
@@ -265,13 +312,19 @@ def gemm_packed(x, w_packed, bias=None, out=None, silu_mul: bool = False) -> tor
 
 def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:
     """fp32 partials [ksplit, M, N] of x @ w.T; consume with add_rmsnorm_splitk."""
-    require_gpu(x, w_packed)
-    _bf16(x, w_packed)
+    require_gpu(x)
+    _bf16(x)
     K = x.shape[-1]
     M = x.numel() // K
     N = w_packed.shape[0]
     if out is None:
         out = torch.empty((ksplit, M, N), dtype=torch.float32, device=x.device)
+    if isinstance(w_packed, Fp8Weight):
+        check(lib.mi_gemm_fp8w_packed_splitk(ptr(x), ptr(w_packed.data), ptr(w_packed.scale), ptr(out), M, N, K,
+                                             ksplit, stream()), "mi_gemm_fp8w_packed_splitk")
+        return out
+    require_gpu(w_packed)
+    _bf16(w_packed)
     check(lib.mi_gemm_bf16_packed_splitk(ptr(x), ptr(w_packed), ptr(out), M, N, K, ksplit, stream()),
           "mi_gemm_bf16_packed_splitk")
     return out

@@ -69,7 +69,7 @@ def _oracle_for(llm, cfg_dict, seed):
                        llm.config.kvcache_block_size)
 
 
-def _engine_vs_oracle(cfg, lens, enforce_eager, seed, tol, max_tokens=6):
+def _engine_vs_oracle(cfg, lens, enforce_eager, seed, tol, max_tokens=6, quantization=None):
     """Per-step logits of the engine vs the fp32-internal CPU oracle driven by the same schedule
     and fed the same (oracle-greedy) tokens."""
     from nanovllm import LLM, SamplingParams
@@ -77,9 +77,17 @@ def _engine_vs_oracle(cfg, lens, enforce_eager, seed, tol, max_tokens=6):
 
     llm = LLM(make_model_dir(cfg), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
               max_model_len=512, num_kvcache_blocks=80, enforce_eager=enforce_eager, warmup=False,
-              synthetic_seed=seed)
+              synthetic_seed=seed, quantization=quantization)
     try:
         oracle = _oracle_for(llm, cfg, seed)
+        if quantization == "fp8":  # the oracle runs on the dequantised (bf16-rounded) weights, as the prefill does
+            from nanovllm import ops
+
+            for name, w in oracle.w.items():
+                if w.dim() == 2 and ("proj" in name or name in ("lm_head.weight", "model.embed_tokens.weight")):
+                    if name == "model.embed_tokens.weight" and not cfg["tie_word_embeddings"]:
+                        continue
+                    oracle.w[name] = ops.dequantize_fp8(*ops.quantize_fp8(w)).to(w.dtype)
         gen = torch.Generator().manual_seed(3)
         prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=gen).tolist() for n in lens]
         for p in prompts:
@@ -119,6 +127,14 @@ def test_engine_matches_oracle_model(enforce_eager):
     the two pipelines share every rounding point and differ by fp32 summation order before each
     bf16 rounding, which occasionally flips an intermediate by one ulp; observed 2.3e-2)."""
     _engine_vs_oracle(MID, [5, 16, 17, 63, 130, 31], enforce_eager, seed=11, tol=4e-2)
+
+
+def test_engine_fp8_weights_match_oracle_on_dequantised_weights():
+    """BASELINE.json configs[4] (fp8 weights): e4m3 + per-row scales for every projection and the
+    head; decode runs the fp8-weight GEMMs (exact w_q * scale), prefill the library GEMM on the
+    bf16-rounded dequantised weights - the oracle uses the latter, so the bound is the bf16 engine's
+    plus the 2^-9 relative difference between the two weight representations."""
+    _engine_vs_oracle(MID, [5, 16, 17, 63, 130, 31], enforce_eager=False, seed=11, tol=6e-2, quantization="fp8")
 
 
 def test_engine_matches_oracle_qwen3_32b_widths():

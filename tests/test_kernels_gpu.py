@@ -383,6 +383,40 @@ def test_decode_attention_golden(ops, golden_attention):
     assert (out.float() - want).abs().max().item() <= 8e-3  # half a bf16 ulp at |o|<=2 + fp32 noise
 
 
+# --------------------------------------------------------------------------- fp8 weights
+@pytest.mark.parametrize("M", [1, 32, 64])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (256, 128), (151936, 1024)])
+def test_gemm_fp8_weights(ops, M, N, K):
+    """e4m3 weights + per-row fp32 scale, bf16 activations: y = x @ (w_q * scale)^T, one rounding.
+    The oracle multiplies the dequantised weights in fp32; the kernel multiplies exact bf16 copies of
+    w_q and scales the fp32 sums - equal up to fp32 rounding, i.e. <= 1 bf16 ulp on a few outputs."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.02).bfloat16()
+    q, scale = ops.quantize_fp8(w)
+    # the GPU quantiser produces the same bytes as the CPU one
+    fw = ops.pack_weight_fp8(w.to(DEV))
+    qg, sg = ops.quantize_fp8(w.to(DEV))
+    assert torch.equal(qg.cpu(), q) and torch.equal(sg.cpu(), scale)
+    wd = ops.dequantize_fp8(q, scale)
+    assert (wd - w.float()).abs().max() <= w.float().abs().amax(dim=1).max() / 16  # e4m3: 3 mantissa bits
+    want32 = x.float() @ wd.T
+    want = want32.bfloat16()
+    got = ops.gemm_packed(x.to(DEV), fw).cpu()
+    assert_bf16_close(got, want, max_ulp=1, max_frac=0.02, atol=K * 2.0 ** -22)
+    if N <= 2048:
+        for ks in (2, 4):
+            if K % (64 * ks):
+                continue
+            parts = ops.gemm_packed_splitk(x.to(DEV), fw, ks).cpu()
+            assert_bf16_close(parts.sum(0).bfloat16(), want, max_ulp=1, max_frac=0.02, atol=K * 2.0 ** -22)
+    if N == 6144:
+        act = ops.gemm_packed(x.to(DEV), fw, silu_mul=True).cpu()
+        gate, up = want[:, : N // 2].float(), want[:, N // 2:].float()
+        ref = (torch.nn.functional.silu(gate).bfloat16().float() * up).bfloat16()
+        assert_bf16_close(act, ref, max_ulp=2, max_frac=0.05, atol=32 * K * 2.0 ** -22)
+
+
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (64, 8), (16, 1)])
 @pytest.mark.parametrize("block_size", [16, 64, 256])
 def test_decode_attention_random(ops, hq, hkv, block_size):
