@@ -20,5 +20,24 @@ def main(path, top=30):
         print(f"{r[0][:100]:100s} {r[1]:7d} {r[2]:9.2f} {r[3]:9.2f} {r[4]:9.2f} {r[5]:11.1f} {100 * r[5] / total:6.2f}")
 
 
+def last_n(path, kernel_substr, n):
+    """Average duration of the LAST n dispatches of the kernels whose name contains kernel_substr
+    (bench.py's roofline loop is the tail of the run)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    q = f"""select (d.end - d.start) / 1000.0 from {kd} d join {ks} s on d.kernel_id = s.id
+            where s.kernel_name like ? order by d.start"""
+    vals = [r[0] for r in cur.execute(q, (f"%{kernel_substr}%",))]
+    tail = vals[-n:]
+    print(f"last {len(tail)} of {len(vals)} dispatches of *{kernel_substr}*: avg {sum(tail) / len(tail):.2f} us "
+          f"min {min(tail):.2f} max {max(tail):.2f}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 30)
+    if len(sys.argv) > 4 and sys.argv[2] == "--last":
+        last_n(sys.argv[1], sys.argv[3], int(sys.argv[4]))
+    else:
+        main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 30)
