@@ -114,7 +114,9 @@ class ModelRunner:
         self._alloc_staging()
         self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
         self.graph_logits: dict[int, torch.Tensor] = {}
-        if config.use_graphs and not (self.world_size > 1 and dist.get_backend() != "nccl"):
+        # with TP the captured graph holds the xGMI exchange kernels; without them (RCCL all-reduce inside)
+        # capture is only attempted on the nccl backend
+        if config.use_graphs and (self.world_size == 1 or self.xgmi is not None or dist.get_backend() == "nccl"):
             try:
                 self.capture_decode_graphs()
             except Exception as e:  # e.g. a collective that refuses stream capture: run eagerly instead
@@ -294,13 +296,13 @@ class ModelRunner:
                         block_size=self.block_size)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # warm-up run outside capture (workspaces, RCCL channels)
-                self.model.compute_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
+            with torch.cuda.stream(side):  # warm-up run outside capture (workspaces, exchange epochs)
+                self.model.lm_head.local_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=pool):
-                logits = self.model.compute_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
+            with torch.cuda.graph(graph, pool=pool):  # kernels only: the logits gather of TP stays outside
+                logits = self.model.lm_head.local_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
             pool = pool or graph.pool()
             self.graphs[bs] = graph
             self.graph_logits[bs] = logits
@@ -319,7 +321,7 @@ class ModelRunner:
         if is_prefill or bucket is None or bucket not in self.graphs:
             return self.model.compute_logits(self.model(input_ids, positions))
         self.graphs[bucket].replay()
-        return self.graph_logits[bucket]
+        return self.model.lm_head.gather(self.graph_logits[bucket])
 
     @torch.inference_mode()
     def run(self, seqs: list[Sequence], is_prefill: bool) -> list[int] | None:

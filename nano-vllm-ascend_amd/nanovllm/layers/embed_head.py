@@ -44,19 +44,28 @@ class ParallelLMHead(VocabParallelEmbedding):
     def pack(self) -> None:
         self.weight_packed = pack_for_decode(self.weight.data, self.weight_packed)
 
-    def forward(self, x: torch.Tensor):
+    def local_logits(self, x: torch.Tensor) -> torch.Tensor:
+        """This rank's vocabulary shard of the logits (kernels only: what a decode graph captures)."""
         context = get_context()
         if context.is_prefill:  # keep only each sequence's last token (embed_head.py:58-60)
             x = ops.gather_last_tokens(x, context.cu_seqlens_q)
-        logits = linear_forward(x, self.weight, None, self.weight_packed)
-        if self.tp_size > 1:  # vocab shards -> rank 0 (embed_head.py:62-65)
-            if dist.get_backend() == "nccl":
-                parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
-                dist.gather(logits, parts, 0)
-                logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
-            else:  # gloo has no device-side gather: place the shard in a zero buffer and sum (tests only)
-                full = torch.zeros((logits.shape[0], self.num_embeddings), dtype=logits.dtype, device=logits.device)
-                full[:, self.vocab_start_idx:self.vocab_end_idx] = logits
-                dist.all_reduce(full)
-                logits = full if self.tp_rank == 0 else None
-        return logits
+        return linear_forward(x, self.weight, None, self.weight_packed)
+
+    def gather(self, logits: torch.Tensor):
+        """Vocabulary shards -> rank 0 (embed_head.py:62-65); None on the other ranks.  A collective of the
+        process group (RCCL), kept outside captured graphs - as the reference keeps compute_logits
+        outside its compiled graph (model_runner.py:394-396)."""
+        if self.tp_size == 1:
+            return logits
+        if dist.get_backend() == "nccl":
+            parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+            dist.gather(logits, parts, 0)
+            return torch.cat(parts, -1) if self.tp_rank == 0 else None
+        # gloo has no device-side gather: place the shard in a zero buffer and sum (tests only)
+        full = torch.zeros((logits.shape[0], self.num_embeddings), dtype=logits.dtype, device=logits.device)
+        full[:, self.vocab_start_idx:self.vocab_end_idx] = logits
+        dist.all_reduce(full)
+        return full if self.tp_rank == 0 else None
+
+    def forward(self, x: torch.Tensor):
+        return self.gather(self.local_logits(x))

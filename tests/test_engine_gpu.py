@@ -166,11 +166,13 @@ def test_generate_api_and_prefix_cache_accounting():
         llm.exit()
 
 
-def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch):
+@pytest.mark.parametrize("enforce_eager", [True, False])
+def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, enforce_eager):
     """Functional tensor-parallel run on a 1-GPU box: two rank processes share cuda:0 and talk over
     gloo (MI355_DIST_BACKEND) - the same sharded layers, RPC channel and collectives call sites as
-    the RCCL path, eager mode.  Greedy tokens must equal the TP=1 run; logits agree to bf16 noise
-    (the K-sum of the row-parallel projections is split differently)."""
+    the RCCL path.  Eager, and with the decode step captured in hipGraphs (the exchange kernels are
+    captured; the logits gather stays outside).  Greedy tokens must equal the TP=1 run; logits agree
+    to bf16 noise (the K-sum of the row-parallel projections is split differently)."""
     import socket
 
     from nanovllm import LLM, SamplingParams
@@ -184,11 +186,12 @@ def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch):
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
-                  max_model_len=512, num_kvcache_blocks=64, enforce_eager=True, warmup=False, synthetic_seed=3,
-                  tensor_parallel_size=tp, hccl_port=port)
+                  max_model_len=512, num_kvcache_blocks=64, enforce_eager=enforce_eager, warmup=False,
+                  synthetic_seed=3, tensor_parallel_size=tp, hccl_port=port)
         try:
             if tp > 1:  # the decode-sized all-reduces go through the xGMI kernel (self-test passed at start-up)
                 assert llm.model_runner.xgmi is not None
+                assert bool(llm.model_runner.graphs) == (not enforce_eager)
             outs = llm.generate(prompts, sp, use_tqdm=False)
             return [o["token_ids"] for o in outs], llm.model_runner.last_logits.float().cpu()
         finally:
