@@ -322,3 +322,58 @@ def test_prefix_aware_prefill_matches_full_recompute_oracle():
         assert worst <= 4e-2, worst
     finally:
         llm.exit()
+
+
+def test_full_size_properties_paging_invariance_and_decode_equals_reprefill():
+    """Size-independent properties at the bench's shape (Qwen3-0.6B, 28 layers, 1024-token prompts),
+    where the CPU oracle is too slow to follow:
+      * paging invariance - which physical blocks hold a sequence is invisible: the same prompts give
+        bit-identical logits when the free list has been scrambled by earlier traffic (different
+        block tables, same batch composition);
+      * decode == re-prefill - the logits of decode step k equal, within bf16 noise, the last-token
+        logits of a fresh prefill over prompt + the k tokens generated so far (the reference's own
+        CPU path shows 3.9e-2 here)."""
+    from nanovllm import LLM, SamplingParams
+    from model_configs import QWEN3_0_6B
+
+    gen = torch.Generator().manual_seed(1024)
+    prompts = [torch.randint(0, 10000, (n,), generator=gen).tolist() for n in (1024, 1024, 1009, 777)]
+    sp = SamplingParams(max_tokens=4, ignore_eos=True, greedy=True)
+
+    def run(llm, batch):
+        seqs = [llm.add_request(p, sp) for p in batch]
+        logits, tables = [], []
+        while not llm.is_finished():
+            sched, is_prefill = llm.scheduler.schedule()
+            tables.append([list(x.block_table) for x in sched])
+            toks = llm.model_runner.call("run", sched, is_prefill)
+            logits.append(llm.model_runner.last_logits[: len(sched)].clone())
+            llm.scheduler.postprocess(sched, toks)
+        return logits, tables, [list(x.completion_token_ids) for x in seqs]
+
+    llm = LLM(make_model_dir(QWEN3_0_6B), kvcache_block_size=16, max_num_seqs=4, max_num_batched_tokens=4096,
+              max_model_len=4096, num_kvcache_blocks=700, warmup=False, synthetic_seed=0)
+    try:
+        a_logits, a_tables, a_tokens = run(llm, prompts)
+        # scramble the free list: short unrelated requests finish at different times
+        noise = [torch.randint(10000, 20000, (n,), generator=gen).tolist() for n in (40, 7, 130)]
+        for p, mt in zip(noise, (2, 5, 3)):
+            llm.add_request(p, SamplingParams(max_tokens=mt, ignore_eos=True, greedy=True))
+        while not llm.is_finished():
+            llm.step()
+        llm.scheduler.block_manager.hash_to_block_id.clear()  # no prefix hits: the same work is redone
+        b_logits, b_tables, b_tokens = run(llm, prompts)
+        assert a_tables != b_tables and a_tokens == b_tokens
+        for x, y in zip(a_logits, b_logits):
+            assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+        # decode == re-prefill, for the first sequence and every decode step
+        llm.scheduler.block_manager.hash_to_block_id.clear()
+        worst = 0.0
+        for k in range(1, len(a_logits)):
+            ext = prompts[0] + a_tokens[0][:k]
+            c_logits, _, _ = run(llm, [ext])
+            llm.scheduler.block_manager.hash_to_block_id.clear()
+            worst = max(worst, (c_logits[0][0].float() - a_logits[k][0].float()).abs().max().item())
+        assert worst <= 8e-2, worst
+    finally:
+        llm.exit()
