@@ -2,6 +2,8 @@
 // All of them are HBM- or latency-bound: 16-byte vector accesses, one rounding
 // point per reference rounding point (compiled with -ffp-contract=off so the
 // fp32 sequences match the reference's unfused torch ops bit for bit).
+#include <stdlib.h>
+
 #include "mi_common.hpp"
 #include "kv_store.hpp"
 
@@ -93,6 +95,81 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
         o[j] = pack_bf(a, b);
       }
       *reinterpret_cast<u32x4*>(y + yoff + vec * 8) = o;
+    }
+  }
+}
+
+// Decode-sized split-K consumer (<= 64 rows): the same arithmetic with WPR waves per row, so a lane
+// has 1/WPR of the partial loads in flight (a row of 1024 columns with 4 splits is 16 fragment loads per
+// lane for one wave, 4 for four).  Sum of squares: lane partials -> wave shuffle tree -> the WPR wave
+// sums added in wave order through LDS.
+template <int PART, int WPR>
+__global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
+    const float* __restrict__ part, const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
+    uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows, int cols, float eps) {
+  __shared__ float wave_ss[WPR];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = cols >> 3;
+  const int64_t off = (int64_t)row * cols;
+  constexpr int MAXV = 2;  // vectors per lane: cols <= WPR * 64 * 8 * MAXV
+  float v[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vec = tid + i * WPR * 64;
+    if (vec < nvec) {
+      f32x4 plo[PART], phi[PART];
+#pragma unroll
+      for (int sp = 0; sp < PART; ++sp) {
+        const float* pp = part + ((int64_t)sp * rows + row) * cols + vec * 8;
+        plo[sp] = *reinterpret_cast<const f32x4*>(pp);
+        phi[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
+      }
+      const u32x4 rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
+      f32x4 lo = plo[0], hi = phi[0];
+#pragma unroll
+      for (int sp = 1; sp < PART; ++sp) {
+        lo += plo[sp];
+        hi += phi[sp];
+      }
+      const u32x4 raw = {pack_bf(lo[0], lo[1]), pack_bf(lo[2], lo[3]), pack_bf(hi[0], hi[1]), pack_bf(hi[2], hi[3])};
+      u32x4 ro;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = lo_bf(raw[j]) + lo_bf(rr[j]);
+        const float b = hi_bf(raw[j]) + hi_bf(rr[j]);
+        ro[j] = pack_bf(a, b);
+        v[i][2 * j] = a;
+        v[i][2 * j + 1] = b;
+        ss += a * a;
+        ss += b * b;
+      }
+      *reinterpret_cast<u32x4*>(residual_out + off + vec * 8) = ro;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) wave_ss[wave] = ss;
+  __syncthreads();
+  float tot = wave_ss[0];
+#pragma unroll
+  for (int wv = 1; wv < WPR; ++wv) tot += wave_ss[wv];
+  const float rs = 1.0f / sqrtf(tot / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vec = tid + i * WPR * 64;
+    if (vec < nvec) {
+      const u32x4 wr = *reinterpret_cast<const u32x4*>(w + vec * 8);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = rbf(v[i][2 * j] * rs) * lo_bf(wr[j]);
+        const float b = rbf(v[i][2 * j + 1] * rs) * hi_bf(wr[j]);
+        o[j] = pack_bf(a, b);
+      }
+      *reinterpret_cast<u32x4*>(y + off + vec * 8) = o;
     }
   }
 }
@@ -561,8 +638,23 @@ extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi
   if (!aligned16(partials) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
     return MI_EINVAL;
   if (rows == 0) return MI_OK;
+  // decode-sized: WPR waves per row (env MI355_NORM_WPR=1 keeps the one-wave-per-row kernel)
+  static const int wpr = [] {
+    const char* e = getenv("MI355_NORM_WPR");
+    return e ? atoi(e) : 4;
+  }();
 #define SPLITK_CASE(NS)                                                                                       \
   case NS:                                                                                                    \
+    if (rows <= 64 && wpr == 4 && cols <= 4 * 64 * 8 * 2) {                                                   \
+      hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<NS, 4>), dim3(rows), dim3(256), 0, S(stream),         \
+                         partials, residual, w, y, residual_out, rows, cols, eps);                            \
+      return check_launch();                                                                                  \
+    }                                                                                                         \
+    if (rows <= 64 && wpr == 2 && cols <= 2 * 64 * 8 * 2) {                                                   \
+      hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<NS, 2>), dim3(rows), dim3(128), 0, S(stream),         \
+                         partials, residual, w, y, residual_out, rows, cols, eps);                            \
+      return check_launch();                                                                                  \
+    }                                                                                                         \
     return launch_rmsnorm<true, NS>(nullptr, partials, nsplit, (int64_t)cols, 1, residual, w, y, residual_out, rows, \
                                     cols, eps, S(stream))
   switch (nsplit) {
