@@ -760,9 +760,15 @@ extern "C" int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride, 
                        n_tokens, n_q_heads, n_kv_heads, block_size);
     return check_launch();
   }
-  hipLaunchKernelGGL((qk_rope_store_kernel<0>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), qkv,
-                     qkv_row_stride, ksrc, qkv_row_stride, vsrc, qkv_row_stride, q_w, k_w, eps, positions,
-                     cos_sin, q_out, nullptr, k_cache, v_cache, slots, slot_is_2d, n_tokens, n_q_heads,
+  // decode-sized: one wave per workgroup, so the (token, head) groups spread over four times as many CUs
+  static const int small_blocks = [] {
+    const char* e = getenv("MI355_ROPE_BLOCK64");
+    return e ? atoi(e) : 1;
+  }();
+  const int threads = (n_tokens <= 64 && small_blocks) ? 64 : 256;
+  hipLaunchKernelGGL((qk_rope_store_kernel<0>), dim3((unsigned)((hs * 8 + threads - 1) / threads)), dim3(threads), 0,
+                     S(stream), qkv, qkv_row_stride, ksrc, qkv_row_stride, vsrc, qkv_row_stride, q_w, k_w, eps,
+                     positions, cos_sin, q_out, nullptr, k_cache, v_cache, slots, slot_is_2d, n_tokens, n_q_heads,
                      n_kv_heads, block_size, 0);
   return check_launch();
 }
