@@ -1,52 +1,63 @@
-"""Per-step metadata side channel between the model runner and the layers
-(reference: nanovllm/utils/context.py:5-37 — same field names, same three
-functions, so layers written against the reference read the same attributes).
+"""Per-step metadata side channel between the model runner and the layers.
 
-Added fields (None / 0 in code written against the reference):
-  kv_lens     [n_seqs] int32 — tokens of each sequence present in the KV cache during
-              prefill (== query lengths in the reference, which recomputes cached
-              prefixes: model_runner.py:248-249).
-  slot_is_2d  decode slot mapping is [B,2] = [block, offset] (model_runner.py:301,353),
-              prefill's is flat (:263-270).
+The reference keeps one module-level record that `Attention.forward` and `ParallelLMHead.forward`
+read (nanovllm/utils/context.py:5-37); layers written against it expect the attribute names below
+and the three accessor functions, so those are the contract kept here.  One field is added:
+
+  kv_lens  [n_seqs] int32 - tokens of each sequence present in the KV cache during prefill.  Equal to
+           the query lengths in the reference (it recomputes cached prefixes, model_runner.py:248-249);
+           larger when prefix-aware prefill skips cache-hit blocks.
+
+The slot mapping is flat int32 [T] in prefill (model_runner.py:263-270) and [B, 2] = [block, offset]
+in decode (:301,353); consumers tell them apart by `slot_mapping.dim()`.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+# attribute -> value when a step does not set it
+_DEFAULTS = {
+    "is_prefill": False,
+    "cu_seqlens_q": None,      # int32 [n_seqs + 1]
+    "cu_seqlens_k": None,
+    "max_seqlen_q": 0,
+    "max_seqlen_k": 0,
+    "slot_mapping": None,
+    "context_lens": None,      # int32 [B], decode
+    "block_tables": None,      # int32 [rows, width], -1 padded
+    "is_enforce_eager": True,
+    "real_bs": -1,
+    "block_size": 256,
+    "kv_lens": None,
+}
 
-import torch
 
-
-@dataclass
 class Context:
-    is_prefill: bool = False
-    cu_seqlens_q: torch.Tensor | None = None
-    cu_seqlens_k: torch.Tensor | None = None
-    max_seqlen_q: int = 0
-    max_seqlen_k: int = 0
-    slot_mapping: torch.Tensor | None = None
-    context_lens: torch.Tensor | None = None
-    block_tables: torch.Tensor | None = None
-    is_enforce_eager: bool = True
-    real_bs: int = -1
-    block_size: int = 256
-    kv_lens: torch.Tensor | None = None
+    __slots__ = tuple(_DEFAULTS)
+
+    def __init__(self, **fields):
+        unknown = set(fields) - set(_DEFAULTS)
+        if unknown:
+            raise TypeError(f"unknown context field(s): {sorted(unknown)}")
+        for name, default in _DEFAULTS.items():
+            setattr(self, name, fields.get(name, default))
+
+    def __repr__(self):
+        shown = ", ".join(f"{k}={getattr(self, k)!r}" for k in _DEFAULTS if getattr(self, k) is not _DEFAULTS[k])
+        return f"Context({shown})"
 
 
-_CONTEXT = Context()
+_current = Context()
 
 
 def get_context() -> Context:
-    return _CONTEXT
+    return _current
 
 
-def set_context(is_prefill, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0, max_seqlen_k=0,
-                slot_mapping=None, context_lens=None, block_tables=None, is_enforce_eager=None, real_bs=None,
-                block_size=None, kv_lens=None) -> None:
-    global _CONTEXT
-    _CONTEXT = Context(is_prefill, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, slot_mapping,
-                       context_lens, block_tables, is_enforce_eager, real_bs, block_size, kv_lens)
+def set_context(is_prefill, **fields) -> None:
+    """Install the metadata of the step about to run.  Fields passed as None keep their defaults."""
+    global _current
+    _current = Context(is_prefill=is_prefill, **{k: v for k, v in fields.items() if v is not None})
 
 
 def reset_context() -> None:
-    global _CONTEXT
-    _CONTEXT = Context()
+    global _current
+    _current = Context()
