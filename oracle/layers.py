@@ -186,3 +186,54 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
         out[a:e] = _attend(q[a:e], k, v, scale, n - (e - a))
     out = out.reshape(t, hq * d)
     return out if keep_fp32 else out.to(q.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp8 weights (BASELINE.json configs[4]).  The reference has no fp8 path: this is the published OCP
+# 8-bit floating point format E4M3 (1 sign, 4 exponent bits with bias 7, 3 mantissa bits, no infinities,
+# maximum 448, subnormals down to 2^-9) restated with integer arithmetic - independent of
+# torch.float8_e4m3fn, which the product's quantiser uses - plus the per-row power-of-two scale rule
+# of nanovllm.ops.quantize_fp8 (row maximum scaled into [128, 256)).
+def e4m3_encode(x: torch.Tensor) -> torch.Tensor:
+    """Round fp32 values (|x| <= 448) to E4M3, nearest even; returns the bytes (uint8)."""
+    x = x.double()
+    sign = (x < 0) | ((x == 0) & (torch.signbit(x)))
+    a = x.abs()
+    e = torch.floor(torch.log2(torch.where(a > 0, a, torch.ones_like(a)))).clamp(min=-6, max=8)
+    quantum = torch.pow(2.0, e - 3)                      # spacing of representable values in this binade
+    n = a / quantum                                      # in [8, 16) for normals, [0, 8) for subnormals
+    r = torch.floor(n)
+    frac = n - r
+    r = r + ((frac > 0.5) | ((frac == 0.5) & (r % 2 == 1))).double()   # ties to even
+    carry = r >= 16                                      # rounded up into the next binade
+    e = torch.where(carry, e + 1, e)
+    r = torch.where(carry, torch.full_like(r, 8.0), r)
+    is_sub = r < 8                                       # only possible at e == -6
+    exp_field = torch.where(is_sub, torch.zeros_like(e), e + 7)
+    mant = torch.where(is_sub, r, r - 8)
+    byte = (sign.long() << 7) | (exp_field.long() << 3) | mant.long()
+    assert int(byte.max()) <= 0xFF and not bool(((byte & 0x7F) == 0x7F).any()), "value outside E4M3's finite range"
+    return byte.to(torch.uint8)
+
+
+def e4m3_decode(b: torch.Tensor) -> torch.Tensor:
+    b = b.long()
+    sign = torch.where((b >> 7) == 1, -1.0, 1.0)
+    exp_field, mant = (b >> 3) & 0xF, (b & 7).double()
+    normal = torch.pow(2.0, exp_field.double() - 7) * (1 + mant / 8)
+    sub = torch.pow(torch.tensor(2.0, dtype=torch.float64), -6) * (mant / 8)
+    return (sign * torch.where(exp_field == 0, sub, normal)).float()
+
+
+def quantize_fp8_rows(w: torch.Tensor):
+    """(E4M3 bytes [N, K], fp32 scale [N]): scale = 2^(exponent of the row maximum - 8), 2^-8 for a zero row."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1)
+    exp = torch.where(amax > 0, torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) + 1,
+                      torch.zeros_like(amax))           # amax = m * 2^exp with m in [0.5, 1)
+    scale = torch.pow(2.0, exp - 8)
+    return e4m3_encode(wf / scale[:, None]), scale.float()
+
+
+def dequantize_fp8_rows(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return e4m3_decode(q) * scale[:, None]

@@ -81,13 +81,13 @@ def _engine_vs_oracle(cfg, lens, enforce_eager, seed, tol, max_tokens=6, quantiz
     try:
         oracle = _oracle_for(llm, cfg, seed)
         if quantization == "fp8":  # the oracle runs on the dequantised (bf16-rounded) weights, as the prefill does
-            from nanovllm import ops
+            from oracle import layers as oracle_layers
 
             for name, w in oracle.w.items():
                 if w.dim() == 2 and ("proj" in name or name in ("lm_head.weight", "model.embed_tokens.weight")):
                     if name == "model.embed_tokens.weight" and not cfg["tie_word_embeddings"]:
                         continue
-                    oracle.w[name] = ops.dequantize_fp8(*ops.quantize_fp8(w)).to(w.dtype)
+                    oracle.w[name] = oracle_layers.dequantize_fp8_rows(*oracle_layers.quantize_fp8_rows(w)).to(w.dtype)
         gen = torch.Generator().manual_seed(3)
         prompts = [torch.randint(0, cfg["vocab_size"], (n,), generator=gen).tolist() for n in lens]
         for p in prompts:

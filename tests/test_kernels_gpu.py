@@ -393,12 +393,12 @@ def test_gemm_fp8_weights(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.02).bfloat16()
-    q, scale = ops.quantize_fp8(w)
-    # the GPU quantiser produces the same bytes as the CPU one
+    q, scale = oracle.quantize_fp8_rows(w)  # integer-arithmetic E4M3 restatement (oracle/layers.py)
+    # the product's quantiser, run on the GPU, produces the oracle's bytes and scales
     fw = ops.pack_weight_fp8(w.to(DEV))
     qg, sg = ops.quantize_fp8(w.to(DEV))
     assert torch.equal(qg.cpu(), q) and torch.equal(sg.cpu(), scale)
-    wd = ops.dequantize_fp8(q, scale)
+    wd = oracle.dequantize_fp8_rows(q, scale)
     assert (wd - w.float()).abs().max() <= w.float().abs().amax(dim=1).max() / 16  # e4m3: 3 mantissa bits
     want32 = x.float() @ wd.T
     want = want32.bfloat16()

@@ -191,3 +191,39 @@ def test_hash_kats_against_xxhash_package():
         h.update(k["chained_with_prefix"].to_bytes(8, "little"))
         h.update(nxt)
         assert h.intdigest() == k["chained"]
+
+
+def test_fp8_e4m3_restatement_and_product_quantiser_agree():
+    """oracle.e4m3_* restates OCP E4M3 with integer arithmetic; the product's quantiser
+    (nanovllm.ops.quantize_fp8, torch.float8_e4m3fn + ldexp) must produce the same bytes and scales,
+    including ties, subnormals, zeros and the format's extremes."""
+    from nanovllm import ops as product_ops
+
+    from oracle import layers as L
+
+    # every finite code decodes to what torch says, and re-encodes to itself
+    codes = torch.tensor([c for c in range(256) if (c & 0x7F) != 0x7F], dtype=torch.uint8)
+    vals = L.e4m3_decode(codes)
+    assert torch.equal(vals, codes.view(torch.float8_e4m3fn).float())
+    assert torch.equal(L.e4m3_encode(vals), codes)
+    assert float(vals.abs().max()) == 448.0 and float(vals[vals > 0].min()) == 2.0 ** -9
+    # exact midpoints between neighbours round to the even mantissa
+    pos = vals[(vals > 0)].sort().values
+    mids = (pos[:-1] + pos[1:]) / 2
+    enc = L.e4m3_encode(mids)
+    assert torch.equal(enc, mids.to(torch.float8_e4m3fn).view(torch.uint8))
+    assert bool(((enc & 1) == 0).all())
+    # row-wise quantiser: random weights, a zero row, a row of one huge value, tiny values
+    g = torch.Generator().manual_seed(8)
+    w = (torch.randn(64, 256, generator=g) * 0.02).bfloat16()
+    w[3] = 0
+    w[5, 7] = 300.0
+    w[9] *= 1e-6
+    q_o, s_o = L.quantize_fp8_rows(w)
+    q_p, s_p = product_ops.quantize_fp8(w)
+    assert torch.equal(s_o, s_p) and torch.equal(q_o, q_p)
+    assert torch.equal(L.dequantize_fp8_rows(q_o, s_o), product_ops.dequantize_fp8(q_p, s_p))
+    rel = ((L.dequantize_fp8_rows(q_o, s_o) - w.float()).abs() / w.float().abs().clamp_min(1e-30))[w.float().abs() > 0]
+    amax = w.float().abs().amax(dim=1, keepdim=True).expand_as(w)[w.float().abs() > 0]
+    normal = w.float().abs()[w.float().abs() > 0] >= amax * 2.0 ** -13  # above the subnormal range of the row
+    assert float(rel[normal].max()) <= 2.0 ** -4 + 1e-6  # half a unit in the last of 3 mantissa bits
