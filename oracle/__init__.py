@@ -23,11 +23,19 @@ Pinning status
   model / scheduler / block-manager classes gives golden greedy tokens and
   logits (``tests/golden/tiny_model.npz``).
 
+* fp8 weights (no reference counterpart): ``e4m3_encode/decode`` restate the published OCP E4M3
+  format with integer arithmetic; pinned against torch's float8_e4m3fn on all 254 finite codes and
+  all midpoints (tests/test_oracle_golden.py).
+
 Rounding points follow the reference file:line cited on each function; where the
 reference delegates to torch's bf16 kernels (F.linear) the oracle accumulates in
 fp32 and rounds once, which is what those kernels do.
 """
 from oracle.layers import (  # noqa: F401
+    dequantize_fp8_rows,
+    e4m3_decode,
+    e4m3_encode,
+    quantize_fp8_rows,
     add_rms_norm,
     apply_rope,
     build_cos_sin_cache,
