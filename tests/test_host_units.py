@@ -380,3 +380,72 @@ def test_chained_block_hashes_in_one_call_equal_the_per_block_chain():
     assert lib.mi_comm_region_bytes(8, 65536) > 2 * 8 * 65536
     assert lib.mi_comm_create(0, 2, None, 1024, None) == -1
     assert lib.mi_allreduce_sum_bf16(None, None, None, 8, None) == -1
+
+
+def test_block_manager_invariants_under_random_traffic():
+    """Structural invariants of the allocator under seeded random admit / decode / preempt / finish traffic
+    (the golden traces pin the exact ids; this pins what must hold for ANY stream):
+      * every block id is either in the free list or in use, never both, never twice in the free list;
+      * a block's ref_count equals the number of live block tables that contain it;
+      * a live table never holds a block twice, and holds exactly ceil(len / block_size) blocks;
+      * every full block of a live sequence carries the chained hash of its tokens, the partial tail none;
+      * num_prefix_tokens counts only leading blocks whose stored tokens equal the sequence's."""
+    import random
+    from collections import Counter
+
+    for seed in range(6):
+        rng = random.Random(seed)
+        bs, nblk = rng.choice([4, 16]), rng.randrange(24, 60)
+        bm = BlockManager(nblk, bs)
+        prefixes = [[rng.randrange(1, 50) for _ in range(bs * rng.randrange(1, 3))] for _ in range(3)]
+        live: list = []
+
+        def check():
+            free = list(bm.free_block_ids)
+            assert len(free) == len(set(free)) and not (set(free) & bm.used_block_ids)
+            assert set(free) | bm.used_block_ids == set(range(nblk))
+            refs = Counter(b for s_ in live for b in s_.block_table)
+            for i, blk in enumerate(bm.blocks):
+                assert blk.ref_count == refs.get(i, 0), (i, blk.ref_count, refs.get(i, 0))
+            for s_ in live:
+                t = s_.block_table
+                assert len(t) == len(set(t)) == s_.num_blocks
+                chain = -1
+                for i, b in enumerate(t):
+                    toks = s_.block(i)
+                    if len(toks) == bs and (i < len(t) - 1 or len(s_) % bs == 0):
+                        chain = BlockManager.compute_hash(toks, chain)
+                        if bm.blocks[b].hash != -1:  # sealed (a decode-grown tail is sealed by may_append)
+                            assert bm.blocks[b].hash == chain and bm.blocks[b].token_ids == toks
+                assert s_.num_prefix_tokens % bs == 0 and s_.num_prefix_tokens <= len(s_)
+
+        for _ in range(400):
+            op = rng.random()
+            if op < 0.35:  # admit
+                body = [rng.randrange(1, 50) for _ in range(rng.randrange(1, 3 * bs))]
+                toks = (rng.choice(prefixes) + body) if rng.random() < 0.6 else body
+                s_ = seq(toks, block_size=bs, max_tokens=64, ignore_eos=True)
+                if bm.can_allocate(s_):
+                    bm.allocate(s_)
+                    live.append(s_)
+            elif op < 0.8 and live:  # one decode step for a random live sequence
+                s_ = rng.choice(live)
+                s_.append_token(rng.randrange(1, 50))
+                if bm.can_append(s_):
+                    bm.may_append(s_)
+                else:  # no block for the new token: preempt it (scheduler.py:79-83)
+                    s_.token_ids.pop()
+                    s_.num_tokens -= 1
+                    s_.last_token = s_.token_ids[-1]
+                    bm.deallocate(s_)
+                    live.remove(s_)
+            elif live:  # finish / preempt
+                s_ = live.pop(rng.randrange(len(live)))
+                bm.deallocate(s_)
+                assert not s_.block_table and s_.num_prefix_tokens == 0
+            check()
+        for s_ in live:
+            bm.deallocate(s_)
+        live.clear()
+        check()
+        assert len(bm.free_block_ids) == nblk
