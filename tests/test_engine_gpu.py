@@ -129,6 +129,12 @@ def test_engine_matches_oracle_model(enforce_eager):
     _engine_vs_oracle(MID, [5, 16, 17, 63, 130, 31], enforce_eager, seed=11, tol=4e-2)
 
 
+def test_engine_matches_oracle_qkv_bias_variant():
+    """attention_bias=True (the Qwen2 wiring of qwen3.py:70-72,135: bias on the qkv projection, no q/k
+    norm): takes the module-by-module decode path (bias epilogue of the skinny GEMM, RoPE without norm)."""
+    _engine_vs_oracle(dict(MID, attention_bias=True), [5, 16, 17, 63, 31], enforce_eager=False, seed=4, tol=4e-2)
+
+
 def test_engine_fp8_weights_match_oracle_on_dequantised_weights():
     """BASELINE.json configs[4] (fp8 weights): e4m3 + per-row scales for every projection and the
     head; decode runs the fp8-weight GEMMs (exact w_q * scale), prefill the library GEMM on the
