@@ -45,3 +45,9 @@ def golden_attention():
 @pytest.fixture(scope="session")
 def golden_tiny():
     return np.load(os.path.join(GOLDEN, "tiny_model.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tiny_bias():
+    """The same run with attention_bias=True: qkv bias, no q/k norm (the Qwen2 wiring)."""
+    return np.load(os.path.join(GOLDEN, "tiny_model_bias.npz"))

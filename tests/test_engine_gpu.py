@@ -19,17 +19,20 @@ def _split(flat, lens):
     return out
 
 
+@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias"])
 @pytest.mark.parametrize("enforce_eager", [True, False])
-def test_tiny_model_golden_run(golden_tiny, enforce_eager):
+def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, enforce_eager, variant):
     """Same prompts, same weights, greedy: block tables follow the same FIFO order, logits
     agree with the reference's bf16 CPU pipeline to a bf16-ulp-scale bound, tokens agree
-    wherever the reference's top-2 margin exceeds that bound."""
+    wherever the reference's top-2 margin exceeds that bound.  Both wirings of qwen3.py:70-72:
+    q/k norm without bias (Qwen3) and qkv bias without norm (attention_bias=True)."""
     from nanovllm import LLM, SamplingParams
     from nanovllm.utils.loader import load_state_dict_packed
 
-    g = golden_tiny
+    g = golden_tiny if variant == "qwen3" else golden_tiny_bias
     block_size, nblk = (int(v) for v in g["meta"])
-    llm = LLM(make_model_dir(TINY), kvcache_block_size=block_size, max_num_seqs=4, max_num_batched_tokens=128,
+    tiny = TINY if variant == "qwen3" else dict(TINY, attention_bias=True)
+    llm = LLM(make_model_dir(tiny), kvcache_block_size=block_size, max_num_seqs=4, max_num_batched_tokens=128,
               max_model_len=128, num_kvcache_blocks=nblk, enforce_eager=enforce_eager, warmup=False)
     try:
         weights = {k[3:]: bf(g[k]) for k in g.files if k.startswith("w::")}

@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import oracle
@@ -109,19 +110,21 @@ def _tiny_oracle(g):
     weights = {k[3:]: bf(g[k]) for k in g.files if k.startswith("w::")}
     from model_configs import TINY
 
-    hf = Qwen3Config(**{k: v for k, v in TINY.items() if k not in ("architectures", "model_type", "torch_dtype")})
+    tiny = dict(TINY, attention_bias=True) if "attention_bias" in g.files and int(g["attention_bias"]) else TINY
+    hf = Qwen3Config(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
     block_size, nblk = (int(v) for v in g["meta"])
     return OracleQwen3(cfg, weights, nblk, block_size), block_size
 
 
-def test_tiny_model_matches_reference_run(golden_tiny):
+@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias"])
+def test_tiny_model_matches_reference_run(golden_tiny, golden_tiny_bias, variant):
     """Replay the reference's own greedy run (its scheduler, block manager, prepare_*,
     model) through the oracle model with the same token stream.  The reference
     pipeline is bf16 end to end with bf16 S/P in attention, so logits agree to a
     bf16-ulp-scale bound, and greedy tokens agree wherever the reference's top-2
     margin exceeds that bound."""
-    g = golden_tiny
+    g = golden_tiny if variant == "qwen3" else golden_tiny_bias
     model, bs = _tiny_oracle(g)
     lens = g["prompt_lens"].tolist()
     flat = g["prompts"].tolist()

@@ -372,7 +372,9 @@ def gen_engine_fuzz(n_scenarios=14):
 
 
 # --------------------------------------------------------------------------- E. tiny model
-def gen_tiny_model():
+def gen_tiny_model(variant: str = ""):
+    """variant "": Qwen3 wiring (q/k norm, no bias); "bias": attention_bias=True - qkv bias, no q/k norm
+    (the Qwen2 wiring of qwen3.py:70-72,135)."""
     from transformers import Qwen3Config
 
     import nanovllm.models.qwen3 as ref_qwen3
@@ -401,9 +403,10 @@ def gen_tiny_model():
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from model_configs import TINY  # the same dict the tests build their model directory from
 
-    hf = Qwen3Config(**{k: v for k, v in TINY.items() if k not in ("architectures", "model_type", "torch_dtype")})
+    tiny = dict(TINY, attention_bias=True) if variant == "bias" else TINY
+    hf = Qwen3Config(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
-    weights = random_weights(cfg, seed=3, std=0.08)
+    weights = random_weights(cfg, seed=3 if not variant else 13, std=0.08)
     # non-trivial norm weights so the norm multiplies are exercised
     g = torch.Generator().manual_seed(5)
     for name in list(weights):
@@ -459,7 +462,8 @@ def gen_tiny_model():
             step += 1
     out["n_steps"] = np.array(step)
     out["final_tokens"] = np.array(sum([s.token_ids for s in seqs_all], []), dtype=np.int64)
-    np.savez_compressed(os.path.join(OUT, "tiny_model.npz"), **out)
+    out["attention_bias"] = np.array(int(variant == "bias"))
+    np.savez_compressed(os.path.join(OUT, f"tiny_model{'_' + variant if variant else ''}.npz"), **out)
 
 
 def main():
@@ -468,7 +472,8 @@ def main():
     import_reference()
     only = sys.argv[1:]  # e.g. `gen_golden.py engine_fuzz` regenerates one fixture
     for name, fn in (("hashes", gen_hashes), ("layers", gen_layers), ("attention", gen_attention),
-                     ("engine", gen_engine), ("engine_fuzz", gen_engine_fuzz), ("tiny_model", gen_tiny_model)):
+                     ("engine", gen_engine), ("engine_fuzz", gen_engine_fuzz), ("tiny_model", gen_tiny_model),
+                     ("tiny_model_bias", lambda: gen_tiny_model("bias"))):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
