@@ -118,6 +118,7 @@ def test_sequence_wire_roundtrip():
     s = Sequence(list(range(100, 140)), SamplingParams(temperature=0.7, max_tokens=5), block_size=16)
     s.block_table = [4, 9, 2]
     s.num_cached_tokens = 16
+    s.num_prefix_tokens, s.table_gen = 16, 3  # prefix-aware prefill / staging-row invalidation travel too
     for is_prefill in (True, False):
         buf = np.array(s.to_wire(is_prefill) + [77], dtype=np.int64)
         r, pos = Sequence.from_wire(buf, 0)
@@ -125,6 +126,7 @@ def test_sequence_wire_roundtrip():
         assert (r.seq_id, len(r), r.num_prompt_tokens, r.num_cached_tokens, r.block_size) == (
             s.seq_id, 40, 40, 16, 16)
         assert r.block_table == [4, 9, 2] and r.last_token == 139 and r.temperature == 0.7
+        assert (r.num_prefix_tokens, r.table_gen, r.greedy) == (16, 3, False)
         assert r.num_blocks == 3 and r.last_block_num_tokens == 8  # works on the receiver
         if is_prefill:
             assert r.token_ids == s.token_ids
