@@ -45,7 +45,7 @@ def step_bytes(batch: int, ctx: int, tp: int = 1) -> float:
     return 1_192_099_840 + batch * (114_688 * ctx + 418_560)
 
 
-def cpu_baseline(sample_steps: int = 1):
+def cpu_baseline(sample_steps: int = 5):
     """The oracle's decode step at bs=32 / ctx=1024 on the host cores (random KV contents
     instead of a CPU prefill: same arithmetic per step, bounded run time)."""
     import torch
