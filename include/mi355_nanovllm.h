@@ -121,6 +121,39 @@ int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride,
                          int batch, int n_q_heads, int n_kv_heads, int head_dim,
                          int block_size, float scale, mi_stream stream);
 
+/* mi_paged_attn_decode with the step's q_norm / k_norm / RoPE (qwen3.py:83-88) and the scatter of the
+ * new token's K / V row (attention.py:32-35) folded into the same launch: reads the packed qkv rows of
+ * QKVParallelLinear ([batch][(n_q_heads + 2 n_kv_heads) * 128], linear.py:117-126) directly.  Output and
+ * cache contents are bit-identical to mi_qknorm_rope_store followed by mi_paged_attn_decode.
+ * The token of row b is attended at position context_lens[b] - 1 and stored at slot_2d[b] = {block id,
+ * offset} (model_runner.py:301,353; both name the same slot); rows with context_len <= 0 (graph padding,
+ * :303-311) produce zeros and do NOT write their dummy slot (the reserved block is never read).
+ * q_w / k_w may be NULL (attention_bias=true models skip the norms, qwen3.py:70).  k_cache / v_cache are
+ * read and written. */
+int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_stride,
+                               const mi_bf16* q_w, const mi_bf16* k_w, float eps,
+                               const int64_t* positions, const float* cos_sin,
+                               const int32_t* slot_2d,
+                               mi_bf16* k_cache, mi_bf16* v_cache,
+                               const int32_t* block_table, int table_stride,
+                               const int32_t* context_lens,
+                               mi_bf16* out, void* workspace, size_t ws_bytes,
+                               int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                               int block_size, float scale, mi_stream stream);
+
+/* Tuning entry point (tools/attn_exp.py): mi_paged_attn_decode with an explicit number of context splits
+ * per (sequence, kv head) (0 = automatic) and explicit element strides of the cache
+ * (block, kv head, 16-token tile). */
+int mi_paged_attn_decode_ex(const mi_bf16* q, int64_t q_row_stride,
+                            const mi_bf16* k_cache, const mi_bf16* v_cache,
+                            const int32_t* block_table, int table_stride,
+                            const int32_t* context_lens,
+                            mi_bf16* out, void* workspace, size_t ws_bytes,
+                            int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                            int block_size, float scale, int num_splits,
+                            int64_t stride_block, int64_t stride_head, int64_t stride_tile,
+                            mi_stream stream);
+
 /* Prefill attention, stands in for npu_fused_infer_attention_score_v2 "TND"
  * sparse_mode=3 (attention.py:47-59): per-sequence causal GQA attention.
  * K/V are read back from the paged cache that mi_reshape_and_cache has just
@@ -211,6 +244,29 @@ int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream 
 int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16* bias,
                         mi_bf16* y, int M, int N, int K, int epilogue, mi_stream stream);
 
+/* RowParallelLinear.forward without the all-reduce (linear.py:149-151) for the small-N projections
+ * (o_proj, down_proj): y[M][N] = bf16(x[M][K] @ w[N][K]^T), complete rows from N / 4 workgroups of four
+ * output features each (every CU streams weights; no split-K partials).  Weight layout
+ * w_packed4[N/4][K/32][4][4][8]:
+ *   w_packed4[((tn*K/32 + tk)*16 + g*4 + n)*8 + e] = w[(4 tn + n)*K + 32 tk + 8 g + e].
+ * 1 <= M <= 64, N % 4 == 0, K % 32 == 0. */
+int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed4, int N, int K, mi_stream stream);
+int mi_gemm_bf16_rows4(const mi_bf16* x, const mi_bf16* w_packed4, mi_bf16* y, int M, int N, int K,
+                       mi_stream stream);
+
+/* RMSNorm.add_rms_forward (layernorm.py:27-38) folded into the column-parallel GEMM that consumes it
+ * (qwen3.py:118-131: post-attention / next-layer norm, then gate_up / qkv projection):
+ *   s = x + residual (fp32);  residual_out = bf16(s);
+ *   y = mi_gemm_bf16_packed( bf16(bf16(s * rsqrt(mean(s^2) + eps)) * norm_w), w_packed, epilogue ).
+ * Every workgroup recomputes the norm of its (<= 64 x K, L2-resident) input under the latency of its
+ * weight stream; one workgroup writes residual_out, which must not alias x or residual.  Same rounding
+ * points as mi_add_rmsnorm followed by mi_gemm_bf16_packed (sums of squares in a different order).
+ * Built for K = 256 * {1, 2, 4, 8} with ceil(M / 16) * K / 256 <= 8 (K = 1024: M <= 32); other shapes
+ * return MI_EUNSUPPORTED and the caller uses the two-call sequence. */
+int mi_gemm_bf16_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
+                                float eps, const mi_bf16* w_packed, mi_bf16* y, mi_bf16* residual_out,
+                                int M, int N, int K, int epilogue, mi_stream stream);
+
 /* Split-K over workgroups for the small-N row-parallel projections (o_proj, down_proj):
  * partials[ksplit][M][N] fp32, summed in split order and rounded to bf16 by the consumer
  * mi_add_rmsnorm_splitk — together bit-identical to mi_gemm_bf16_packed + mi_add_rmsnorm
@@ -264,6 +320,11 @@ int mi_gemm_fp8w_packed(const mi_bf16* x, const uint8_t* w_packed, const float* 
                         int M, int N, int K, int epilogue, mi_stream stream);
 int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
                                float* partials, int M, int N, int K, int ksplit, mi_stream stream);
+/* mi_gemm_bf16_packed_addnorm on fp8 weights (K = 512 * {1, 2, 4}). */
+int mi_gemm_fp8w_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
+                                float eps, const uint8_t* w_packed, const float* scale, mi_bf16* y,
+                                mi_bf16* residual_out, int M, int N, int K, int epilogue,
+                                mi_stream stream);
 
 /* ---- tensor-parallel exchange over xGMI -----------------------------------
  * Stands in for the HCCL all-reduce after every row-parallel projection and the

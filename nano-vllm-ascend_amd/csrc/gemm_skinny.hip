@@ -27,14 +27,34 @@
 
 namespace mi {
 
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{pack_bf(f[0], f[1]), pack_bf(f[2], f[3]), pack_bf(f[4], f[5]), pack_bf(f[6], f[7])};
+}
+
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
 
+// Operands of the add + RMSNorm prologue (PRO): the GEMM input is not read from memory but computed,
+//   s = x + residual (fp32), residual_out = bf16(s), x' = bf16(bf16(s * rsqrt(mean(s^2) + eps)) * w)
+// (RMSNorm.add_rms_forward, layernorm.py:27-38, in front of a column-parallel linear, qwen3.py:118-131)
+struct NormPro {
+  const uint16_t* residual;  // [M][K]
+  const uint16_t* norm_w;    // [K]
+  uint16_t* residual_out;    // [M][K]; must not alias x or residual (other workgroups still read them)
+  float eps;
+};
+
 // WF: weight format - 0 row-major bf16, 1 fragment-native bf16, 2 fragment-native fp8 (e4m3) + per-row scale
-template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
+// PRO: every workgroup recomputes the add + RMSNorm of its (L2-resident, <= 64-row) input while its weight
+// fragments are in flight from HBM: each wave loads ITS K-slice of x and residual as B fragments, the row
+// sums of squares go lane -> xor-16/32 -> LDS -> summed in wave order (every workgroup gets the same
+// bits), and the normalised slice is the wave's MFMA operand without ever touching memory.  The wave's
+// K-slice must be one loop iteration (K == WAVES * 32 * STEPS); workgroup (0, 0) writes residual_out.
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS, bool PRO = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][RT*MT][256]
+    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K,
+    NormPro np = NormPro{}) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][RT*MT][256] (+ PRO: [WAVES][64] row sums)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -74,7 +94,103 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   for (int k = 0; k < kslice; k += 32 * STEPS) {
     u32x4 a[RT][STEPS], bfrag[MT][STEPS];
     // every load of the block is issued before the first MFMA: no branches, no waits in between
-    if (WF == 2) {
+    if (PRO) {
+      // operand loads first (L2 hits), then the weight stream (HBM): vmcnt retires in order, so the
+      // prologue's wait covers only its own loads and runs under the weights' latency
+      u32x4 xa[MT][STEPS], ra[MT][STEPS], nw[STEPS];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          xa[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + 32 * s);
+          ra[m][s] = *reinterpret_cast<const u32x4*>(np.residual + (xp[m] - x) + 32 * s);
+        }
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) nw[s] = *reinterpret_cast<const u32x4*>(np.norm_w + kbeg + 8 * g + 32 * s);
+      if (WF == 2) {
+        u32x4 raw[RT][(STEPS + 1) / 2];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int s2 = 0; s2 < STEPS / 2; ++s2)
+            raw[t][s2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + s2 * 512));
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int s = 0; s < STEPS; ++s) {
+            const uint32_t lo = raw[t][s >> 1][2 * (s & 1)], hi = raw[t][s >> 1][2 * (s & 1) + 1];
+            const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+            const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+            a[t][s] = u32x4{pack_bf(f0[0], f0[1]), pack_bf(f1[0], f1[1]), pack_bf(f2[0], f2[1]), pack_bf(f3[0], f3[1])};
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int s = 0; s < STEPS; ++s)
+            a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + s * WSTEP));
+      }
+      // s = x + residual is formed twice from the packed operands (two exact bf16 -> fp32 widenings and
+      // one add: same bits both times) rather than kept in 8 registers per fragment
+      auto s_of = [&](int m, int s, int j, float& v0, float& v1) {
+        v0 = lo_bf(xa[m][s][j]) + lo_bf(ra[m][s][j]);
+        v1 = hi_bf(xa[m][s][j]) + hi_bf(ra[m][s][j]);
+      };
+      float ss[MT];
+      const bool writer = blockIdx.x == 0 && blockIdx.y == 0;  // one workgroup holds every element of s once
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          ss[m] = 0.f;
+#pragma unroll
+          for (int s = 0; s < STEPS; ++s) {
+            u32x4 so;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v0, v1;
+              s_of(m, s, j, v0, v1);
+              ss[m] += v0 * v0;
+              ss[m] += v1 * v1;
+              so[j] = pack_bf(v0, v1);
+            }
+            if (writer && 16 * m + r < M) *reinterpret_cast<u32x4*>(np.residual_out + (xp[m] - x) + 32 * s) = so;
+          }
+          ss[m] += __shfl_xor(ss[m], 16, 64);
+          ss[m] += __shfl_xor(ss[m], 32, 64);
+        }
+      }
+      float* rowss = red + WAVES * RT * MT * 256;  // [WAVES][64]
+      if (g == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) rowss[wave * 64 + 16 * m + r] = ss[m];
+      }
+      // make the second formation of s a real recomputation (otherwise the compiler keeps all of s live
+      // across the barrier: 8 registers per fragment at the 128-register budget of a 16-wave workgroup)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) asm volatile("" : "+v"(xa[m][s]), "+v"(ra[m][s]));
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float tot = rowss[16 * m + r];
+#pragma unroll
+        for (int wv = 1; wv < WAVES; ++wv) tot += rowss[wv * 64 + 16 * m + r];
+        const float rs = 1.0f / sqrtf(tot / (float)K + np.eps);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          u32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v0, v1;
+            s_of(m, s, j, v0, v1);
+            o[j] = pack_bf(rbf(v0 * rs) * lo_bf(nw[s][j]), rbf(v1 * rs) * hi_bf(nw[s][j]));
+          }
+          bfrag[m][s] = o;
+        }
+      }
+    } else if (WF == 2) {
       static_assert(WF != 2 || STEPS % 2 == 0, "an fp8 fragment load covers two k-steps");
       u32x4 raw[RT][(STEPS + 1) / 2];
 #pragma unroll
@@ -175,6 +291,112 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Row-parallel projections (o_proj, down_proj: N = hidden is small, K large): complete bf16 rows from
+// every workgroup, no split-K partials - the consumer (the next GEMM's add + RMSNorm prologue) then
+// re-reads 2 bytes per element instead of 4 x ksplit.
+//   A workgroup owns FOUR output features and the whole K: N / 4 workgroups (256 for hidden 1024) each
+//   stream 8 K bytes of weights - all CUs pull from HBM, which a 16-feature tile (N / 16 = 64
+//   workgroups) cannot do for these shapes and which split-K only buys with fp32 partials.
+//   Weights are packed [N/4][K/32][4 k-groups][4 features][8]: a wave's K-slice is one contiguous run,
+//   the A fragment row r of v_mfma_f32_16x16x32_bf16 carries feature r % 4 (rows 4..15 are duplicates
+//   whose results are never read), the B fragments are the rows of x as in gemm_skinny_kernel, so lane
+//   (g = 0, c) ends up with features 0..3 of activation row c: one 8-byte store per row.
+//   The WAVES K-slices are summed through LDS in wave order (deterministic) and rounded to bf16 once.
+// ---------------------------------------------------------------------------------------------------
+template <int MT, int WAVES, int STEPS>
+__global__ __launch_bounds__(WAVES * 64) void gemm_rows4_kernel(const uint16_t* __restrict__ x,
+                                                                const uint16_t* __restrict__ w4,
+                                                                uint16_t* __restrict__ y, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float red[WAVES][MT][16][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int kslice = K / WAVES;  // multiple of 32 * STEPS (checked on the host)
+  const int kbeg = wave * kslice;
+  const uint16_t* wp = w4 + ((int64_t)blockIdx.x * (K >> 5) + (kbeg >> 5)) * 128 + (g * 4 + (r & 3)) * 8;
+  const uint16_t* xp[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) xp[m] = x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 8 * g;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kslice; k += 32 * STEPS) {
+    u32x4 a[STEPS], bfrag[MT][STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+      a[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((k >> 5) + s) * 128));
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[s]), as_frag(bfrag[m][s]), acc[m], 0, 0, 0);
+  }
+  // C fragment: lane (g, c) holds rows 4g .. 4g+3 (features) of column c (activation row): g == 0 is real
+  if (g == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(&red[wave][m][r][0]) = acc[m];
+  }
+  __syncthreads();
+  if (threadIdx.x < MT * 16) {
+    const int m = threadIdx.x >> 4, c = threadIdx.x & 15;
+    f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][m][c][0]);
+#pragma unroll
+    for (int wv = 1; wv < WAVES; ++wv) t += *reinterpret_cast<const f32x4*>(&red[wv][m][c][0]);
+    const int row = 16 * m + c;
+    if (row < M)
+      *reinterpret_cast<u32x2*>(y + (int64_t)row * N + 4 * blockIdx.x) = u32x2{pack_bf(t[0], t[1]), pack_bf(t[2], t[3])};
+  }
+}
+
+// dst[((tn * K/32 + tk) * 16 + g * 4 + n) * 8 + e] = src[(4 tn + n) * K + 32 tk + 8 g + e]
+__global__ __launch_bounds__(256) void pack_weight_rows4_kernel(const uint16_t* __restrict__ src,
+                                                                uint16_t* __restrict__ dst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+  if (idx >= (int64_t)N * K / 8) return;
+  const int u = idx & 15, n = u & 3, g = u >> 2;
+  const int64_t frag = idx >> 4;
+  const int ktiles = K >> 5;
+  const int tk = frag % ktiles;
+  const int64_t tn = frag / ktiles;
+  *reinterpret_cast<u32x4*>(dst + idx * 8) = *reinterpret_cast<const u32x4*>(src + (tn * 4 + n) * K + tk * 32 + g * 8);
+}
+
+template <int MT, int WAVES>
+static bool rows4_steps(const uint16_t* x, const uint16_t* w4, uint16_t* y, int M, int N, int K, hipStream_t st) {
+  if (K % WAVES) return false;
+  const int kslice = K / WAVES;
+#define ROWS4_GO(ST)                                                                                      \
+  do {                                                                                                    \
+    hipLaunchKernelGGL((gemm_rows4_kernel<MT, WAVES, ST>), dim3(N / 4), dim3(WAVES * 64), 0, st, x, w4, y, \
+                       M, N, K);                                                                          \
+    return true;                                                                                          \
+  } while (0)
+  // the whole K-slice in flight when the registers allow (MT + 1 fragments per k-step)
+  if (kslice == 256 && MT <= 2) ROWS4_GO(8);
+  if (kslice == 192 && MT <= 2) ROWS4_GO(6);
+  if (kslice % 128 == 0) ROWS4_GO(4);
+  if (kslice % 96 == 0) ROWS4_GO(3);
+  if (kslice % 64 == 0) ROWS4_GO(2);
+  if (kslice % 32 == 0) ROWS4_GO(1);
+#undef ROWS4_GO
+  return false;
+}
+
+template <int MT>
+static int rows4_waves(const uint16_t* x, const uint16_t* w4, uint16_t* y, int M, int N, int K, hipStream_t st) {
+  // 16 waves when every wave still gets >= 64 of K, else 8 / 4
+  bool ok = false;
+  if (K >= 16 * 64) ok = rows4_steps<MT, 16>(x, w4, y, M, N, K, st);
+  if (!ok && K >= 8 * 32) ok = rows4_steps<MT, 8>(x, w4, y, M, N, K, st);
+  if (!ok) ok = rows4_steps<MT, 4>(x, w4, y, M, N, K, st) || rows4_steps<MT, 1>(x, w4, y, M, N, K, st);
+  return ok ? check_launch() : MI_EUNSUPPORTED;
+}
+
 // fragment-native repack: dst[(tn * K/32 + tk) * 512 + lane * 8 + e] = src[(16 tn + lane%16) * K + 32 tk + 8 (lane/16) + e]
 __global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t* __restrict__ src,
                                                           uint16_t* __restrict__ dst, int N, int K) {
@@ -197,13 +419,29 @@ struct GemmArgs {
   int M, N, K, ksplit;
   hipStream_t st;
   const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
+  bool pro = false;              // add + RMSNorm prologue (np)
+  NormPro np = NormPro{};
 };
+
+// shapes the prologue kernels are instantiated for: 8 waves (256-register budget: the wave's K-slice of
+// x, residual, norm weight and weights in registers at once - 16 waves at 128 registers spilled)
+template <int MT, int WAVES, int STEPS, int WF, int EPI>
+constexpr bool pro_built() {
+  return WAVES == 8 && WF != 0 && MT * STEPS <= 8 && EPI != EPI_PARTIAL && (WF != 2 || STEPS % 2 == 0);
+}
 
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
 static void launch(const GemmArgs& a) {
-  const size_t lds = (size_t)WAVES * RT * MT * 256 * sizeof(float);
+  const size_t lds = (size_t)WAVES * RT * MT * 256 * sizeof(float) + (a.pro ? WAVES * 64 * sizeof(float) : 0);
   const int tiles = a.N / 16;
   const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
+  if constexpr (pro_built<MT, WAVES, STEPS, WF, EPI>()) {
+    if (a.pro) {
+      hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false, true>), grid, dim3(WAVES * 64), lds,
+                         a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.np);
+      return;
+    }
+  }
   if (a.bias && EPI == EPI_NONE)
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
                        a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K);
@@ -219,6 +457,22 @@ static bool try_waves(const GemmArgs& a) {
   const int kslice = a.K / (a.ksplit * WAVES);
   constexpr int FRAGS = MT + RT;  // fragments (4 VGPRs each) per k-step
   constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 6 ? 4 : 2);
+  if (a.pro) {  // one loop iteration per wave, and only the instantiated shapes
+    if (a.ksplit != 1 || a.bias) return false;
+    if constexpr (pro_built<MT, WAVES, 8, WF, EPI>()) {
+      if (kslice == 256) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
+    }
+    if constexpr (pro_built<MT, WAVES, 4, WF, EPI>()) {
+      if (kslice == 128) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
+    }
+    if constexpr (pro_built<MT, WAVES, 2, WF, EPI>()) {
+      if (kslice == 64) return launch<MT, RT, WAVES, 2, WF, EPI>(a), true;
+    }
+    if constexpr (pro_built<MT, WAVES, 1, WF, EPI>()) {
+      if (kslice == 32) return launch<MT, RT, WAVES, 1, WF, EPI>(a), true;
+    }
+    return false;
+  }
   if (MAXS >= 8 && kslice % 256 == 0) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
   if (MAXS >= 4 && kslice % 128 == 0) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
   if (kslice % 64 == 0) return launch<MT, RT, WAVES, 2, WF, EPI>(a), true;
@@ -236,6 +490,10 @@ static int pick_waves(const GemmArgs& a) {
   const int wgs = (a.N / 16) / (EPI == EPI_SILU ? 2 : RT) * a.ksplit;
   const int kper = a.K / a.ksplit;
   bool ok = false;
+  if (a.pro) {
+    if (!try_waves<MT, RT, 8, WF, EPI>(a)) return MI_EUNSUPPORTED;
+    return check_launch();
+  }
   if (wgs >= 2048) {
     ok = try_waves<MT, RT, 4, WF, EPI>(a) || try_waves<MT, RT, 2, WF, EPI>(a);
   } else {
@@ -317,6 +575,75 @@ extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, co
   // two row tiles per workgroup halve the x traffic per weight byte once there are plenty of tiles
   if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, 1, EPI_NONE>(a);
   return pick_mt<1, 1, EPI_NONE>(a);
+}
+
+// add + RMSNorm prologue in front of the packed GEMM (see NormPro)
+static int check_addnorm(const void* residual, const void* norm_w, const void* residual_out, const void* x,
+                         int epilogue, int N) {
+  if (!residual || !norm_w || !residual_out) return MI_EINVAL;
+  if (!aligned16(residual) || !aligned16(norm_w) || !aligned16(residual_out)) return MI_EINVAL;
+  if (residual_out == residual || residual_out == x) return MI_EINVAL;
+  if (epilogue != 0 && epilogue != 1) return MI_EINVAL;
+  if (epilogue == 1 && N % 32) return MI_EUNSUPPORTED;
+  return MI_OK;
+}
+
+extern "C" int mi_gemm_bf16_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
+                                           float eps, const mi_bf16* w_packed, mi_bf16* y, mi_bf16* residual_out,
+                                           int M, int N, int K, int epilogue, mi_stream stream) {
+  int rc = check_gemm(x, w_packed, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  rc = check_addnorm(residual, norm_w, residual_out, x, epilogue, N);
+  if (rc != MI_OK) return rc;
+  if (M == 0) return MI_OK;
+  GemmArgs a{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)};
+  a.pro = true;
+  a.np = NormPro{residual, norm_w, residual_out, eps};
+  if (epilogue == 1) return pick_mt<2, 1, EPI_SILU>(a);
+  return pick_mt<1, 1, EPI_NONE>(a);
+}
+
+extern "C" int mi_gemm_fp8w_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
+                                           float eps, const uint8_t* w_packed, const float* scale, mi_bf16* y,
+                                           mi_bf16* residual_out, int M, int N, int K, int epilogue,
+                                           mi_stream stream) {
+  int rc = check_gemm(x, w_packed, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  rc = check_addnorm(residual, norm_w, residual_out, x, epilogue, N);
+  if (rc != MI_OK) return rc;
+  if (!scale || !aligned16(scale)) return MI_EINVAL;
+  if (K % 64) return MI_EUNSUPPORTED;
+  if (M == 0) return MI_OK;
+  GemmArgs a{x, reinterpret_cast<const uint16_t*>(w_packed), nullptr, y, nullptr, M, N, K, 1, S(stream)};
+  a.scale = scale;
+  a.pro = true;
+  a.np = NormPro{residual, norm_w, residual_out, eps};
+  if (epilogue == 1) return pick_mt<2, 2, EPI_SILU>(a);
+  return pick_mt<1, 2, EPI_NONE>(a);
+}
+
+extern "C" int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream) {
+  if (!w || !w_packed || N <= 0 || K <= 0) return MI_EINVAL;
+  if (N % 4 || K % 32) return MI_EUNSUPPORTED;
+  if (!aligned16(w) || !aligned16(w_packed)) return MI_EINVAL;
+  const int64_t chunks = (int64_t)N * K / 8;
+  hipLaunchKernelGGL(pack_weight_rows4_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, S(stream), w,
+                     w_packed, N, K);
+  return check_launch();
+}
+
+extern "C" int mi_gemm_bf16_rows4(const mi_bf16* x, const mi_bf16* w_packed4, mi_bf16* y, int M, int N, int K,
+                                  mi_stream stream) {
+  if (!x || !w_packed4 || !y || M < 0 || N <= 0 || K <= 0) return MI_EINVAL;
+  if (M > 64 || K % 32 || N % 4) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(w_packed4) || !aligned16(y)) return MI_EINVAL;
+  if (M == 0) return MI_OK;
+  switch ((M + 15) / 16) {
+    case 1: return rows4_waves<1>(x, w_packed4, y, M, N, K, S(stream));
+    case 2: return rows4_waves<2>(x, w_packed4, y, M, N, K, S(stream));
+    case 3: return rows4_waves<3>(x, w_packed4, y, M, N, K, S(stream));
+    default: return rows4_waves<4>(x, w_packed4, y, M, N, K, S(stream));
+  }
 }
 
 extern "C" int mi_gemm_bf16_packed_splitk(const mi_bf16* x, const mi_bf16* w_packed, float* partials, int M, int N,

@@ -1,7 +1,8 @@
 // 8-lanes-per-head helpers shared by the elementwise kernels and the fused decode attention:
 // q/k RMSNorm + NeoX RoPE with the reference's rounding points, and the scatter of one token's
-// K / V head into the fragment-native cache tiles.  Translation units that include this must be
-// compiled with -ffp-contract=off (separate fp32 mul / add roundings, as torch's unfused ops).
+// K / V head into the fragment-native cache tiles.  The arithmetic helpers carry
+// `#pragma clang fp contract(off)` (separate fp32 mul / add roundings, as torch's unfused ops), so
+// they give the same bits in translation units built with or without -ffp-contract=off.
 #pragma once
 #include "mi_common.hpp"
 
@@ -25,6 +26,7 @@ __device__ __forceinline__ u32x4 pack16(const float (&f)[8]) {
 // rms-normalise the 128 values held by 8 lanes (16 each) with weight w
 __device__ __forceinline__ void head_rmsnorm(float (&a)[8], float (&b)[8], const uint16_t* w, int j,
                                              float eps) {
+#pragma clang fp contract(off)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
@@ -46,6 +48,7 @@ __device__ __forceinline__ void head_rmsnorm(float (&a)[8], float (&b)[8], const
 
 // NeoX rotation in fp32 (rotary_embedding.py:6-14): separate mul / sub / add
 __device__ __forceinline__ void head_rope(float (&a)[8], float (&b)[8], const float* cs, int j) {
+#pragma clang fp contract(off)
   const float4 c0 = *reinterpret_cast<const float4*>(cs + 8 * j);
   const float4 c1 = *reinterpret_cast<const float4*>(cs + 8 * j + 4);
   const float4 s0 = *reinterpret_cast<const float4*>(cs + 64 + 8 * j);
@@ -57,6 +60,59 @@ __device__ __forceinline__ void head_rope(float (&a)[8], float (&b)[8], const fl
     const float x1 = a[i], x2 = b[i];
     a[i] = rbf(x1 * c[i] - x2 * s[i]);
     b[i] = rbf(x2 * c[i] + x1 * s[i]);
+  }
+}
+
+// ---- the same arithmetic on the MFMA-operand distribution of a head --------------------------
+// Four lanes g = 0..3 (lane ids n, n+16, n+32, n+48 of a wavefront) hold one head: lane g owns
+// dims 8g + 32kk + e (kk < 4, e < 8) in x[kk][e] - the B fragment of K.Q^T.  Lane g is the union of
+// the 8-lane form's lanes j = g (x[0] = its a, x[2] = its b) and j = g + 4 (x[1], x[3]); the sums
+// below are associated exactly as head_rmsnorm's (lane sums, then the xor-1/2/4 tree), so both
+// forms give identical bits.
+__device__ __forceinline__ void head_rmsnorm_frag(float (&x)[4][8], const uint16_t* w, int g, float eps) {
+#pragma clang fp contract(off)
+  float lo = 0.f, hi = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lo += x[0][i] * x[0][i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lo += x[2][i] * x[2][i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hi += x[1][i] * x[1][i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hi += x[3][i] * x[3][i];
+  lo += __shfl_xor(lo, 16, 64);
+  lo += __shfl_xor(lo, 32, 64);
+  hi += __shfl_xor(hi, 16, 64);
+  hi += __shfl_xor(hi, 32, 64);
+  const float ss = lo + hi;
+  const float rs = 1.0f / sqrtf(ss / 128.0f + eps);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    float wv[8];
+    load16(w + 8 * g + 32 * kk, wv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[kk][i] = rbf(rbf(x[kk][i] * rs) * wv[i]);
+  }
+}
+
+// NeoX pairs (d, d + 64) = (x[0], x[2]) with cos/sin index 8g + e and (x[1], x[3]) with 32 + 8g + e
+__device__ __forceinline__ void head_rope_frag(float (&x)[4][8], const float* cs, int g) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float* cp = cs + 32 * p + 8 * g;
+    const float4 c0 = *reinterpret_cast<const float4*>(cp);
+    const float4 c1 = *reinterpret_cast<const float4*>(cp + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(cp + 64);
+    const float4 s1 = *reinterpret_cast<const float4*>(cp + 68);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x1 = x[p][i], x2 = x[p + 2][i];
+      x[p][i] = rbf(x1 * c[i] - x2 * s[i]);
+      x[p + 2][i] = rbf(x2 * c[i] + x1 * s[i]);
+    }
   }
 }
 

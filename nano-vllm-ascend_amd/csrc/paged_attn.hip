@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "mi_common.hpp"
+#include "kv_store.hpp"
 
 namespace mi {
 
@@ -59,7 +60,15 @@ __device__ __forceinline__ void score_chunk(const u32x4 (&K0)[4], const u32x4 (&
   }
 }
 
-// online softmax update + O^T += V^T . P for one chunk
+typedef __attribute__((ext_vector_type(4))) short s16x4;  // one MFMA 16x16x16 bf16 operand
+
+// online softmax update + O^T += V^T . P for one chunk.
+// X16 = false: one 32-deep MFMA per (dim block, P part); its A operand is assembled from halves of a
+//   tile-0 and a tile-1 fragment (register moves).
+// X16 = true: two 16-deep MFMAs (v_mfma_f32_16x16x16_bf16), one per tile, whose operands are aligned
+//   halves of the registers as loaded - no moves, so nothing touches a fragment between its load and its
+//   MFMA (the two-chunks-in-flight loop depends on that: a move right behind the load would wait for it).
+template <bool X16>
 __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0)[4], const u32x4 (&V1)[4],
                                                  float& m, float& l, f32x4 (&acc)[8]) {
   float mc = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
@@ -88,23 +97,36 @@ __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0
     ph[i] = pack_bf(p[2 * i], p[2 * i + 1]);
     pl[i] = pack_bf(p[2 * i] - lo_bf(ph[i]), p[2 * i + 1] - hi_bf(ph[i]));
   }
-  const bf16x8 Ph = as_frag(ph), Pl = as_frag(pl);
+  if (X16) {
+    auto half = [](const u32x4& v, int hf) { return __builtin_bit_cast(s16x4, u32x2{v[hf], v[hf + 1]}); };
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int jp = j >> 1, hf = (j & 1) * 2;
-    const u32x4 a = {V0[jp][hf], V0[jp][hf + 1], V1[jp][hf], V1[jp][hf + 1]};
-    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Ph, acc[j], 0, 0, 0);
-    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Pl, acc[j], 0, 0, 0);
+    for (int part = 0; part < 4; ++part) {  // (tile 0, hi), (tile 0, lo), (tile 1, hi), (tile 1, lo)
+      const s16x4 pb = half((part & 1) ? pl : ph, (part >> 1) * 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)  // eight independent accumulators between two uses of the same one
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(half((part >> 1) ? V1[j >> 1] : V0[j >> 1], (j & 1) * 2), pb,
+                                                           acc[j], 0, 0, 0);
+    }
+  } else {
+    const bf16x8 Ph = as_frag(ph), Pl = as_frag(pl);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jp = j >> 1, hf = (j & 1) * 2;
+      const u32x4 a = {V0[jp][hf], V0[jp][hf + 1], V1[jp][hf], V1[jp][hf + 1]};
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Ph, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Pl, acc[j], 0, 0, 0);
+    }
   }
 }
 
+template <bool X16 = false>
 __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
                                              const u32x4 (&V0)[4], const u32x4 (&V1)[4],
                                              const bf16x8 (&Q)[4], int tok0, int limit, int limit_all,
                                              float scale_log2e, int g, float& m, float& l, f32x4 (&acc)[8]) {
   float p[8];
   score_chunk(K0, K1, Q, tok0, limit, limit_all, scale_log2e, g, p);
-  accumulate_chunk(p, V0, V1, m, l, acc);
+  accumulate_chunk<X16>(p, V0, V1, m, l, acc);
 }
 
 // element strides of the KV cache: block id, kv head, 16-token tile inside a block
@@ -141,23 +163,83 @@ __device__ __forceinline__ void load_tiles(const uint16_t* __restrict__ cache, c
   load_tile(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(t2 % tpb) * st.tile, lane, T1);
 }
 
-template <int G, int WAVES>
+// Operands of the fused step prologue (FUSE): the packed qkv row of QKVParallelLinear is consumed
+// directly - q_norm / k_norm / RoPE (qwen3.py:83-88) and the scatter of the new token's K / V row
+// (attention.py:32-35) happen inside the attention launch (bit-identical to mi_qknorm_rope_store,
+// same helpers).
+struct FusedStep {
+  const uint16_t* q_w;        // [128] or nullptr (attention_bias models have no q/k norm)
+  const uint16_t* k_w;
+  const int64_t* positions;   // [batch]
+  const float* cos_sin;       // [max_pos][128] fp32
+  const int32_t* slots;       // [batch][2] = {block id, offset}
+  float eps;
+};
+
+// One wavefront: lane (g, n) takes head n of {the G query heads of kv head h, then its k head}, dims
+// 8g + 32kk + e; normalised + rotated query heads go to LDS (sm_q[G][128]), the K and V row of the
+// step's token into their cache tile (k_tile / v_tile: element base of the 4 KiB tile, or nullptr).
+template <int G>
+__device__ __forceinline__ void step_prologue(const uint16_t* row, int n_q_heads, int n_kv, int h,
+                                              const FusedStep& fs, const float* cs, uint16_t* k_tile,
+                                              uint16_t* v_tile, int tok, uint16_t* sm_q) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  for (int hh = n; hh < G + 1; hh += 16) {  // uniform over the four lanes that share a head
+    const bool is_k = hh == G;
+    const uint16_t* src = row + (int64_t)(is_k ? n_q_heads + h : h * G + hh) * 128;
+    float x[4][8];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) load16(src + 8 * g + 32 * kk, x[kk]);
+    const uint16_t* w = is_k ? fs.k_w : fs.q_w;
+    if (w != nullptr) head_rmsnorm_frag(x, w, g, fs.eps);
+    head_rope_frag(x, cs, g);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const u32x4 pk = pack16(x[kk]);
+      if (!is_k) *reinterpret_cast<u32x4*>(sm_q + hh * 128 + 8 * g + 32 * kk) = pk;
+      else if (k_tile != nullptr)  // k_tile_off(t, 32kk + 8g) = kk*512 + (g*16 + t)*8
+        *reinterpret_cast<u32x4*>(k_tile + kk * 512 + (g * 16 + tok) * 8) = pk;
+    }
+  }
+  if (v_tile != nullptr) {  // V row: plain copy, two dims per lane
+    const uint32_t vv = *reinterpret_cast<const uint32_t*>(row + (int64_t)(n_q_heads + n_kv + h) * 128 + 2 * lane);
+    v_tile[v_tile_off(tok, 2 * lane)] = (uint16_t)(vv & 0xffffu);
+    v_tile[v_tile_off(tok, 2 * lane + 1)] = (uint16_t)(vv >> 16);
+  }
+}
+
+// PIPE = false: the round-1 geometry - 16 waves x 128 VGPRs, one chunk per wave in flight (load all,
+//   attend, load the next), overlap comes from the 16 waves being in different phases.
+// PIPE = true: 8 waves x 256 VGPRs, TWO chunks per wave in flight: chunk i+2 is requested as soon as
+//   chunk i has been consumed, so every wave keeps 16-32 KiB of loads outstanding while it computes
+//   (the same 256 KiB per CU as the 16-wave form, but no wave ever sits with nothing requested), half
+//   the waves to merge, and register room for the fused step prologue.
+template <int G, int WAVES, bool FUSE, bool PIPE>
 __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
-    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
-    const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* kc,
+    const uint16_t* vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ ctx_lens, float* __restrict__ part_o, float* __restrict__ part_ml,
-    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, float scale_log2e) {
+    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, float scale_log2e, FusedStep fs) {
+  static_assert(!FUSE || PIPE, "the fused prologue needs the register room of the 8-wave form");
   __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
   __shared__ float sm_m[WAVES][16];
   __shared__ float sm_l[WAVES][16];
+  // PIPE: the step's query heads, staged once per workgroup (FUSE: produced by the prologue wave)
+  __shared__ __attribute__((aligned(16))) uint16_t sm_q[PIPE ? G : 1][128];
 
   const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
   const int ctx = max(ctx_lens[b], 0);
   const int n_tiles = (ctx + 15) >> 4;
   // the context is cut into chunks of two 16-token tiles (only the very last chunk may hold one);
-  // the chunks are dealt to the WAVES*splits waves as evenly as possible, each wave a contiguous run
+  // the chunks are dealt to the WAVES*splits waves as evenly as possible, each wave a contiguous run:
+  // run r covers chunks [deal(r), deal(r + 1)), sizes differ by at most one, the longer runs come
+  // first (so the run that holds the LAST chunk - which, when FUSE, does the step prologue before its
+  // first load - is never a long one)
   const int n_chunks = (n_tiles + 1) >> 1, n_waves = WAVES * splits;
-  const int wg_c0 = split * WAVES * n_chunks / n_waves, wg_c1 = (split + 1) * WAVES * n_chunks / n_waves;
+  const int deal_q = n_chunks / n_waves, deal_r = n_chunks % n_waves;
+  auto deal = [&](int r) { return r * deal_q + min(r, deal_r); };
+  const int wg_c0 = deal(split * WAVES), wg_c1 = deal((split + 1) * WAVES);
+  const int owner_vw = min(n_chunks, n_waves) - 1;  // the run with the last chunk (context end)
   const int64_t row0 = (int64_t)b * n_q_heads + h * G;  // first q head of this kv head
   if (wg_c0 >= wg_c1) {  // uniform for the workgroup: nothing to attend in this split
     if (splits == 1) {     // empty context (graph padding row): the output row is zero
@@ -176,39 +258,119 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int g = lane >> 4, n = lane & 15;
   const int32_t* table_row = block_table + (int64_t)b * table_stride;
   const int vw = split * WAVES + wave;
-  const int t0 = 2 * (vw * n_chunks / n_waves), t1 = min(n_tiles, 2 * ((vw + 1) * n_chunks / n_waves));
+  const int t0 = 2 * deal(vw), t1 = min(n_tiles, 2 * deal(vw + 1));
+
+  if (FUSE) {
+    // The token of this step sits at position ctx - 1, i.e. in the last tile.  In the workgroup that
+    // attends that tile the prologue wave is the wave that owns it: it stores the new K / V row, drains
+    // the stores (vmcnt(0)) and only then issues its own tile loads, which therefore read the row back;
+    // nobody else in this launch reads that row.  Other splits run the prologue for the query heads only.
+    const int pro_wave = split == owner_vw / WAVES ? owner_vw % WAVES : 0;
+    if (wave == pro_wave) {
+      const int32_t blk = fs.slots[2 * b], off = fs.slots[2 * b + 1];
+      const bool store = split == owner_vw / WAVES && blk >= 0 && off >= 0;
+      const int64_t tile_w = (int64_t)blk * kvs.block + (int64_t)h * kvs.head + (int64_t)(off >> 4) * kvs.tile;
+      step_prologue<G>(q + (int64_t)b * q_stride, n_q_heads, (int)gridDim.y, h, fs,
+                       fs.cos_sin + fs.positions[b] * 128, store ? const_cast<uint16_t*>(kc) + tile_w : nullptr,
+                       store ? const_cast<uint16_t*>(vc) + tile_w : nullptr, off & 15, &sm_q[0][0]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+
+  if (PIPE && !FUSE && wave == 0) {  // stage the G query heads (contiguous G*256 bytes of the q row)
+    for (int c = lane; c < G * 16; c += 64)
+      *reinterpret_cast<u32x4*>(&sm_q[0][0] + 8 * c) =
+          *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)h * G * 128 + 8 * c);
+  }
 
   float m = -INFINITY, l = 0.f;
   f32x4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bool has_work = t0 < t1;
-  int t = t0;
-  u32x4 K0[4], K1[4], V0[4], V1[4];
-  if (has_work) {
-    const int t2 = t + 1 < t1 ? t + 1 : t;
-    load_tiles(kc, table_row, t, t2, h, kvs, tpb, lane, K0, K1);  // 16 fragment loads back to back
-    load_tiles(vc, table_row, t, t2, h, kvs, tpb, lane, V0, V1);
-  }
-  if (has_work) {
-    bf16x8 Q[4];
+  // a single-tile chunk loads its tile twice (a cache hit) and masks the duplicate through the limit
+  auto second = [&](int t) { return t + 1 < t1 ? t + 1 : t; };
+  auto limit_of = [&](int t) { return t + 1 < t1 ? ctx : min(ctx, (t + 1) * 16); };
+  auto load_q = [&](bf16x8 (&Q)[4]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 +
-                                                8 * g + 32 * kk);  // n >= G reads head 0 (valid memory)
+      u32x4 v;
+      if (PIPE) v = *reinterpret_cast<const u32x4*>(&sm_q[PIPE && n < G ? n : 0][8 * g + 32 * kk]);
+      else  // n >= G reads head 0 (valid memory)
+        v = *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 +
+                                            8 * g + 32 * kk);
       if (n >= G) v = u32x4{0, 0, 0, 0};
       Q[kk] = as_frag(v);
     }
-    while (true) {
-      // a single-tile chunk masks its (duplicate) second half through the token limit
-      const int lim = t + 1 < t1 ? ctx : min(ctx, (t + 1) * 16);
-      attend_chunk(K0, K1, V0, V1, Q, t * 16, lim, lim, scale_log2e, g, m, l, acc);
-      t += 2;
-      if (t >= t1) break;
-      const int t2 = t + 1 < t1 ? t + 1 : t;
-      load_tiles(kc, table_row, t, t2, h, kvs, tpb, lane, K0, K1);
-      load_tiles(vc, table_row, t, t2, h, kvs, tpb, lane, V0, V1);
+  };
+
+  if (PIPE) {
+    // Two chunk buffers A and B.  Every path below is straight-line in its loads (no load sits under a
+    // condition the following attend does not also sit under), so the compiler's vmcnt bookkeeping is
+    // exact: an attend waits for ITS buffer only (s_waitcnt vmcnt(16)) while the other buffer's 16
+    // fragment loads stay in flight behind it.
+    u32x4 AK0[4], AK1[4], AV0[4], AV1[4], BK0[4], BK1[4], BV0[4], BV1[4];
+    bf16x8 Q[4];
+    int ta = t0, tb = t0 + 2;
+    auto load_a = [&]() {
+      load_tiles(kc, table_row, ta, second(ta), h, kvs, tpb, lane, AK0, AK1);
+      load_tiles(vc, table_row, ta, second(ta), h, kvs, tpb, lane, AV0, AV1);
+    };
+    auto load_b = [&]() {
+      load_tiles(kc, table_row, tb, second(tb), h, kvs, tpb, lane, BK0, BK1);
+      load_tiles(vc, table_row, tb, second(tb), h, kvs, tpb, lane, BV0, BV1);
+    };
+    auto attend_a = [&]() {
+      attend_chunk<true>(AK0, AK1, AV0, AV1, Q, ta * 16, limit_of(ta), limit_of(ta), scale_log2e, g, m, l, acc);
+    };
+    auto attend_b = [&]() {
+      attend_chunk<true>(BK0, BK1, BV0, BV1, Q, tb * 16, limit_of(tb), limit_of(tb), scale_log2e, g, m, l, acc);
+    };
+    if (tb < t1) {  // at least two chunks
+      load_a();
+      load_b();
+      __syncthreads();  // sm_q is complete (this wave's tile loads are in flight behind the barrier)
+      load_q(Q);
+      while (tb + 4 < t1) {  // both buffers have a successor
+        attend_a();
+        ta += 4;
+        load_a();
+        attend_b();
+        tb += 4;
+        load_b();
+      }
+      attend_a();
+      if (ta + 4 < t1) {  // one more chunk behind B
+        ta += 4;
+        load_a();
+        attend_b();
+        attend_a();
+      } else {
+        attend_b();
+      }
+    } else if (ta < t1) {  // a single chunk
+      load_a();
+      __syncthreads();
+      load_q(Q);
+      attend_a();
+    } else {
+      __syncthreads();
+    }
+  } else {
+    int t = t0;
+    u32x4 K0[4], K1[4], V0[4], V1[4];
+    if (t < t1) {
+      load_tiles(kc, table_row, t, second(t), h, kvs, tpb, lane, K0, K1);  // 16 fragment loads back to back
+      load_tiles(vc, table_row, t, second(t), h, kvs, tpb, lane, V0, V1);
+      bf16x8 Q[4];
+      load_q(Q);
+      while (true) {
+        attend_chunk(K0, K1, V0, V1, Q, t * 16, limit_of(t), limit_of(t), scale_log2e, g, m, l, acc);
+        t += 2;
+        if (t >= t1) break;
+        load_tiles(kc, table_row, t, second(t), h, kvs, tpb, lane, K0, K1);
+        load_tiles(vc, table_row, t, second(t), h, kvs, tpb, lane, V0, V1);
+      }
     }
   }
   l += __shfl_xor(l, 16, 64);
@@ -539,7 +701,8 @@ static int check_attn_common(const void* q, const void* kc, const void* vc, cons
 static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache, const mi_bf16* v_cache,
                        const int32_t* block_table, int table_stride, const int32_t* context_lens, mi_bf16* out,
                        void* workspace, size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
-                       int block_size, float scale, int num_splits, KvStrides kvs, mi_stream stream) {
+                       int block_size, float scale, int num_splits, KvStrides kvs, mi_stream stream,
+                       const FusedStep* fused = nullptr) {
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -548,18 +711,27 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   if (batch == 0) return MI_OK;
   if (ws_bytes < mi_paged_attn_decode_workspace(batch, n_q_heads)) return MI_EWORKSPACE;
   const int G = n_q_heads / n_kv_heads;
-  const int waves = decode_waves(G);
-  int nsplit = num_splits > 0 ? num_splits : decode_splits(batch, n_kv_heads, waves);
+  // geometry: 0 = 16 waves, one chunk per wave in flight; 1 = 8 waves, two chunks per wave in flight.
+  // The fused entry point always uses 1; MI355_ATTN_PIPE (0/1) selects it for the plain one.
+  const char* pipe_env = getenv("MI355_ATTN_PIPE");  // read per call (a host-side getenv; captured graphs keep their choice)
+  const bool pipe = fused != nullptr || !pipe_env || atoi(pipe_env) != 0;
+  const int waves = pipe ? 8 : decode_waves(G);
+  int nsplit = num_splits > 0 ? num_splits : decode_splits(batch, n_kv_heads, pipe ? 16 : waves);
   if (nsplit > 16) nsplit = 16;
   float* part_o = static_cast<float*>(workspace);
   float* part_ml = part_o + (size_t)batch * n_q_heads * 16 * 128;
   const float sl2 = scale * 1.4426950408889634f;
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
-#define LAUNCH_DEC(GG, WW)                                                                                   \
-  hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW>), grid, dim3(WW * 64), 0, st, q, q_row_stride, k_cache, \
-                     v_cache, block_table, table_stride, context_lens, part_o, part_ml, out, n_q_heads, kvs, \
-                     block_size / 16, sl2)
+  const FusedStep fs = fused ? *fused : FusedStep{};
+#define LAUNCH_DEC_AS(GG, WW, FF, PP)                                                                          \
+  hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW, FF, PP>), grid, dim3(WW * 64), 0, st, q, q_row_stride, \
+                     k_cache, v_cache, block_table, table_stride, context_lens, part_o, part_ml, out,         \
+                     n_q_heads, kvs, block_size / 16, sl2, fs)
+#define LAUNCH_DEC(GG, WW)                       \
+  if (fused) LAUNCH_DEC_AS(GG, 8, true, true);   \
+  else if (pipe) LAUNCH_DEC_AS(GG, 8, false, true); \
+  else LAUNCH_DEC_AS(GG, WW, false, false)
   switch (G) {
     case 1: LAUNCH_DEC(1, 16); break;
     case 2: LAUNCH_DEC(2, 16); break;
@@ -568,6 +740,7 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
     default: LAUNCH_DEC(16, 4); break;
   }
 #undef LAUNCH_DEC
+#undef LAUNCH_DEC_AS
   rc = check_launch();
   if (rc != MI_OK || nsplit == 1) return rc;
   const int rows = batch * n_q_heads;
@@ -586,7 +759,23 @@ extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, cons
                      default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream);
 }
 
-// experiment entry point (not part of the public header yet): explicit split count and cache strides
+extern "C" int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w,
+                                          const mi_bf16* k_w, float eps, const int64_t* positions,
+                                          const float* cos_sin, const int32_t* slot_2d, mi_bf16* k_cache,
+                                          mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                          const int32_t* context_lens, mi_bf16* out, void* workspace,
+                                          size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                                          int block_size, float scale, mi_stream stream) {
+  if (!positions || !cos_sin || !slot_2d) return MI_EINVAL;
+  if ((q_w == nullptr) != (k_w == nullptr)) return MI_EINVAL;
+  if (!aligned16(cos_sin) || (q_w && (!aligned16(q_w) || !aligned16(k_w)))) return MI_EINVAL;
+  const FusedStep fs{q_w, k_w, positions, cos_sin, slot_2d, eps};
+  return decode_impl(qkv, qkv_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out,
+                     workspace, ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, 0,
+                     default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream, &fs);
+}
+
+// tuning entry point: explicit split count and cache strides (tools/attn_exp.py)
 extern "C" int mi_paged_attn_decode_ex(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
                                        const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
                                        const int32_t* context_lens, mi_bf16* out, void* workspace,

@@ -23,6 +23,7 @@ LIB_PATH = os.environ.get(
 )
 
 MI_OK = 0
+MI_EUNSUPPORTED = -2
 HEAD_DIM = 128
 KV_TILE_TOKENS = 16
 KV_TILE_ELEMS = 2048
@@ -59,6 +60,16 @@ _SIGNATURES = {
         c_int,
         [_p, c_int64, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_float, _p],
     ),
+    "mi_paged_attn_decode_fused": (
+        c_int,
+        [_p, c_int64, _p, _p, c_float, _p, _p, _p, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int,
+         c_int, c_int, c_float, _p],
+    ),
+    "mi_paged_attn_decode_ex": (
+        c_int,
+        [_p, c_int64, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+         c_int64, c_int64, c_int64, _p],
+    ),
     "mi_paged_attn_prefill": (
         c_int,
         [_p, c_int64, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int, c_int, c_int, c_float, _p],
@@ -75,6 +86,10 @@ _SIGNATURES = {
     "mi_pack_weight": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_packed": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
     "mi_gemm_bf16_packed_splitk": (c_int, [_p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_pack_weight_rows4": (c_int, [_p, _p, c_int, c_int, _p]),
+    "mi_gemm_bf16_rows4": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_gemm_bf16_packed_addnorm": (c_int, [_p, _p, _p, c_float, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_gemm_fp8w_packed_addnorm": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_embedding": (c_int, [_p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
     "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),

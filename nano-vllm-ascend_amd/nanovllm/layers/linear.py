@@ -70,6 +70,7 @@ class LinearBase(nn.Module):
         else:
             self.register_parameter("bias", None)
         self.weight_packed: torch.Tensor | None = None
+        self.weight_rows4: torch.Tensor | None = None  # row-parallel layers: mi_gemm_bf16_rows4 layout
 
     def pack(self) -> None:
         """Build the fragment-native copy of the (already sharded) weight that the decode GEMMs
@@ -147,6 +148,17 @@ class RowParallelLinear(LinearBase):
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
         cols = param.data.size(self.tp_dim)
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * cols, cols))
+
+    def pack(self) -> None:
+        super().pack()
+        # bf16 weights: a second decode layout whose GEMM returns complete rows from N/4 workgroups
+        # (mi_gemm_bf16_rows4); after super().pack() the parameter holds the (possibly dequantised) values
+        w = self.weight.data
+        if w.is_cuda and not isinstance(self.weight_packed, ops.Fp8Weight) and w.shape[0] % 4 == 0 \
+                and w.shape[1] % 32 == 0:
+            self.weight_rows4 = ops.pack_weight_rows4(w, self.weight_rows4)
+        else:
+            self.weight_rows4 = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = linear_forward(x, self.weight, self.bias if self.tp_rank == 0 else None, self.weight_packed)

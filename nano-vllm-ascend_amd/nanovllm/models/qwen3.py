@@ -180,50 +180,92 @@ class Qwen3Model(nn.Module):
         return ks
 
     def _forward_streaming(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
-        """<= 64 tokens (every decode step): 8 launches per layer instead of 13 -
-          add+RMSNorm (summing the previous projection's split-K partials) -> packed qkv GEMM ->
-          q/k-norm+RoPE+KV-store -> paged attention -> split-K o_proj -> add+RMSNorm ->
-          packed gate_up GEMM with the SwiGLU epilogue -> split-K down_proj.
-        With tensor parallelism the two row-parallel projections produce bf16 partial sums; the
-        all-reduce over the ranks (linear.py:149-153) and the following add+RMSNorm are ONE launch over
-        xGMI (mi_allreduce_add_rmsnorm), or RCCL all-reduce + add+RMSNorm when that path is off.
-        Rounding points are those of the module-by-module path (tests require equal results up to
-        fp32 summation order)."""
+        """<= 64 tokens (every decode step).  Single GPU, bf16 weights, <= 32 rows: FIVE launches per layer
+        (the reference's eager decode layer is ~13):
+          qkv GEMM with the add + RMSNorm of its input as prologue           (mi_gemm_bf16_packed_addnorm)
+          -> q/k-norm + RoPE + KV store + paged attention                     (mi_paged_attn_decode_fused)
+          -> o_proj, complete bf16 rows from N/4 workgroups                   (mi_gemm_bf16_rows4)
+          -> gate_up GEMM, add + RMSNorm prologue, SwiGLU epilogue            (mi_gemm_bf16_packed_addnorm)
+          -> down_proj                                                        (mi_gemm_bf16_rows4)
+        Shapes outside that (fp8 weights, > 32 rows, other widths) and MI355_DECODE_FUSION=0 take the
+        eight-launch sequence add+RMSNorm (summing split-K partials) -> qkv -> q/k-norm+RoPE+store ->
+        attention -> split-K o_proj -> add+RMSNorm -> gate_up+SwiGLU -> split-K down_proj.
+        With tensor parallelism the two row-parallel projections produce bf16 partial sums; the all-reduce
+        over the ranks (linear.py:149-153) and the following add+RMSNorm are ONE launch over xGMI
+        (mi_allreduce_add_rmsnorm), or RCCL all-reduce + add+RMSNorm when that path is off.
+        Rounding points are those of the module-by-module path in every variant (tests require equal
+        results up to fp32 summation order)."""
         tp = tp_size()
+        ctx = get_context()
         h = self.embed_tokens(input_ids)
-        residual, parts = None, None
+        rows = h.shape[0]
+        fusion = os.environ.get("MI355_DECODE_FUSION", "1") != "0"
+        l0 = self.layers[0]
+        # complete-row projections: bf16 weights only (fp8 keeps the split-K kernels)
+        rows4 = fusion and l0.self_attn.o_proj.weight_rows4 is not None and l0.mlp.down_proj.weight_rows4 is not None
+        fuse_attn = fusion and not ctx.is_prefill and os.environ.get("MI355_ATTN_FUSED", "1") != "0"
+        fuse_norm = rows4 and tp == 1 and os.environ.get("MI355_NORM_FUSED", "1") != "0"
 
         xgmi = get_xgmi_comm() if tp > 1 else None
-        fused_seam = (xgmi is not None and xgmi.fits_rows(h.shape[0], h.shape[1])
+        fused_seam = (xgmi is not None and xgmi.fits_rows(rows, h.shape[1])
                       and os.environ.get("MI355_XGMI_FUSED", "1") != "0")
 
-        def row_parallel(x, lin):
-            if tp == 1:
-                return ops.gemm_packed_splitk(x, lin.weight_packed, self._ksplit(lin.weight))
-            y = ops.gemm_packed(x, lin.weight_packed)  # this rank's bf16 partial sums
-            return y if fused_seam else all_reduce_sum(y)
+        def attend(attn, qkv):
+            if not fuse_attn:
+                return attn._attend_fused(positions, qkv)
+            a, rope = attn.attn, attn.rotary_emb
+            a.block_size = ctx.block_size
+            if rope.cos_sin_cache.device != qkv.device:
+                rope.cos_sin_cache = rope.cos_sin_cache.to(qkv.device)
+            qw = None if attn.qkv_bias else attn.q_norm.weight
+            kw = None if attn.qkv_bias else attn.k_norm.weight
+            return ops.paged_attn_decode_fused(qkv, qw, kw, attn.rms_norm_eps, positions, rope.cos_sin_cache,
+                                               ctx.slot_mapping, a.k_cache, a.v_cache, ctx.block_tables,
+                                               ctx.context_lens, attn.num_heads, attn.num_kv_heads, ctx.block_size,
+                                               a.scale)
 
-        def add_norm(y, res, ln):
-            if tp == 1:
+        def row_parallel(x, lin):
+            """-> (tensor, is_partials): bf16 rows, or fp32 split-K partials for add_rmsnorm_splitk"""
+            if rows4:
+                y = ops.gemm_rows4(x, lin.weight_rows4)
+            elif tp == 1:
+                return ops.gemm_packed_splitk(x, lin.weight_packed, self._ksplit(lin.weight)), True
+            else:
+                y = ops.gemm_packed(x, lin.weight_packed)  # this rank's bf16 partial sums
+            if tp > 1 and not fused_seam:
+                y = all_reduce_sum(y)
+            return y, False
+
+        def add_norm(y, is_partials, res, ln):
+            if is_partials:
                 return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps)
             if fused_seam:  # all-reduce over xGMI + add + RMSNorm in one launch
                 return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
             return ops.add_rmsnorm(y, res, ln.weight, ln.eps)
 
+        def norm_linear(y, is_partials, res, ln, w_packed, silu_mul=False):
+            """linear(rmsnorm(y + res)) -> (out, new residual)"""
+            if fuse_norm and not is_partials:
+                got = ops.gemm_packed_addnorm(y, res, ln.weight, ln.eps, w_packed, silu_mul=silu_mul)
+                if got is not None:
+                    return got
+            x, res = add_norm(y, is_partials, res, ln)
+            return ops.gemm_packed(x, w_packed, silu_mul=silu_mul), res
+
+        residual, parts, is_partials = None, None, False
         for layer in self.layers:
             attn, mlp = layer.self_attn, layer.mlp
             ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
-            if residual is None:
-                residual, x = h, ops.rmsnorm(h, ln1.weight, ln1.eps)
+            if residual is None:  # first layer: the residual stream starts as the embedding (qwen3.py:137-138)
+                residual = h
+                qkv = ops.gemm_packed(ops.rmsnorm(h, ln1.weight, ln1.eps), attn.qkv_proj.weight_packed)
             else:
-                x, residual = add_norm(parts, residual, ln1)
-            qkv = ops.gemm_packed(x, attn.qkv_proj.weight_packed)
-            o = attn._attend_fused(positions, qkv)
-            parts = row_parallel(o, attn.o_proj)
-            x, residual = add_norm(parts, residual, ln2)
-            act = ops.gemm_packed(x, mlp.gate_up_proj.weight_packed, silu_mul=True)
-            parts = row_parallel(act, mlp.down_proj)
-        x, _ = add_norm(parts, residual, self.norm)
+                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj.weight_packed)
+            o = attend(attn, qkv)
+            parts, is_partials = row_parallel(o, attn.o_proj)
+            act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj.weight_packed, silu_mul=True)
+            parts, is_partials = row_parallel(act, mlp.down_proj)
+        x, _ = add_norm(parts, is_partials, residual, self.norm)
         return x
 
 

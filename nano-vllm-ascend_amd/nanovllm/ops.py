@@ -100,6 +100,35 @@ def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, n_q_heads
     return out
 
 
+def paged_attn_decode_fused(qkv, q_w, k_w, eps: float, positions, cos_sin, slots_2d, k_cache, v_cache, block_tables,
+                            context_lens, n_q_heads: int, n_kv_heads: int, block_size: int, scale: float,
+                            out=None, workspace=None) -> torch.Tensor:
+    """q/k-norm + RoPE + KV store of the step's token + paged decode attention in ONE launch, straight
+    from the packed qkv rows (bit-identical to qknorm_rope_store followed by paged_attn_decode)."""
+    require_gpu(qkv, positions, cos_sin, slots_2d, k_cache, v_cache, block_tables, context_lens)
+    _bf16(qkv, k_cache, v_cache, q_w, k_w)
+    batch = qkv.shape[0]
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape[1] == (n_q_heads + 2 * n_kv_heads) * HEAD_DIM
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == batch
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
+    assert slots_2d.dtype == torch.int32 and slots_2d.is_contiguous() and slots_2d.shape == (batch, 2)
+    assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
+    if out is None:
+        out = torch.empty((batch, n_q_heads * HEAD_DIM), dtype=_BF16, device=qkv.device)
+    if workspace is None:
+        workspace = attn_workspace(qkv.device, batch, n_q_heads)
+    check(
+        lib.mi_paged_attn_decode_fused(ptr(qkv), qkv.stride(0), ptr(q_w), ptr(k_w), float(eps), ptr(positions),
+                                       ptr(cos_sin), ptr(slots_2d), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                       block_tables.stride(0), ptr(context_lens), ptr(out), ptr(workspace),
+                                       workspace.numel() * workspace.element_size(), batch, n_q_heads, n_kv_heads,
+                                       HEAD_DIM, block_size, float(scale), stream()),
+        "mi_paged_attn_decode_fused",
+    )
+    return out
+
+
 def paged_attn_prefill(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens, max_seqlen_q: int,
                        n_q_heads: int, n_kv_heads: int, block_size: int, scale: float, out=None) -> torch.Tensor:
     require_gpu(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
@@ -308,6 +337,64 @@ def gemm_packed(x, w_packed, bias=None, out=None, silu_mul: bool = False) -> tor
     check(lib.mi_gemm_bf16_packed(ptr(x), ptr(w_packed), ptr(bias), ptr(out), M, N, K, int(silu_mul), stream()),
           "mi_gemm_bf16_packed")
     return out
+
+
+def pack_weight_rows4(w, out=None) -> torch.Tensor:
+    """[N/4][K/32][4][4][8] copy of a [N, K] weight for gemm_rows4 (same shape/bytes; refreshes `out` in place)."""
+    require_gpu(w)
+    _bf16(w)
+    assert w.dim() == 2 and w.is_contiguous() and w.shape[0] % 4 == 0 and w.shape[1] % 32 == 0
+    if out is None or out.shape != w.shape or out.device != w.device:
+        out = torch.empty_like(w)
+    check(lib.mi_pack_weight_rows4(ptr(w), ptr(out), w.shape[0], w.shape[1], stream()), "mi_pack_weight_rows4")
+    return out
+
+
+def gemm_rows4(x, w_packed4, out=None) -> torch.Tensor:
+    """y = bf16(x @ w.T) for the small-N row-parallel projections, complete rows (no split-K partials)."""
+    require_gpu(x, w_packed4)
+    _bf16(x, w_packed4)
+    assert x.is_contiguous() and w_packed4.is_contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w_packed4.shape[0]
+    assert w_packed4.shape[1] == K
+    if out is None:
+        out = torch.empty((*x.shape[:-1], N), dtype=_BF16, device=x.device)
+    check(lib.mi_gemm_bf16_rows4(ptr(x), ptr(w_packed4), ptr(out), M, N, K, stream()), "mi_gemm_bf16_rows4")
+    return out
+
+
+def gemm_packed_addnorm(x, residual, norm_w, eps: float, w_packed, silu_mul: bool = False, out=None,
+                        residual_out=None):
+    """(y, residual_out) with residual_out = bf16(x + residual) and y = gemm_packed(rmsnorm(x + residual), w_packed):
+    RMSNorm.add_rms_forward folded into the prologue of the GEMM that consumes it.  Returns None when the
+    shape is outside what the prologue kernels are built for (the caller then uses the two-call sequence)."""
+    require_gpu(x, residual, norm_w)
+    _bf16(x, residual, norm_w)
+    assert x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w_packed.shape[0]
+    assert w_packed.shape[1] == K and norm_w.numel() == K
+    n_out = N // 2 if silu_mul else N
+    if out is None:
+        out = torch.empty((*x.shape[:-1], n_out), dtype=_BF16, device=x.device)
+    if residual_out is None:
+        residual_out = torch.empty_like(residual)
+    if isinstance(w_packed, Fp8Weight):
+        rc = lib.mi_gemm_fp8w_packed_addnorm(ptr(x), ptr(residual), ptr(norm_w), float(eps), ptr(w_packed.data),
+                                             ptr(w_packed.scale), ptr(out), ptr(residual_out), M, N, K,
+                                             int(silu_mul), stream())
+    else:
+        require_gpu(w_packed)
+        _bf16(w_packed)
+        rc = lib.mi_gemm_bf16_packed_addnorm(ptr(x), ptr(residual), ptr(norm_w), float(eps), ptr(w_packed), ptr(out),
+                                             ptr(residual_out), M, N, K, int(silu_mul), stream())
+    if rc == _C.MI_EUNSUPPORTED:
+        return None
+    check(rc, "mi_gemm_packed_addnorm")
+    return out, residual_out
 
 
 def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:

@@ -22,6 +22,14 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=[1, 0], ids=["pipe8", "waves16"])
+def attn_geometry(request, monkeypatch):
+    """both geometries of the decode attention kernel: 8 waves with two chunks in flight (default) and the
+    16-wave one-chunk form (MI355_ATTN_PIPE is read by the library on every call)"""
+    monkeypatch.setenv("MI355_ATTN_PIPE", str(request.param))
+    return request.param
+
+
 def ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """distance in bf16 ulps between two bf16 tensors (monotone integer mapping)"""
     def key(t):
@@ -334,6 +342,75 @@ def test_gemm_packed_qwen3_32b_tp8_shapes(ops, N, K):
                           max_ulp=2, max_frac=3e-2, atol=32 * atol)
 
 
+def _pack_rows4_ref(w):
+    """host model of mi_pack_weight_rows4: [N/4][K/32][4 (g)][4 (n)][8]"""
+    N, K = w.shape
+    return w.view(N // 4, 4, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(1024, 2048), (1024, 3072), (5120, 1024), (5120, 3200), (2048, 1024), (64, 96),
+                                 (4, 32), (1024, 256)])
+def test_gemm_rows4(ops, M, N, K):
+    """row-parallel projections (o_proj / down_proj; also the per-rank shards of TP 2..8 and Qwen3-32B widths):
+    complete rows, fp32 accumulate, one rounding"""
+    g = torch.Generator().manual_seed(M * 5 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    w4 = ops.pack_weight_rows4(w.to(DEV))
+    assert torch.equal(w4.cpu().view(torch.int16), _pack_rows4_ref(w).view(torch.int16))  # pure permutation
+    y = ops.gemm_rows4(x.to(DEV), w4)
+    assert_bf16_close(y, oracle.linear(x, w), max_ulp=1, max_frac=2e-2, atol=K * 2.0 ** -22)
+    if M >= 4 and K >= 32:  # transpose / layout detector
+        xe = torch.zeros(M, K).bfloat16()
+        xe[3, 5] = 1.0
+        ye = ops.gemm_rows4(xe.to(DEV), w4).cpu()
+        assert torch.equal(ye[3].view(torch.int16), w[:, 5].contiguous().view(torch.int16))
+        assert float(ye.float().abs().sum() - ye[3].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 32])
+@pytest.mark.parametrize("N,K,silu", [(4096, 1024, False), (6144, 1024, True), (512, 256, False), (1024, 512, True),
+                                      (2048, 2048, False)])
+def test_gemm_packed_addnorm(ops, M, N, K, silu):
+    """add + RMSNorm folded into the GEMM prologue: residual_out is the exact bf16(x + residual); y equals
+    the two-call sequence up to the norm's summation order (<= 1 ulp of the GEMM input on a few elements)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    r = (torch.randn(M, K, generator=g) * 2).bfloat16()
+    nw = (1 + 0.2 * torch.randn(K, generator=g)).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    wp = ops.pack_weight(w.to(DEV))
+    got = ops.gemm_packed_addnorm(x.to(DEV), r.to(DEV), nw.to(DEV), 1e-6, wp, silu_mul=silu)
+    if K == 2048 and M > 16:
+        assert got is None  # outside the built shapes: the caller falls back
+        return
+    y, r2 = got
+    xn, ro = oracle.add_rms_norm(x, r, nw, 1e-6)
+    assert torch.equal(r2.cpu().view(torch.int16), ro.view(torch.int16))
+    want = oracle.linear(xn, w)
+    atol = K * 2.0 ** -20  # a 1-ulp flip of one normalised input moves an output by up to |w| * 2^-7
+    if silu:
+        assert_bf16_close(y, oracle.silu_and_mul(want), max_ulp=2, max_frac=5e-2, atol=32 * atol)
+    else:
+        assert_bf16_close(y, want, max_ulp=1, max_frac=3e-2, atol=atol)
+    # and against this library's own two-call sequence
+    xn_d, r_d = ops.add_rmsnorm(x.to(DEV), r.to(DEV), nw.to(DEV), 1e-6)
+    assert torch.equal(r_d.view(torch.int16), r2.view(torch.int16))
+    y2 = ops.gemm_packed(xn_d, wp, silu_mul=silu)
+    assert_bf16_close(y, y2.cpu(), max_ulp=2, max_frac=5e-2, atol=32 * atol)
+
+
+def test_gemm_packed_addnorm_rejects_aliasing(ops):
+    x = torch.zeros(32, 1024, dtype=torch.bfloat16, device=DEV)
+    r = torch.zeros_like(x)
+    nw = torch.ones(1024, dtype=torch.bfloat16, device=DEV)
+    wp = ops.pack_weight(torch.zeros(4096, 1024, dtype=torch.bfloat16, device=DEV))
+    from nanovllm._C import MiError
+    with pytest.raises(MiError):
+        ops.gemm_packed_addnorm(x, r, nw, 1e-6, wp, residual_out=r)
+
+
 def test_gemm_lm_head_shape(ops):
     g = torch.Generator().manual_seed(1)
     M, N, K = 32, 151936, 1024
@@ -364,7 +441,7 @@ def _random_paged_case(gen, hq, hkv, block_size, ctx_lens, extra_blocks=3, scale
     return q, kc, vc, bt
 
 
-def test_decode_attention_golden(ops, golden_attention):
+def test_decode_attention_golden(ops, golden_attention, attn_geometry):
     """vs the reference's own CPU attention (bf16 S/P): bound 3e-2; vs oracle: 2e-3."""
     g = golden_attention
     hq, hkv, d, bs, nblk = (int(v) for v in g["meta"])
@@ -421,7 +498,7 @@ def test_gemm_fp8_weights(ops, M, N, K):
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (64, 8), (16, 1)])
 @pytest.mark.parametrize("block_size", [16, 64, 256])
-def test_decode_attention_random(ops, hq, hkv, block_size):
+def test_decode_attention_random(ops, hq, hkv, block_size, attn_geometry):
     """fp32-softmax oracle; kernel keeps P to ~16 bits (hi/lo bf16 split), so the only
     error left is the final bf16 rounding: |out - oracle_fp32| <= half a bf16 ulp."""
     gen = torch.Generator().manual_seed(hq * 1000 + hkv * 10 + block_size)
@@ -444,7 +521,7 @@ def test_decode_attention_random(ops, hq, hkv, block_size):
     assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
 
 
-def test_decode_attention_sharp_softmax(ops):
+def test_decode_attention_sharp_softmax(ops, attn_geometry):
     """large score spread (forces the online-softmax rescale path across chunks/waves/splits)"""
     gen = torch.Generator().manual_seed(9)
     ctx_lens = [700, 1024, 3000]
@@ -461,7 +538,7 @@ def test_decode_attention_sharp_softmax(ops):
 
 
 @pytest.mark.parametrize("batch", [1, 32, 256])
-def test_decode_attention_batch_sizes(ops, batch):
+def test_decode_attention_batch_sizes(ops, batch, attn_geometry):
     gen = torch.Generator().manual_seed(batch)
     ctx_lens = [int(x) for x in torch.randint(1, 300, (batch,), generator=gen)]
     q, kc_l, vc_l, bt = _random_paged_case(gen, 16, 8, 16, ctx_lens)
@@ -471,6 +548,62 @@ def test_decode_attention_batch_sizes(ops, batch):
                                 bt.to(DEV), ctx.to(DEV), 16, 8, 16, 1.0 / math.sqrt(128)).cpu()
     err = (out.float() - want).abs()
     assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
+
+
+@pytest.mark.parametrize("hq,hkv,with_norm", [(16, 8, True), (8, 8, True), (32, 8, True), (64, 8, True), (16, 1, False),
+                                               (16, 8, False)])
+@pytest.mark.parametrize("block_size", [16, 64])
+def test_decode_attention_fused_step(ops, hq, hkv, with_norm, block_size):
+    """mi_paged_attn_decode_fused == mi_qknorm_rope_store followed by mi_paged_attn_decode, bit for bit:
+    attention output and cache contents (context ends at tile / chunk / block boundaries, one-token
+    contexts, a padded row, contexts long enough for every wave and - small batch - several splits)."""
+    gen = torch.Generator().manual_seed(hq * 31 + hkv * 7 + block_size)
+    ctx_lens = [1, 2, 15, 16, 17, 31, 32, 33, 48, 49, 100, 257, 512, 1024, 1025, 1040, 0, 2049]
+    B = len(ctx_lens)
+    _, kc_l, vc_l, bt = _random_paged_case(gen, hq, hkv, block_size, ctx_lens, extra_blocks=4)
+    nblk = kc_l.shape[0]
+    used = set(int(b) for b in bt.flatten() if b >= 0)
+    dummy = next(b for b in range(nblk) if b not in used)  # padded rows point at a block nobody reads
+    qkv = (torch.randn(B, (hq + 2 * hkv) * 128, generator=gen) * 1.5).bfloat16().to(DEV)
+    qw = (1 + 0.2 * torch.randn(128, generator=gen)).bfloat16().to(DEV) if with_norm else None
+    kw = (1 + 0.2 * torch.randn(128, generator=gen)).bfloat16().to(DEV) if with_norm else None
+    table = oracle.build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    ctx = torch.tensor(ctx_lens, dtype=torch.int32)
+    pos = torch.tensor([max(n - 1, 0) for n in ctx_lens], dtype=torch.int64)
+    slots = torch.tensor([[int(bt[i][(n - 1) // block_size]), (n - 1) % block_size] if n > 0 else [dummy, 0]
+                          for i, n in enumerate(ctx_lens)], dtype=torch.int32)
+    kc1, vc1 = to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV)
+    kc2, vc2 = kc1.clone(), vc1.clone()
+    scale = 1.0 / math.sqrt(128)
+    args = (bt.to(DEV), ctx.to(DEV), hq, hkv, block_size, scale)
+    q = ops.qknorm_rope_store(qkv, qw, kw, 1e-6, pos.to(DEV), table, kc1, vc1, slots.to(DEV), hq, hkv, block_size)
+    out1 = ops.paged_attn_decode(q, kc1, vc1, *args)
+    out2 = ops.paged_attn_decode_fused(qkv, qw, kw, 1e-6, pos.to(DEV), table, slots.to(DEV), kc2, vc2, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(out1.view(torch.int16), out2.view(torch.int16))
+    keep = [b for b in range(nblk) if b != dummy]  # the fused launch does not write a padded row's dummy slot
+    assert torch.equal(kc1[keep].view(torch.int16), kc2[keep].view(torch.int16))
+    assert torch.equal(vc1[keep].view(torch.int16), vc2[keep].view(torch.int16))
+    # ... and it IS the attention of the oracle over the updated cache
+    want = oracle.paged_attention_decode(q.cpu().view(B, hq, 128), to_logical(kc1.cpu(), block_size, False),
+                                         to_logical(vc1.cpu(), block_size, True), bt, ctx, keep_fp32=True)
+    err = (out2.cpu().float() - want).abs()
+    assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
+    # few sequences: the context is split over several workgroups (merge kernel), same bits again
+    few = [13, 17]  # rows with ctx 1024 and 2049
+    sel = torch.tensor(few)
+    kc3, vc3 = to_fragment(kc_l, False).to(DEV), to_fragment(vc_l, True).to(DEV)
+    out3 = ops.paged_attn_decode_fused(qkv[sel.to(DEV)].contiguous(), qw, kw, 1e-6, pos[sel].to(DEV), table,
+                                       slots[sel].contiguous().to(DEV), kc3, vc3, bt[sel].contiguous().to(DEV),
+                                       ctx[sel].to(DEV), hq, hkv, block_size, scale)
+    err3 = (out3.cpu().float() - want[sel]).abs()
+    assert bool((err3 <= want[sel].abs() * 2 ** -8 + 1e-4).all()), err3.max().item()
+    for i in few:  # the stored rows are the same bits
+        b, off = int(slots[i][0]), int(slots[i][1])
+        assert torch.equal(to_logical(kc3.cpu(), block_size, False)[b, off].view(torch.int16),
+                           to_logical(kc1.cpu(), block_size, False)[b, off].view(torch.int16))
+        assert torch.equal(to_logical(vc3.cpu(), block_size, True)[b, off].view(torch.int16),
+                           to_logical(vc1.cpu(), block_size, True)[b, off].view(torch.int16))
 
 
 def test_prefill_attention_golden(ops, golden_attention):

@@ -93,6 +93,29 @@ def main():
         byt2 = B * 2 * c2 * hkv * 128 * 2
         res[f"paged_attn_decode ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
 
+    # geometry A/B (MI355_ATTN_PIPE is read per call; a captured graph keeps its choice) and the fused step
+    os.environ["MI355_ATTN_PIPE"] = "0"
+    t = timeit(lambda l: ops.paged_attn_decode(q, kc[l], vc[l], perm, ctxl, hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
+    res["paged_attn_decode 16 waves (r01)"] = {"us": t * 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
+    os.environ["MI355_ATTN_PIPE"] = "1"
+    qkv_ = torch.randn(B, (hq + 2 * hkv) * 128, device=DEV).bfloat16()
+    w128 = torch.ones(128, device=DEV).bfloat16()
+    rope_t = torch.randn(4096, 128, device=DEV)
+    for c2 in (ctx, 1100):
+        ctx2 = torch.full((B,), c2, dtype=torch.int32, device=DEV)
+        nb2 = (c2 + bs - 1) // bs
+        perm2 = torch.randperm(nblk, generator=g)[: B * nb2].to(torch.int32).view(B, nb2).to(DEV)
+        pos2 = torch.full((B,), c2 - 1, dtype=torch.int64, device=DEV)
+        sl2 = torch.stack([perm2[:, (c2 - 1) // bs], torch.full((B,), (c2 - 1) % bs, dtype=torch.int32, device=DEV)], 1).contiguous()
+        byt2 = B * 2 * c2 * hkv * 128 * 2
+        qo_ = torch.empty(B, hq * 128, dtype=torch.bfloat16, device=DEV)
+        t = timeit(lambda l: (ops.qknorm_rope_store(qkv_, w128, w128, 1e-6, pos2, rope_t, kc[l], vc[l], sl2, hq, hkv, bs, q_out=qo_),
+                              ops.paged_attn_decode(qo_, kc[l], vc[l], perm2, ctx2, hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws)), L)
+        res[f"rope_store + attn ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
+        t = timeit(lambda l: ops.paged_attn_decode_fused(qkv_, w128, w128, 1e-6, pos2, rope_t, sl2, kc[l], vc[l], perm2, ctx2,
+                                                         hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
+        res[f"attn fused step ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
+
     if os.environ.get("KBENCH_ONLY") == "attn":
         for k, v in res.items():
             print(f"{k:32s} " + "  ".join(f"{a}={b:9.2f}" for a, b in v.items()))
@@ -126,6 +149,23 @@ def main():
             res[name]["splitk4+addnorm_us"] = t5 * 1e6
             t6 = timeit(lambda l: (ops.gemm_packed(x, wp_[l], out=y), ops.add_rmsnorm(y, r, nw, 1e-6, out=y, residual_out=r)), n)
             res[name]["packed+addnorm_us"] = t6 * 1e6
+        if N <= 2048:  # complete rows from N/4 workgroups, and the pair (projection, consumer GEMM with norm prologue)
+            w4_ = [ops.pack_weight_rows4(w_) for w_ in ws_]
+            yr = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            t9 = timeit(lambda l: ops.gemm_rows4(x, w4_[l], out=yr), n)
+            res[name]["rows4_us"] = t9 * 1e6
+            wc_ = [ops.pack_weight((torch.randn(4096, N, device=DEV) * 0.02).bfloat16()) for _ in range(n)]
+            yc = torch.empty(M, 4096, dtype=torch.bfloat16, device=DEV)
+            r2 = torch.randn(M, N, device=DEV).bfloat16()
+            ro2 = torch.empty_like(r2)
+            xn2 = torch.empty_like(r2)
+            t10 = timeit(lambda l: (ops.gemm_rows4(x, w4_[l], out=yr),
+                                    ops.gemm_packed_addnorm(yr, r2, nw, 1e-6, wc_[l], out=yc, residual_out=ro2)), n)
+            res[name]["rows4+addnormGEMM4096_us"] = t10 * 1e6
+            t11 = timeit(lambda l: (ops.gemm_packed_splitk(x, wp_[l], 4, out=parts[:4]),
+                                    ops.add_rmsnorm_splitk(parts[:4], r2, nw, 1e-6, out=xn2, residual_out=ro2),
+                                    ops.gemm_packed(xn2, wc_[l], out=yc)), n)
+            res[name]["splitk4+addnorm+GEMM4096_us"] = t11 * 1e6
         if N == 6144:
             so_ = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
             t7 = timeit(lambda l: ops.gemm_packed(x, wp_[l], out=so_, silu_mul=True), n)
