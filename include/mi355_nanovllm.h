@@ -245,27 +245,17 @@ int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16
                         mi_bf16* y, int M, int N, int K, int epilogue, mi_stream stream);
 
 /* RowParallelLinear.forward without the all-reduce (linear.py:149-151) for the small-N projections
- * (o_proj, down_proj): y[M][N] = bf16(x[M][K] @ w[N][K]^T), complete rows from N / 4 workgroups of four
- * output features each (every CU streams weights; no split-K partials).  Weight layout
+ * (o_proj, down_proj) under tensor parallelism: y[M][N] = bf16(x[M][K] @ w[N][K]^T), this rank's bf16
+ * partial sums as complete rows from N / 4 workgroups of four output features each (every CU streams
+ * weights; the all-reduce wants bf16 rows, so split-K partials are no option).  A workgroup reads ALL of
+ * x: good for the short K of a TP shard, not for TP = 1 (there split-K + mi_add_rmsnorm_splitk moves a
+ * quarter of the activation bytes through each CU and measured faster).  Weight layout
  * w_packed4[N/4][K/32][4][4][8]:
  *   w_packed4[((tn*K/32 + tk)*16 + g*4 + n)*8 + e] = w[(4 tn + n)*K + 32 tk + 8 g + e].
  * 1 <= M <= 64, N % 4 == 0, K % 32 == 0. */
 int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed4, int N, int K, mi_stream stream);
 int mi_gemm_bf16_rows4(const mi_bf16* x, const mi_bf16* w_packed4, mi_bf16* y, int M, int N, int K,
                        mi_stream stream);
-
-/* RMSNorm.add_rms_forward (layernorm.py:27-38) folded into the column-parallel GEMM that consumes it
- * (qwen3.py:118-131: post-attention / next-layer norm, then gate_up / qkv projection):
- *   s = x + residual (fp32);  residual_out = bf16(s);
- *   y = mi_gemm_bf16_packed( bf16(bf16(s * rsqrt(mean(s^2) + eps)) * norm_w), w_packed, epilogue ).
- * Every workgroup recomputes the norm of its (<= 64 x K, L2-resident) input under the latency of its
- * weight stream; one workgroup writes residual_out, which must not alias x or residual.  Same rounding
- * points as mi_add_rmsnorm followed by mi_gemm_bf16_packed (sums of squares in a different order).
- * Built for K = 256 * {1, 2, 4, 8} with ceil(M / 16) * K / 256 <= 8 (K = 1024: M <= 32); other shapes
- * return MI_EUNSUPPORTED and the caller uses the two-call sequence. */
-int mi_gemm_bf16_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
-                                float eps, const mi_bf16* w_packed, mi_bf16* y, mi_bf16* residual_out,
-                                int M, int N, int K, int epilogue, mi_stream stream);
 
 /* Split-K over workgroups for the small-N row-parallel projections (o_proj, down_proj):
  * partials[ksplit][M][N] fp32, summed in split order and rounded to bf16 by the consumer
@@ -320,11 +310,6 @@ int mi_gemm_fp8w_packed(const mi_bf16* x, const uint8_t* w_packed, const float* 
                         int M, int N, int K, int epilogue, mi_stream stream);
 int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
                                float* partials, int M, int N, int K, int ksplit, mi_stream stream);
-/* mi_gemm_bf16_packed_addnorm on fp8 weights (K = 512 * {1, 2, 4}). */
-int mi_gemm_fp8w_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
-                                float eps, const uint8_t* w_packed, const float* scale, mi_bf16* y,
-                                mi_bf16* residual_out, int M, int N, int K, int epilogue,
-                                mi_stream stream);
 
 /* ---- tensor-parallel exchange over xGMI -----------------------------------
  * Stands in for the HCCL all-reduce after every row-parallel projection and the

@@ -27,37 +27,64 @@
 
 namespace mi {
 
-__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
-  return u32x4{pack_bf(f[0], f[1]), pack_bf(f[2], f[3]), pack_bf(f[4], f[5]), pack_bf(f[6], f[7])};
-}
-
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
 
-// Operands of the add + RMSNorm prologue (PRO): the GEMM input is not read from memory but computed,
-//   s = x + residual (fp32), residual_out = bf16(s), x' = bf16(bf16(s * rsqrt(mean(s^2) + eps)) * w)
-// (RMSNorm.add_rms_forward, layernorm.py:27-38, in front of a column-parallel linear, qwen3.py:118-131)
-struct NormPro {
-  const uint16_t* residual;  // [M][K]
-  const uint16_t* norm_w;    // [K]
-  uint16_t* residual_out;    // [M][K]; must not alias x or residual (other workgroups still read them)
-  float eps;
-};
+// B fragments (the activations x^T) of one wave for STEPS k-steps starting at xk = x + k0:
+//   bfrag[m][s] of lane (g, c) = x[16 m + c][k0 + 32 s + 8 g .. +7]   (rows >= M clamped to M - 1).
+// Read straight from memory a fragment load touches sixteen rows with 64 bytes each - sixteen cache
+// lines per instruction, half of each used - and costs the CU's address path as much as the weight
+// stream itself (tools/gemm_exp.py: 4.95 us per qkv launch, 4.16 without any x traffic, 4.23 with x
+// fetched in full lines).  So, for pairs of k-steps, the wave fetches its [16 MT rows][64 k] block as
+// whole 128-byte lines (8 lanes per row, 8 rows per instruction), parks it in its private LDS slab
+// (16-byte units XOR-swizzled by row) and reads the fragments back with ds_read_b128.  LDS operations of
+// one wave execute in order, so the slab needs no barrier and is reused for every pair.
+template <int MT, int STEPS>
+__device__ __forceinline__ void issue_x_lines(const uint16_t* __restrict__ x, int M, int K, int k0, int lane,
+                                              u32x4 (&stage)[(STEPS + 1) / 2][MT * 2]) {
+#pragma unroll
+  for (int sp = 0; sp < STEPS / 2; ++sp)
+#pragma unroll
+    for (int i = 0; i < MT * 2; ++i) {
+      const int row = i * 8 + (lane >> 3), c = lane & 7;
+      stage[sp][i] = *reinterpret_cast<const u32x4*>(x + (int64_t)min(row, M - 1) * K + k0 + 64 * sp + 8 * c);
+    }
+}
+template <int MT, int STEPS>
+__device__ __forceinline__ void x_lines_to_frags(const u32x4 (&stage)[(STEPS + 1) / 2][MT * 2], uint16_t* slab, int lane,
+                                                 u32x4 (&bfrag)[MT][STEPS]) {
+  const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+  for (int sp = 0; sp < STEPS / 2; ++sp) {
+#pragma unroll
+    for (int i = 0; i < MT * 2; ++i) {
+      const int row = i * 8 + (lane >> 3), c = lane & 7;
+      *reinterpret_cast<u32x4*>(slab + (row * 8 + (c ^ (row & 7))) * 8) = stage[sp][i];
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int row = 16 * m + r, c = 4 * h2 + g;
+        bfrag[m][2 * sp + h2] = *reinterpret_cast<const u32x4*>(slab + (row * 8 + (c ^ (row & 7))) * 8);
+      }
+  }
+}
+// bytes of one wave's slab: [16 MT rows][64 k] bf16
+constexpr int x_slab_bytes(int MT) { return MT * 16 * 64 * 2; }
 
 // WF: weight format - 0 row-major bf16, 1 fragment-native bf16, 2 fragment-native fp8 (e4m3) + per-row scale
-// PRO: every workgroup recomputes the add + RMSNorm of its (L2-resident, <= 64-row) input while its weight
-// fragments are in flight from HBM: each wave loads ITS K-slice of x and residual as B fragments, the row
-// sums of squares go lane -> xor-16/32 -> LDS -> summed in wave order (every workgroup gets the same
-// bits), and the normalised slice is the wave's MFMA operand without ever touching memory.  The wave's
-// K-slice must be one loop iteration (K == WAVES * 32 * STEPS); workgroup (0, 0) writes residual_out.
-template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS, bool PRO = false>
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K,
-    NormPro np = NormPro{}) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [WAVES][RT*MT][256] (+ PRO: [WAVES][64] row sums)
+    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K) {
+  // [WAVES][RT*MT][256] fp32 K-slice sums; before that, each wave's slot doubles as its x slab
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  constexpr int SLOT = RT * MT * 1024 > x_slab_bytes(MT) ? RT * MT * 1024 : x_slab_bytes(MT);  // bytes per wave
+  constexpr bool LINES = STEPS % 2 == 0;  // x in whole cache lines through LDS
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
+  uint16_t* slab = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(red) + wave * SLOT);
   const int ksplit = gridDim.y;
   const int kslice = K / (ksplit * WAVES);  // multiple of 32 * STEPS (checked on the host)
   const int kbeg = (blockIdx.y * WAVES + wave) * kslice;
@@ -94,103 +121,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   for (int k = 0; k < kslice; k += 32 * STEPS) {
     u32x4 a[RT][STEPS], bfrag[MT][STEPS];
     // every load of the block is issued before the first MFMA: no branches, no waits in between
-    if (PRO) {
-      // operand loads first (L2 hits), then the weight stream (HBM): vmcnt retires in order, so the
-      // prologue's wait covers only its own loads and runs under the weights' latency
-      u32x4 xa[MT][STEPS], ra[MT][STEPS], nw[STEPS];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-          xa[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + 32 * s);
-          ra[m][s] = *reinterpret_cast<const u32x4*>(np.residual + (xp[m] - x) + 32 * s);
-        }
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) nw[s] = *reinterpret_cast<const u32x4*>(np.norm_w + kbeg + 8 * g + 32 * s);
-      if (WF == 2) {
-        u32x4 raw[RT][(STEPS + 1) / 2];
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-          for (int s2 = 0; s2 < STEPS / 2; ++s2)
-            raw[t][s2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + s2 * 512));
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-          for (int s = 0; s < STEPS; ++s) {
-            const uint32_t lo = raw[t][s >> 1][2 * (s & 1)], hi = raw[t][s >> 1][2 * (s & 1) + 1];
-            const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
-            const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-            a[t][s] = u32x4{pack_bf(f0[0], f0[1]), pack_bf(f1[0], f1[1]), pack_bf(f2[0], f2[1]), pack_bf(f3[0], f3[1])};
-          }
-      } else {
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-          for (int s = 0; s < STEPS; ++s)
-            a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + s * WSTEP));
-      }
-      // s = x + residual is formed twice from the packed operands (two exact bf16 -> fp32 widenings and
-      // one add: same bits both times) rather than kept in 8 registers per fragment
-      auto s_of = [&](int m, int s, int j, float& v0, float& v1) {
-        v0 = lo_bf(xa[m][s][j]) + lo_bf(ra[m][s][j]);
-        v1 = hi_bf(xa[m][s][j]) + hi_bf(ra[m][s][j]);
-      };
-      float ss[MT];
-      const bool writer = blockIdx.x == 0 && blockIdx.y == 0;  // one workgroup holds every element of s once
-      {
-#pragma clang fp contract(off)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          ss[m] = 0.f;
-#pragma unroll
-          for (int s = 0; s < STEPS; ++s) {
-            u32x4 so;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float v0, v1;
-              s_of(m, s, j, v0, v1);
-              ss[m] += v0 * v0;
-              ss[m] += v1 * v1;
-              so[j] = pack_bf(v0, v1);
-            }
-            if (writer && 16 * m + r < M) *reinterpret_cast<u32x4*>(np.residual_out + (xp[m] - x) + 32 * s) = so;
-          }
-          ss[m] += __shfl_xor(ss[m], 16, 64);
-          ss[m] += __shfl_xor(ss[m], 32, 64);
-        }
-      }
-      float* rowss = red + WAVES * RT * MT * 256;  // [WAVES][64]
-      if (g == 0) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) rowss[wave * 64 + 16 * m + r] = ss[m];
-      }
-      // make the second formation of s a real recomputation (otherwise the compiler keeps all of s live
-      // across the barrier: 8 registers per fragment at the 128-register budget of a 16-wave workgroup)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) asm volatile("" : "+v"(xa[m][s]), "+v"(ra[m][s]));
-      __syncthreads();
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        float tot = rowss[16 * m + r];
-#pragma unroll
-        for (int wv = 1; wv < WAVES; ++wv) tot += rowss[wv * 64 + 16 * m + r];
-        const float rs = 1.0f / sqrtf(tot / (float)K + np.eps);
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-          u32x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v0, v1;
-            s_of(m, s, j, v0, v1);
-            o[j] = pack_bf(rbf(v0 * rs) * lo_bf(nw[s][j]), rbf(v1 * rs) * hi_bf(nw[s][j]));
-          }
-          bfrag[m][s] = o;
-        }
-      }
-    } else if (WF == 2) {
+    if (WF == 2) {
       static_assert(WF != 2 || STEPS % 2 == 0, "an fp8 fragment load covers two k-steps");
       u32x4 raw[RT][(STEPS + 1) / 2];
 #pragma unroll
@@ -198,10 +129,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
         for (int s2 = 0; s2 < STEPS / 2; ++s2)
           raw[t][s2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 6) + s2) * 512));
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+      u32x4 stage[(STEPS + 1) / 2][MT * 2];
+      issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+      x_lines_to_frags<MT, STEPS>(stage, slab, lane, bfrag);
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -217,10 +147,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
           a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 5) + s) * WSTEP));
+      if (LINES) {
+        u32x4 stage[(STEPS + 1) / 2][MT * 2];
+        issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+        x_lines_to_frags<MT, STEPS>(stage, slab, lane, bfrag);
+      } else {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+          for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+      }
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
@@ -237,17 +173,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-      *reinterpret_cast<f32x4*>(red + (((wave * RT + t) * MT + m) * 64 + lane) * 4) = acc[t][m];
+      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(red) + wave * SLOT + ((t * MT + m) * 64 + lane) * 16) = acc[t][m];
   __syncthreads();
   // each (row tile, m-tile, lane) result is finished by one thread, summing K-slices in wave order
   constexpr int ITEMS = (EPI == EPI_SILU ? 1 : RT) * MT * 64;
   for (int item = threadIdx.x; item < ITEMS; item += WAVES * 64) {
     const int l = item & 63, m = (item >> 6) % MT, t = (item >> 6) / MT;
     auto total = [&](int tt) {
-      f32x4 s = *reinterpret_cast<const f32x4*>(red + (((0 * RT + tt) * MT + m) * 64 + l) * 4);
+      f32x4 s = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(red) + ((tt * MT + m) * 64 + l) * 16);
 #pragma unroll
       for (int wv = 1; wv < WAVES; ++wv) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(red + (((wv * RT + tt) * MT + m) * 64 + l) * 4);
+        const f32x4 u =
+            *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(red) + wv * SLOT + ((tt * MT + m) * 64 + l) * 16);
         s += u;
       }
       if (WF == 2) s *= *reinterpret_cast<const f32x4*>(scale + tile[tt] * 16 + 4 * (l >> 4));  // per weight row
@@ -309,6 +246,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_rows4_kernel(const uint16_t* 
                                                                 const uint16_t* __restrict__ w4,
                                                                 uint16_t* __restrict__ y, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) float red[WAVES][MT][16][4];
+  __shared__ __attribute__((aligned(16))) uint16_t slabs[WAVES][STEPS % 2 == 0 ? MT * 16 * 64 : 8];  // x in whole lines
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -326,10 +264,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_rows4_kernel(const uint16_t* 
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
       a[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((k >> 5) + s) * 128));
+    if (STEPS % 2 == 0) {
+      u32x4 stage[(STEPS + 1) / 2][MT * 2];
+      issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+      x_lines_to_frags<MT, STEPS>(stage, &slabs[wave][0], lane, bfrag);
+    } else {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+        for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
 #pragma unroll
@@ -419,29 +363,14 @@ struct GemmArgs {
   int M, N, K, ksplit;
   hipStream_t st;
   const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
-  bool pro = false;              // add + RMSNorm prologue (np)
-  NormPro np = NormPro{};
 };
-
-// shapes the prologue kernels are instantiated for: 8 waves (256-register budget: the wave's K-slice of
-// x, residual, norm weight and weights in registers at once - 16 waves at 128 registers spilled)
-template <int MT, int WAVES, int STEPS, int WF, int EPI>
-constexpr bool pro_built() {
-  return WAVES == 8 && WF != 0 && MT * STEPS <= 8 && EPI != EPI_PARTIAL && (WF != 2 || STEPS % 2 == 0);
-}
 
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
 static void launch(const GemmArgs& a) {
-  const size_t lds = (size_t)WAVES * RT * MT * 256 * sizeof(float) + (a.pro ? WAVES * 64 * sizeof(float) : 0);
+  const size_t slot = (size_t)RT * MT * 1024 > (size_t)x_slab_bytes(MT) ? (size_t)RT * MT * 1024 : (size_t)x_slab_bytes(MT);
+  const size_t lds = (size_t)WAVES * slot;
   const int tiles = a.N / 16;
   const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
-  if constexpr (pro_built<MT, WAVES, STEPS, WF, EPI>()) {
-    if (a.pro) {
-      hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false, true>), grid, dim3(WAVES * 64), lds,
-                         a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.np);
-      return;
-    }
-  }
   if (a.bias && EPI == EPI_NONE)
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
                        a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K);
@@ -456,25 +385,15 @@ static bool try_waves(const GemmArgs& a) {
   if (a.K % (a.ksplit * WAVES)) return false;
   const int kslice = a.K / (a.ksplit * WAVES);
   constexpr int FRAGS = MT + RT;  // fragments (4 VGPRs each) per k-step
-  constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 6 ? 4 : 2);
-  if (a.pro) {  // one loop iteration per wave, and only the instantiated shapes
-    if (a.ksplit != 1 || a.bias) return false;
-    if constexpr (pro_built<MT, WAVES, 8, WF, EPI>()) {
-      if (kslice == 256) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
-    }
-    if constexpr (pro_built<MT, WAVES, 4, WF, EPI>()) {
-      if (kslice == 128) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
-    }
-    if constexpr (pro_built<MT, WAVES, 2, WF, EPI>()) {
-      if (kslice == 64) return launch<MT, RT, WAVES, 2, WF, EPI>(a), true;
-    }
-    if constexpr (pro_built<MT, WAVES, 1, WF, EPI>()) {
-      if (kslice == 32) return launch<MT, RT, WAVES, 1, WF, EPI>(a), true;
-    }
-    return false;
+  // k-steps in flight per wave and iteration, bounded by the 128-register budget of a 16-wave workgroup
+  // (x is staged as whole lines: its registers are live twice for a moment)
+  constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 5 ? 4 : 2);
+  if constexpr (MAXS >= 8) {
+    if (kslice % 256 == 0) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
   }
-  if (MAXS >= 8 && kslice % 256 == 0) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
-  if (MAXS >= 4 && kslice % 128 == 0) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
+  if constexpr (MAXS >= 4) {
+    if (kslice % 128 == 0) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
+  }
   if (kslice % 64 == 0) return launch<MT, RT, WAVES, 2, WF, EPI>(a), true;
   if constexpr (WF != 2) {  // an fp8 fragment load spans 64 k
     if (kslice % 32 == 0) return launch<MT, RT, WAVES, 1, WF, EPI>(a), true;
@@ -490,10 +409,6 @@ static int pick_waves(const GemmArgs& a) {
   const int wgs = (a.N / 16) / (EPI == EPI_SILU ? 2 : RT) * a.ksplit;
   const int kper = a.K / a.ksplit;
   bool ok = false;
-  if (a.pro) {
-    if (!try_waves<MT, RT, 8, WF, EPI>(a)) return MI_EUNSUPPORTED;
-    return check_launch();
-  }
   if (wgs >= 2048) {
     ok = try_waves<MT, RT, 4, WF, EPI>(a) || try_waves<MT, RT, 2, WF, EPI>(a);
   } else {
@@ -575,51 +490,6 @@ extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, co
   // two row tiles per workgroup halve the x traffic per weight byte once there are plenty of tiles
   if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, 1, EPI_NONE>(a);
   return pick_mt<1, 1, EPI_NONE>(a);
-}
-
-// add + RMSNorm prologue in front of the packed GEMM (see NormPro)
-static int check_addnorm(const void* residual, const void* norm_w, const void* residual_out, const void* x,
-                         int epilogue, int N) {
-  if (!residual || !norm_w || !residual_out) return MI_EINVAL;
-  if (!aligned16(residual) || !aligned16(norm_w) || !aligned16(residual_out)) return MI_EINVAL;
-  if (residual_out == residual || residual_out == x) return MI_EINVAL;
-  if (epilogue != 0 && epilogue != 1) return MI_EINVAL;
-  if (epilogue == 1 && N % 32) return MI_EUNSUPPORTED;
-  return MI_OK;
-}
-
-extern "C" int mi_gemm_bf16_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
-                                           float eps, const mi_bf16* w_packed, mi_bf16* y, mi_bf16* residual_out,
-                                           int M, int N, int K, int epilogue, mi_stream stream) {
-  int rc = check_gemm(x, w_packed, y, M, N, K);
-  if (rc != MI_OK) return rc;
-  rc = check_addnorm(residual, norm_w, residual_out, x, epilogue, N);
-  if (rc != MI_OK) return rc;
-  if (M == 0) return MI_OK;
-  GemmArgs a{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)};
-  a.pro = true;
-  a.np = NormPro{residual, norm_w, residual_out, eps};
-  if (epilogue == 1) return pick_mt<2, 1, EPI_SILU>(a);
-  return pick_mt<1, 1, EPI_NONE>(a);
-}
-
-extern "C" int mi_gemm_fp8w_packed_addnorm(const mi_bf16* x, const mi_bf16* residual, const mi_bf16* norm_w,
-                                           float eps, const uint8_t* w_packed, const float* scale, mi_bf16* y,
-                                           mi_bf16* residual_out, int M, int N, int K, int epilogue,
-                                           mi_stream stream) {
-  int rc = check_gemm(x, w_packed, y, M, N, K);
-  if (rc != MI_OK) return rc;
-  rc = check_addnorm(residual, norm_w, residual_out, x, epilogue, N);
-  if (rc != MI_OK) return rc;
-  if (!scale || !aligned16(scale)) return MI_EINVAL;
-  if (K % 64) return MI_EUNSUPPORTED;
-  if (M == 0) return MI_OK;
-  GemmArgs a{x, reinterpret_cast<const uint16_t*>(w_packed), nullptr, y, nullptr, M, N, K, 1, S(stream)};
-  a.scale = scale;
-  a.pro = true;
-  a.np = NormPro{residual, norm_w, residual_out, eps};
-  if (epilogue == 1) return pick_mt<2, 2, EPI_SILU>(a);
-  return pick_mt<1, 2, EPI_NONE>(a);
 }
 
 extern "C" int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream) {

@@ -176,35 +176,151 @@ struct FusedStep {
   float eps;
 };
 
-// One wavefront: lane (g, n) takes head n of {the G query heads of kv head h, then its k head}, dims
-// 8g + 32kk + e; normalised + rotated query heads go to LDS (sm_q[G][128]), the K and V row of the
-// step's token into their cache tile (k_tile / v_tile: element base of the 4 KiB tile, or nullptr).
+// Step prologue of the fused launch, run by ONE wavefront per workgroup.  Lane (g, n) takes head
+// hh = n (+16 for a second pass when G = 16) of {the G query heads of kv head h, then its k head}, dims
+// 8g + 32kk + e.  The operand loads are ISSUED before the wave's K/V tile loads (vmcnt retires in
+// order: they can then be waited for without waiting for the tiles) and CONSUMED behind them, so the
+// prologue's arithmetic runs under the tile loads' latency.
 template <int G>
-__device__ __forceinline__ void step_prologue(const uint16_t* row, int n_q_heads, int n_kv, int h,
-                                              const FusedStep& fs, const float* cs, uint16_t* k_tile,
-                                              uint16_t* v_tile, int tok, uint16_t* sm_q) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
-  for (int hh = n; hh < G + 1; hh += 16) {  // uniform over the four lanes that share a head
-    const bool is_k = hh == G;
-    const uint16_t* src = row + (int64_t)(is_k ? n_q_heads + h : h * G + hh) * 128;
-    float x[4][8];
+struct StepOperands {
+  static constexpr int PASSES = (G + 1 + 15) / 16;
+  u32x4 x[PASSES][4], w[PASSES][4];
+  float4 cs[8];  // cos(8g..), cos(8g+4..), sin(..), sin(..) for the pair (kk0, kk2), then for (kk1, kk3)
+  uint32_t v;    // two dims of the V row
+};
+
+template <int G>
+__device__ __forceinline__ void step_prologue_issue(StepOperands<G>& o, const uint16_t* row, int n_q_heads, int n_kv,
+                                                    int h, const FusedStep& fs, const float* cs, int lane) {
+  const int g = lane >> 4, n = lane & 15;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) load16(src + 8 * g + 32 * kk, x[kk]);
+  for (int ps = 0; ps < StepOperands<G>::PASSES; ++ps) {
+    const int hh = min(n + 16 * ps, G);  // lanes beyond the last head shadow the k head (results unused)
+    const bool is_k = hh == G;
+    const uint16_t* src = row + (int64_t)(is_k ? n_q_heads + h : h * G + hh) * 128 + 8 * g;
     const uint16_t* w = is_k ? fs.k_w : fs.q_w;
-    if (w != nullptr) head_rmsnorm_frag(x, w, g, fs.eps);
-    head_rope_frag(x, cs, g);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const u32x4 pk = pack16(x[kk]);
-      if (!is_k) *reinterpret_cast<u32x4*>(sm_q + hh * 128 + 8 * g + 32 * kk) = pk;
-      else if (k_tile != nullptr)  // k_tile_off(t, 32kk + 8g) = kk*512 + (g*16 + t)*8
-        *reinterpret_cast<u32x4*>(k_tile + kk * 512 + (g * 16 + tok) * 8) = pk;
+      o.x[ps][kk] = *reinterpret_cast<const u32x4*>(src + 32 * kk);
+      if (w != nullptr) o.w[ps][kk] = *reinterpret_cast<const u32x4*>(w + 8 * g + 32 * kk);
     }
   }
-  if (v_tile != nullptr) {  // V row: plain copy, two dims per lane
-    const uint32_t vv = *reinterpret_cast<const uint32_t*>(row + (int64_t)(n_q_heads + n_kv + h) * 128 + 2 * lane);
-    v_tile[v_tile_off(tok, 2 * lane)] = (uint16_t)(vv & 0xffffu);
-    v_tile[v_tile_off(tok, 2 * lane + 1)] = (uint16_t)(vv >> 16);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float* cp = cs + 32 * p + 8 * g;
+    o.cs[4 * p + 0] = *reinterpret_cast<const float4*>(cp);
+    o.cs[4 * p + 1] = *reinterpret_cast<const float4*>(cp + 4);
+    o.cs[4 * p + 2] = *reinterpret_cast<const float4*>(cp + 64);
+    o.cs[4 * p + 3] = *reinterpret_cast<const float4*>(cp + 68);
+  }
+  o.v = *reinterpret_cast<const uint32_t*>(row + (int64_t)(n_q_heads + n_kv + h) * 128 + 2 * lane);
+}
+
+// q/k RMSNorm + RoPE with the rounding points (and the summation order) of head_rmsnorm / head_rope in
+// kv_store.hpp; query heads -> sm_q[G][128], the new K / V row -> sm_k / sm_v and (k_tile / v_tile non-null)
+// into the cache tile.
+template <int G>
+__device__ __forceinline__ void step_prologue_finish(const StepOperands<G>& o, bool has_norm, float eps, int lane,
+                                                     uint16_t* k_tile, uint16_t* v_tile, int tok, uint16_t* sm_q,
+                                                     uint16_t* sm_k, uint16_t* sm_v) {
+#pragma clang fp contract(off)
+  const int g = lane >> 4, n = lane & 15;
+  u32x4 krow[4] = {};
+#pragma unroll
+  for (int ps = 0; ps < StepOperands<G>::PASSES; ++ps) {
+    const int hh = n + 16 * ps;
+    float x[4][8];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[kk][2 * j] = lo_bf(o.x[ps][kk][j]);
+        x[kk][2 * j + 1] = hi_bf(o.x[ps][kk][j]);
+      }
+    if (has_norm) {  // head_rmsnorm_frag with the weights already in registers
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lo += x[0][i] * x[0][i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lo += x[2][i] * x[2][i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hi += x[1][i] * x[1][i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hi += x[3][i] * x[3][i];
+      lo += __shfl_xor(lo, 16, 64);
+      lo += __shfl_xor(lo, 32, 64);
+      hi += __shfl_xor(hi, 16, 64);
+      hi += __shfl_xor(hi, 32, 64);
+      const float rs = 1.0f / sqrtf((lo + hi) / 128.0f + eps);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[kk][2 * j] = rbf(rbf(x[kk][2 * j] * rs) * lo_bf(o.w[ps][kk][j]));
+          x[kk][2 * j + 1] = rbf(rbf(x[kk][2 * j + 1] * rs) * hi_bf(o.w[ps][kk][j]));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float c[8] = {o.cs[4 * p].x, o.cs[4 * p].y, o.cs[4 * p].z, o.cs[4 * p].w,
+                          o.cs[4 * p + 1].x, o.cs[4 * p + 1].y, o.cs[4 * p + 1].z, o.cs[4 * p + 1].w};
+      const float sn[8] = {o.cs[4 * p + 2].x, o.cs[4 * p + 2].y, o.cs[4 * p + 2].z, o.cs[4 * p + 2].w,
+                           o.cs[4 * p + 3].x, o.cs[4 * p + 3].y, o.cs[4 * p + 3].z, o.cs[4 * p + 3].w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x1 = x[p][i], x2 = x[p + 2][i];
+        x[p][i] = rbf(x1 * c[i] - x2 * sn[i]);
+        x[p + 2][i] = rbf(x2 * c[i] + x1 * sn[i]);
+      }
+    }
+    if (hh <= G) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const u32x4 pk = pack16(x[kk]);
+        if (hh < G) {
+          *reinterpret_cast<u32x4*>(sm_q + hh * 128 + 8 * g + 32 * kk) = pk;
+        } else {
+          *reinterpret_cast<u32x4*>(sm_k + 8 * g + 32 * kk) = pk;
+          krow[kk] = pk;
+        }
+      }
+    }
+  }
+  *reinterpret_cast<uint32_t*>(sm_v + 2 * lane) = o.v;  // V row: plain copy, two dims per lane
+  // the cache stores come LAST: with loads and stores pending on the same counter, every wait would have
+  // to be vmcnt(0), i.e. wait for the wave's tile loads as well
+  if (k_tile != nullptr && n == G % 16) {  // k_tile_off(t, 32kk + 8g) = kk*512 + (g*16 + t)*8
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<u32x4*>(k_tile + kk * 512 + (g * 16 + tok) * 8) = krow[kk];
+  }
+  if (v_tile != nullptr) {
+    v_tile[v_tile_off(tok, 2 * lane)] = (uint16_t)(o.v & 0xffffu);
+    v_tile[v_tile_off(tok, 2 * lane + 1)] = (uint16_t)(o.v >> 16);
+  }
+}
+
+// Overwrite row `tok` of a loaded K / V tile with the step's token (sm_k / sm_v): the wave that attends
+// the context's last tile does not wait for the prologue wave's cache store, it patches its fragments.
+//   K fragment i of lane (g, n) = K[token n][32i + 8g .. +7]
+//   V fragment i of lane (g, n): dwords {0,1} = V[tokens 4g .. 4g+3][32i + n], {2,3} = V[..][32i + 16 + n]
+// `hit` (wave-uniform): this tile is the one that holds the token.  Callers patch BOTH tiles of a chunk
+// with their own `hit` instead of branching to one of them: two alternative calls get their common code
+// sunk behind a pointer phi, which forces the fragment arrays out of registers into scratch memory.
+__device__ __forceinline__ void patch_new_token(u32x4 (&K)[4], u32x4 (&V)[4], const uint16_t* sm_k,
+                                                const uint16_t* sm_v, int tok, int g, int n, bool hit) {
+  // branch-free bit masks with static register indices (a select over the dword index would be lowered
+  // to a dynamically indexed vector, i.e. through scratch memory)
+  const uint32_t sh = (tok & 1) * 16, field = 0xffffu << sh;
+  const bool mine = hit && g == (tok >> 2);
+  const uint32_t m_even = (mine && !(tok & 2)) ? field : 0u, m_odd = (mine && (tok & 2)) ? field : 0u;
+  const uint32_t m_k1 = hit && n == tok ? 0xffffffffu : 0u;
+  const u32x4 m_k = {m_k1, m_k1, m_k1, m_k1}, m_v = {m_even, m_odd, m_even, m_odd};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4 kn = *reinterpret_cast<const u32x4*>(sm_k + 32 * i + 8 * g);
+    const uint32_t va = (uint32_t)sm_v[32 * i + n] << sh, vb = (uint32_t)sm_v[32 * i + 16 + n] << sh;
+    K[i] = (K[i] & ~m_k) | (kn & m_k);
+    V[i] = (V[i] & ~m_v) | (u32x4{va, va, vb, vb} & m_v);
   }
 }
 
@@ -226,6 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   __shared__ float sm_l[WAVES][16];
   // PIPE: the step's query heads, staged once per workgroup (FUSE: produced by the prologue wave)
   __shared__ __attribute__((aligned(16))) uint16_t sm_q[PIPE ? G : 1][128];
+  __shared__ __attribute__((aligned(16))) uint16_t sm_k[FUSE ? 128 : 8], sm_v[FUSE ? 128 : 8];  // the step's new K / V row
 
   const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
   const int ctx = max(ctx_lens[b], 0);
@@ -233,13 +350,12 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   // the context is cut into chunks of two 16-token tiles (only the very last chunk may hold one);
   // the chunks are dealt to the WAVES*splits waves as evenly as possible, each wave a contiguous run:
   // run r covers chunks [deal(r), deal(r + 1)), sizes differ by at most one, the longer runs come
-  // first (so the run that holds the LAST chunk - which, when FUSE, does the step prologue before its
-  // first load - is never a long one)
+  // first (so the last wave of a workgroup - which, when FUSE, also does the step prologue - never has
+  // a long one)
   const int n_chunks = (n_tiles + 1) >> 1, n_waves = WAVES * splits;
   const int deal_q = n_chunks / n_waves, deal_r = n_chunks % n_waves;
   auto deal = [&](int r) { return r * deal_q + min(r, deal_r); };
   const int wg_c0 = deal(split * WAVES), wg_c1 = deal((split + 1) * WAVES);
-  const int owner_vw = min(n_chunks, n_waves) - 1;  // the run with the last chunk (context end)
   const int64_t row0 = (int64_t)b * n_q_heads + h * G;  // first q head of this kv head
   if (wg_c0 >= wg_c1) {  // uniform for the workgroup: nothing to attend in this split
     if (splits == 1) {     // empty context (graph padding row): the output row is zero
@@ -260,22 +376,27 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int vw = split * WAVES + wave;
   const int t0 = 2 * deal(vw), t1 = min(n_tiles, 2 * deal(vw + 1));
 
-  if (FUSE) {
-    // The token of this step sits at position ctx - 1, i.e. in the last tile.  In the workgroup that
-    // attends that tile the prologue wave is the wave that owns it: it stores the new K / V row, drains
-    // the stores (vmcnt(0)) and only then issues its own tile loads, which therefore read the row back;
-    // nobody else in this launch reads that row.  Other splits run the prologue for the query heads only.
-    const int pro_wave = split == owner_vw / WAVES ? owner_vw % WAVES : 0;
-    if (wave == pro_wave) {
-      const int32_t blk = fs.slots[2 * b], off = fs.slots[2 * b + 1];
-      const bool store = split == owner_vw / WAVES && blk >= 0 && off >= 0;
-      const int64_t tile_w = (int64_t)blk * kvs.block + (int64_t)h * kvs.head + (int64_t)(off >> 4) * kvs.tile;
-      step_prologue<G>(q + (int64_t)b * q_stride, n_q_heads, (int)gridDim.y, h, fs,
-                       fs.cos_sin + fs.positions[b] * 128, store ? const_cast<uint16_t*>(kc) + tile_w : nullptr,
-                       store ? const_cast<uint16_t*>(vc) + tile_w : nullptr, off & 15, &sm_q[0][0]);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  // FUSE: the token of this step sits at position ctx - 1: row new_tok of tile new_tile.  The last wave of
+  // the workgroup (never a long run, see deal()) produces the query heads and that token's K / V row in LDS
+  // and - in split 0, which always has work - writes the row into the cache, fire and forget: the
+  // wave that attends new_tile patches the row into its fragments from LDS instead of reading it back.
+  const int new_tile = (ctx - 1) >> 4, new_tok = (ctx - 1) & 15;
+  const bool is_pro = FUSE && wave == WAVES - 1;
+  StepOperands<G> pro;
+  int32_t blk = 0, off = 0;  // fetched with the other prologue operands, i.e. ahead of the tile loads
+  if (is_pro) {
+    blk = fs.slots[2 * b];
+    off = fs.slots[2 * b + 1];
   }
+  auto finish_prologue = [&]() __attribute__((always_inline)) {
+    const bool store = split == 0 && blk >= 0 && off >= 0;  // split 0 always has work (the longer runs come first)
+    const int64_t tile_w = (int64_t)blk * kvs.block + (int64_t)h * kvs.head + (int64_t)(off >> 4) * kvs.tile;
+    step_prologue_finish<G>(pro, fs.q_w != nullptr, fs.eps, lane, store ? const_cast<uint16_t*>(kc) + tile_w : nullptr,
+                            store ? const_cast<uint16_t*>(vc) + tile_w : nullptr, off & 15, &sm_q[0][0], sm_k, sm_v);
+  };
+  if (is_pro)
+    step_prologue_issue<G>(pro, q + (int64_t)b * q_stride, n_q_heads, (int)gridDim.y, h, fs,
+                           fs.cos_sin + fs.positions[b] * 128, lane);
 
   if (PIPE && !FUSE && wave == 0) {  // stage the G query heads (contiguous G*256 bytes of the q row)
     for (int c = lane; c < G * 16; c += 64)
@@ -291,7 +412,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   // a single-tile chunk loads its tile twice (a cache hit) and masks the duplicate through the limit
   auto second = [&](int t) { return t + 1 < t1 ? t + 1 : t; };
   auto limit_of = [&](int t) { return t + 1 < t1 ? ctx : min(ctx, (t + 1) * 16); };
-  auto load_q = [&](bf16x8 (&Q)[4]) {
+  auto load_q = [&](bf16x8 (&Q)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       u32x4 v;
@@ -312,24 +433,33 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     u32x4 AK0[4], AK1[4], AV0[4], AV1[4], BK0[4], BK1[4], BV0[4], BV1[4];
     bf16x8 Q[4];
     int ta = t0, tb = t0 + 2;
-    auto load_a = [&]() {
+    auto load_a = [&]() __attribute__((always_inline)) {
       load_tiles(kc, table_row, ta, second(ta), h, kvs, tpb, lane, AK0, AK1);
       load_tiles(vc, table_row, ta, second(ta), h, kvs, tpb, lane, AV0, AV1);
     };
-    auto load_b = [&]() {
+    auto load_b = [&]() __attribute__((always_inline)) {
       load_tiles(kc, table_row, tb, second(tb), h, kvs, tpb, lane, BK0, BK1);
       load_tiles(vc, table_row, tb, second(tb), h, kvs, tpb, lane, BV0, BV1);
     };
-    auto attend_a = [&]() {
+    auto attend_a = [&]() __attribute__((always_inline)) {
+      if (FUSE && (ta == new_tile || ta + 1 == new_tile)) {  // wave-uniform, true once per (sequence, kv head)
+        patch_new_token(AK0, AV0, sm_k, sm_v, new_tok, g, n, ta == new_tile);
+        patch_new_token(AK1, AV1, sm_k, sm_v, new_tok, g, n, ta + 1 == new_tile);
+      }
       attend_chunk<true>(AK0, AK1, AV0, AV1, Q, ta * 16, limit_of(ta), limit_of(ta), scale_log2e, g, m, l, acc);
     };
-    auto attend_b = [&]() {
+    auto attend_b = [&]() __attribute__((always_inline)) {
+      if (FUSE && (tb == new_tile || tb + 1 == new_tile)) {
+        patch_new_token(BK0, BV0, sm_k, sm_v, new_tok, g, n, tb == new_tile);
+        patch_new_token(BK1, BV1, sm_k, sm_v, new_tok, g, n, tb + 1 == new_tile);
+      }
       attend_chunk<true>(BK0, BK1, BV0, BV1, Q, tb * 16, limit_of(tb), limit_of(tb), scale_log2e, g, m, l, acc);
     };
     if (tb < t1) {  // at least two chunks
       load_a();
+      if (is_pro) finish_prologue();  // under the latency of buffer A
       load_b();
-      __syncthreads();  // sm_q is complete (this wave's tile loads are in flight behind the barrier)
+      __syncthreads();  // sm_q (sm_k, sm_v) complete; this wave's tile loads are in flight behind the barrier
       load_q(Q);
       while (tb + 4 < t1) {  // both buffers have a successor
         attend_a();
@@ -350,10 +480,12 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
       }
     } else if (ta < t1) {  // a single chunk
       load_a();
+      if (is_pro) finish_prologue();
       __syncthreads();
       load_q(Q);
       attend_a();
     } else {
+      if (is_pro) finish_prologue();
       __syncthreads();
     }
   } else {

@@ -88,8 +88,6 @@ _SIGNATURES = {
     "mi_gemm_bf16_packed_splitk": (c_int, [_p, _p, _p, c_int, c_int, c_int, c_int, _p]),
     "mi_pack_weight_rows4": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_rows4": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
-    "mi_gemm_bf16_packed_addnorm": (c_int, [_p, _p, _p, c_float, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
-    "mi_gemm_fp8w_packed_addnorm": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_embedding": (c_int, [_p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
     "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),

@@ -151,11 +151,11 @@ class RowParallelLinear(LinearBase):
 
     def pack(self) -> None:
         super().pack()
-        # bf16 weights: a second decode layout whose GEMM returns complete rows from N/4 workgroups
-        # (mi_gemm_bf16_rows4); after super().pack() the parameter holds the (possibly dequantised) values
+        # tensor parallelism, bf16 weights: a second decode layout whose GEMM returns this rank's partial
+        # sums as complete bf16 rows from N/4 workgroups (mi_gemm_bf16_rows4)
         w = self.weight.data
-        if w.is_cuda and not isinstance(self.weight_packed, ops.Fp8Weight) and w.shape[0] % 4 == 0 \
-                and w.shape[1] % 32 == 0:
+        if self.tp_size > 1 and w.is_cuda and not isinstance(self.weight_packed, ops.Fp8Weight) \
+                and w.shape[0] % 4 == 0 and w.shape[1] % 32 == 0:
             self.weight_rows4 = ops.pack_weight_rows4(w, self.weight_rows4)
         else:
             self.weight_rows4 = None

@@ -180,31 +180,25 @@ class Qwen3Model(nn.Module):
         return ks
 
     def _forward_streaming(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
-        """<= 64 tokens (every decode step).  Single GPU, bf16 weights, <= 32 rows: FIVE launches per layer
-        (the reference's eager decode layer is ~13):
-          qkv GEMM with the add + RMSNorm of its input as prologue           (mi_gemm_bf16_packed_addnorm)
-          -> q/k-norm + RoPE + KV store + paged attention                     (mi_paged_attn_decode_fused)
-          -> o_proj, complete bf16 rows from N/4 workgroups                   (mi_gemm_bf16_rows4)
-          -> gate_up GEMM, add + RMSNorm prologue, SwiGLU epilogue            (mi_gemm_bf16_packed_addnorm)
-          -> down_proj                                                        (mi_gemm_bf16_rows4)
-        Shapes outside that (fp8 weights, > 32 rows, other widths) and MI355_DECODE_FUSION=0 take the
-        eight-launch sequence add+RMSNorm (summing split-K partials) -> qkv -> q/k-norm+RoPE+store ->
-        attention -> split-K o_proj -> add+RMSNorm -> gate_up+SwiGLU -> split-K down_proj.
-        With tensor parallelism the two row-parallel projections produce bf16 partial sums; the all-reduce
-        over the ranks (linear.py:149-153) and the following add+RMSNorm are ONE launch over xGMI
-        (mi_allreduce_add_rmsnorm), or RCCL all-reduce + add+RMSNorm when that path is off.
-        Rounding points are those of the module-by-module path in every variant (tests require equal
-        results up to fp32 summation order)."""
+        """<= 64 tokens (every decode step): SEVEN launches per layer (the reference's eager decode layer
+        is ~13):
+          add+RMSNorm (summing the previous projection's split-K partials)      (mi_add_rmsnorm_splitk)
+          -> packed qkv GEMM                                                     (mi_gemm_bf16_packed)
+          -> q/k-norm + RoPE + KV store + paged attention in one launch          (mi_paged_attn_decode_fused)
+          -> split-K o_proj -> add+RMSNorm -> gate_up GEMM + SwiGLU epilogue -> split-K down_proj.
+        MI355_ATTN_FUSED=0 keeps q/k-norm+RoPE+store as its own launch (mi_qknorm_rope_store).
+        With tensor parallelism the two row-parallel projections produce bf16 partial sums as complete
+        rows (mi_gemm_bf16_rows4); the all-reduce over the ranks (linear.py:149-153) and the following
+        add+RMSNorm are ONE launch over xGMI (mi_allreduce_add_rmsnorm), or RCCL all-reduce + add+RMSNorm
+        when that path is off.  Rounding points are those of the module-by-module path in every variant
+        (tests require equal results up to fp32 summation order)."""
         tp = tp_size()
         ctx = get_context()
         h = self.embed_tokens(input_ids)
         rows = h.shape[0]
-        fusion = os.environ.get("MI355_DECODE_FUSION", "1") != "0"
         l0 = self.layers[0]
-        # complete-row projections: bf16 weights only (fp8 keeps the split-K kernels)
-        rows4 = fusion and l0.self_attn.o_proj.weight_rows4 is not None and l0.mlp.down_proj.weight_rows4 is not None
-        fuse_attn = fusion and not ctx.is_prefill and os.environ.get("MI355_ATTN_FUSED", "1") != "0"
-        fuse_norm = rows4 and tp == 1 and os.environ.get("MI355_NORM_FUSED", "1") != "0"
+        rows4 = tp > 1 and l0.self_attn.o_proj.weight_rows4 is not None and l0.mlp.down_proj.weight_rows4 is not None
+        fuse_attn = not ctx.is_prefill and os.environ.get("MI355_ATTN_FUSED", "1") != "0"
 
         xgmi = get_xgmi_comm() if tp > 1 else None
         fused_seam = (xgmi is not None and xgmi.fits_rows(rows, h.shape[1])
@@ -245,10 +239,6 @@ class Qwen3Model(nn.Module):
 
         def norm_linear(y, is_partials, res, ln, w_packed, silu_mul=False):
             """linear(rmsnorm(y + res)) -> (out, new residual)"""
-            if fuse_norm and not is_partials:
-                got = ops.gemm_packed_addnorm(y, res, ln.weight, ln.eps, w_packed, silu_mul=silu_mul)
-                if got is not None:
-                    return got
             x, res = add_norm(y, is_partials, res, ln)
             return ops.gemm_packed(x, w_packed, silu_mul=silu_mul), res
 

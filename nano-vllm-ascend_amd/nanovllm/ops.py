@@ -365,38 +365,6 @@ def gemm_rows4(x, w_packed4, out=None) -> torch.Tensor:
     return out
 
 
-def gemm_packed_addnorm(x, residual, norm_w, eps: float, w_packed, silu_mul: bool = False, out=None,
-                        residual_out=None):
-    """(y, residual_out) with residual_out = bf16(x + residual) and y = gemm_packed(rmsnorm(x + residual), w_packed):
-    RMSNorm.add_rms_forward folded into the prologue of the GEMM that consumes it.  Returns None when the
-    shape is outside what the prologue kernels are built for (the caller then uses the two-call sequence)."""
-    require_gpu(x, residual, norm_w)
-    _bf16(x, residual, norm_w)
-    assert x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
-    K = x.shape[-1]
-    M = x.numel() // K
-    N = w_packed.shape[0]
-    assert w_packed.shape[1] == K and norm_w.numel() == K
-    n_out = N // 2 if silu_mul else N
-    if out is None:
-        out = torch.empty((*x.shape[:-1], n_out), dtype=_BF16, device=x.device)
-    if residual_out is None:
-        residual_out = torch.empty_like(residual)
-    if isinstance(w_packed, Fp8Weight):
-        rc = lib.mi_gemm_fp8w_packed_addnorm(ptr(x), ptr(residual), ptr(norm_w), float(eps), ptr(w_packed.data),
-                                             ptr(w_packed.scale), ptr(out), ptr(residual_out), M, N, K,
-                                             int(silu_mul), stream())
-    else:
-        require_gpu(w_packed)
-        _bf16(w_packed)
-        rc = lib.mi_gemm_bf16_packed_addnorm(ptr(x), ptr(residual), ptr(norm_w), float(eps), ptr(w_packed), ptr(out),
-                                             ptr(residual_out), M, N, K, int(silu_mul), stream())
-    if rc == _C.MI_EUNSUPPORTED:
-        return None
-    check(rc, "mi_gemm_packed_addnorm")
-    return out, residual_out
-
-
 def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:
     """fp32 partials [ksplit, M, N] of x @ w.T; consume with add_rmsnorm_splitk."""
     require_gpu(x)

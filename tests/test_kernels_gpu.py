@@ -366,49 +366,8 @@ def test_gemm_rows4(ops, M, N, K):
         xe[3, 5] = 1.0
         ye = ops.gemm_rows4(xe.to(DEV), w4).cpu()
         assert torch.equal(ye[3].view(torch.int16), w[:, 5].contiguous().view(torch.int16))
-        assert float(ye.float().abs().sum() - ye[3].float().abs().sum()) == 0.0
-
-
-@pytest.mark.parametrize("M", [1, 5, 16, 32])
-@pytest.mark.parametrize("N,K,silu", [(4096, 1024, False), (6144, 1024, True), (512, 256, False), (1024, 512, True),
-                                      (2048, 2048, False)])
-def test_gemm_packed_addnorm(ops, M, N, K, silu):
-    """add + RMSNorm folded into the GEMM prologue: residual_out is the exact bf16(x + residual); y equals
-    the two-call sequence up to the norm's summation order (<= 1 ulp of the GEMM input on a few elements)"""
-    g = torch.Generator().manual_seed(M + N + K)
-    x = torch.randn(M, K, generator=g).bfloat16()
-    r = (torch.randn(M, K, generator=g) * 2).bfloat16()
-    nw = (1 + 0.2 * torch.randn(K, generator=g)).bfloat16()
-    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
-    wp = ops.pack_weight(w.to(DEV))
-    got = ops.gemm_packed_addnorm(x.to(DEV), r.to(DEV), nw.to(DEV), 1e-6, wp, silu_mul=silu)
-    if K == 2048 and M > 16:
-        assert got is None  # outside the built shapes: the caller falls back
-        return
-    y, r2 = got
-    xn, ro = oracle.add_rms_norm(x, r, nw, 1e-6)
-    assert torch.equal(r2.cpu().view(torch.int16), ro.view(torch.int16))
-    want = oracle.linear(xn, w)
-    atol = K * 2.0 ** -20  # a 1-ulp flip of one normalised input moves an output by up to |w| * 2^-7
-    if silu:
-        assert_bf16_close(y, oracle.silu_and_mul(want), max_ulp=2, max_frac=5e-2, atol=32 * atol)
-    else:
-        assert_bf16_close(y, want, max_ulp=1, max_frac=3e-2, atol=atol)
-    # and against this library's own two-call sequence
-    xn_d, r_d = ops.add_rmsnorm(x.to(DEV), r.to(DEV), nw.to(DEV), 1e-6)
-    assert torch.equal(r_d.view(torch.int16), r2.view(torch.int16))
-    y2 = ops.gemm_packed(xn_d, wp, silu_mul=silu)
-    assert_bf16_close(y, y2.cpu(), max_ulp=2, max_frac=5e-2, atol=32 * atol)
-
-
-def test_gemm_packed_addnorm_rejects_aliasing(ops):
-    x = torch.zeros(32, 1024, dtype=torch.bfloat16, device=DEV)
-    r = torch.zeros_like(x)
-    nw = torch.ones(1024, dtype=torch.bfloat16, device=DEV)
-    wp = ops.pack_weight(torch.zeros(4096, 1024, dtype=torch.bfloat16, device=DEV))
-    from nanovllm._C import MiError
-    with pytest.raises(MiError):
-        ops.gemm_packed_addnorm(x, r, nw, 1e-6, wp, residual_out=r)
+        ye[3] = 0
+        assert not bool(ye.float().abs().max() > 0)  # every other row is exactly zero
 
 
 def test_gemm_lm_head_shape(ops):

@@ -154,18 +154,6 @@ def main():
             yr = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
             t9 = timeit(lambda l: ops.gemm_rows4(x, w4_[l], out=yr), n)
             res[name]["rows4_us"] = t9 * 1e6
-            wc_ = [ops.pack_weight((torch.randn(4096, N, device=DEV) * 0.02).bfloat16()) for _ in range(n)]
-            yc = torch.empty(M, 4096, dtype=torch.bfloat16, device=DEV)
-            r2 = torch.randn(M, N, device=DEV).bfloat16()
-            ro2 = torch.empty_like(r2)
-            xn2 = torch.empty_like(r2)
-            t10 = timeit(lambda l: (ops.gemm_rows4(x, w4_[l], out=yr),
-                                    ops.gemm_packed_addnorm(yr, r2, nw, 1e-6, wc_[l], out=yc, residual_out=ro2)), n)
-            res[name]["rows4+addnormGEMM4096_us"] = t10 * 1e6
-            t11 = timeit(lambda l: (ops.gemm_packed_splitk(x, wp_[l], 4, out=parts[:4]),
-                                    ops.add_rmsnorm_splitk(parts[:4], r2, nw, 1e-6, out=xn2, residual_out=ro2),
-                                    ops.gemm_packed(xn2, wc_[l], out=yc)), n)
-            res[name]["splitk4+addnorm+GEMM4096_us"] = t11 * 1e6
         if N == 6144:
             so_ = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
             t7 = timeit(lambda l: ops.gemm_packed(x, wp_[l], out=so_, silu_mul=True), n)
