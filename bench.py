@@ -4,7 +4,16 @@ bf16, paged decode under hipGraph — BASELINE.json configs[1] — on N MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W          # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W   # N ranks, tensor parallel over RCCL
+        --master-port P bench.py --gpus N --steps K --warmup W [--mode replicas|tp]
+
+N > 1 has two modes (the JSON line says which: `mode`, `scaling`, `config.parallelism`):
+  replicas (default)  the decode batch is a set of independent sequences, so the path shards with NO
+                      data-path collective: every rank runs the whole 0.6 B model on its own GPU over its own
+                      32 sequences (global batch 32 N, weak scaling); `value` is the sum over ranks of
+                      tokens / the slowest rank's time (barrier + synchronize on both sides, max over ranks).
+  tp                  Megatron tensor parallelism over RCCL/xGMI at the fixed batch of 32 (strong scaling):
+                      what a model that does not fit one GPU needs (BASELINE configs[2]); for this 0.6 B
+                      model every all-reduce is a 64 KiB latency-bound message, so it does not speed up.
 
 A "step" is one engine decode step over the batch of 32 sequences (scheduler -> metadata
 -> graph replay -> sampling -> postprocess), i.e. 32 new tokens.  Inputs are synthetic
@@ -112,14 +121,32 @@ def _attention_roofline(llm, seqs, iters):
         tables = torch.randperm(nblk - 1)[: real * width].to(torch.int32).view(real, width).to(dev)
     attn_mods = [m for m in mr.model.modules() if hasattr(m, "k_cache") and hasattr(m, "v_cache")]
     a0 = attn_mods[0]
-    q = torch.randn(real, a0.num_heads * 128, device=dev).bfloat16()
-    out = torch.empty_like(q)
+    out = torch.empty(real, a0.num_heads * 128, dtype=torch.bfloat16, device=dev)
     ws = ops.attn_workspace(dev, real, a0.num_heads)
+    fused = os.environ.get("MI355_ATTN_FUSED", "1") != "0"
+    if fused:
+        # the launch the engine's decode step uses: q/k-norm + RoPE + KV store + attention straight from a
+        # packed qkv row.  Position ctx - 1 of every sequence is re-written with that (random) row - the run is
+        # over, and this is exactly the store a decode step performs.
+        qkv = torch.randn(real, (a0.num_heads + 2 * a0.num_kv_heads) * 128, device=dev).bfloat16()
+        pos = torch.tensor([c - 1 for c in ctx_host], dtype=torch.int64, device=dev)
+        slots = torch.tensor([[int(tables[i][(c - 1) // mr.block_size]), (c - 1) % mr.block_size]
+                              for i, c in enumerate(ctx_host)], dtype=torch.int32, device=dev)
+        layers = [l.self_attn for l in mr.model.model.layers]
 
-    def launch_all():
-        for m in attn_mods:
-            ops.paged_attn_decode(q, m.k_cache, m.v_cache, tables, ctx, m.num_heads, m.num_kv_heads,
-                                  mr.block_size, m.scale, out=out, workspace=ws)
+        def launch_all():
+            for sa in layers:
+                m = sa.attn
+                ops.paged_attn_decode_fused(qkv, sa.q_norm.weight, sa.k_norm.weight, sa.rms_norm_eps, pos,
+                                            sa.rotary_emb.cos_sin_cache, slots, m.k_cache, m.v_cache, tables, ctx,
+                                            m.num_heads, m.num_kv_heads, mr.block_size, m.scale, out=out, workspace=ws)
+    else:
+        q = torch.randn(real, a0.num_heads * 128, device=dev).bfloat16()
+
+        def launch_all():
+            for m in attn_mods:
+                ops.paged_attn_decode(q, m.k_cache, m.v_cache, tables, ctx, m.num_heads, m.num_kv_heads,
+                                      mr.block_size, m.scale, out=out, workspace=ws)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -140,20 +167,81 @@ def _attention_roofline(llm, seqs, iters):
     dur = s.elapsed_time(e) * 1e-3 / (iters * len(attn_mods))
     ctx_sum = int(sum(ctx_host))
     algo = ctx_sum * 2 * a0.num_kv_heads * 128 * 2  # K+V rows of every context token, bf16
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-    # gfx950 x2 read correction) of this same command, committed under profiles/; only quoted when
-    # the launch configuration matches the one that was profiled
-    traffic = None
+    # HBM bytes per launch: the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2
+    # read correction) of this same loop, committed under profiles/, give measured / algorithmic bytes for
+    # this kernel; the ratio is a property of the access pattern (every K/V tile of the context read once),
+    # so it is applied to this run's algorithmic bytes whatever --steps made the contexts
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(REPO, "profiles", "r01_attn_traffic.json")) as f:
+        import glob
+        newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_attn_traffic.json")))[-1]
+        with open(newest) as f:
             pmc = json.load(f)
-        if pmc["batch"] == real and pmc["ctx_sum"] == ctx_sum:
-            traffic = pmc["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        traffic = pmc["traffic_over_algorithmic"] * algo
+        traffic_src = f"{os.path.basename(newest)}: measured/algorithmic = {pmc['traffic_over_algorithmic']:.4f} at ctx_sum {pmc['ctx_sum']}"
+    except (OSError, KeyError, ValueError, IndexError):
         pass
-    return {"kernel": "paged_attn_decode_kernel", "bound": "hbm", "achieved": algo / dur / 1e9,
+    return {"kernel": "paged_attn_decode_kernel" + (" (fused step: q/k-norm + RoPE + KV store + attention)" if fused else ""),
+            "bound": "hbm", "achieved": algo / dur / 1e9,
             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / dur / HBM_PEAK, "traffic": traffic,
+            "traffic_source": traffic_src,
             "bytes_per_launch": algo, "avg_launch_us": dur * 1e6, "launches_timed": iters * len(attn_mods)}
+
+
+def chain_roofline(llm, batch: int, iters: int = 20):
+    """The six launches per layer that are NOT attention (add+RMSNorm x2, qkv / o_proj / gate_up+SwiGLU /
+    down_proj GEMMs) replayed as one graph over all layers' real weights, HIP events on the launch stream:
+    algorithmic bytes = the layers' weights (activations excluded, as BASELINE.md §2) / time."""
+    import torch
+
+    from nanovllm import ops
+
+    with torch.inference_mode():
+        model = llm.model_runner.model.model
+        dev = llm.model_runner.device
+        hidden = model.embed_tokens.weight.shape[1]
+        ks = [(model._ksplit(l.self_attn.o_proj.weight), model._ksplit(l.mlp.down_proj.weight)) for l in model.layers]
+        res = torch.randn(batch, hidden, device=dev).bfloat16()
+        parts = torch.randn(ks[0][1], batch, hidden, device=dev) * 0.1
+        o = torch.randn(batch, model.layers[0].self_attn.o_proj.weight.shape[1], device=dev).bfloat16()
+
+        def run():
+            p = parts
+            for layer, (ko, kd) in zip(model.layers, ks):
+                attn, mlp = layer.self_attn, layer.mlp
+                x, r = ops.add_rmsnorm_splitk(p, res, layer.input_layernorm.weight, layer.input_layernorm.eps)
+                ops.gemm_packed(x, attn.qkv_proj.weight_packed)
+                p2 = ops.gemm_packed_splitk(o, attn.o_proj.weight_packed, ko)
+                x, r = ops.add_rmsnorm_splitk(p2, r, layer.post_attention_layernorm.weight,
+                                              layer.post_attention_layernorm.eps)
+                act = ops.gemm_packed(x, mlp.gate_up_proj.weight_packed, silu_mul=True)
+                p = ops.gemm_packed_splitk(act, mlp.down_proj.weight_packed, kd)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+        graph.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        dur = s.elapsed_time(e) * 1e-3 / iters
+        wbytes = sum(w.numel() * 2 for l in model.layers
+                     for w in (l.self_attn.qkv_proj.weight, l.self_attn.o_proj.weight, l.mlp.gate_up_proj.weight,
+                               l.mlp.down_proj.weight))
+        n = len(model.layers)
+        return {"kernels": "add_rmsnorm_splitk x2, gemm_skinny qkv / o_proj split-K / gate_up+SwiGLU / down_proj split-K",
+                "bound": "hbm", "achieved": wbytes / dur / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": wbytes / dur / HBM_PEAK, "bytes_per_layer": wbytes // n, "us_per_layer": dur / n * 1e6,
+                "launches_per_layer": 6, "layers": n}
 
 
 def main():
@@ -161,19 +249,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--mode", choices=("replicas", "tp"), default="replicas",
+                    help="N > 1: independent replicas (weak scaling, default) or tensor parallelism (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    from model_configs import QWEN3_0_6B, make_model_dir
+    from model_configs import QWEN3_0_6B
     from nanovllm import LLM, SamplingParams
     from nanovllm.engine.llm_engine import run_worker
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    tp = world if args.mode == "tp" else 1
     port = int(os.environ.get("MASTER_PORT", "29500"))
     if world > 1:
         local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
@@ -196,18 +287,18 @@ def main():
         dist.barrier()
     total_new = args.warmup + args.steps + 2
     blocks_needed = BATCH * ((PROMPT_LEN + total_new) // BLOCK + 2) + 64
-    kw = dict(tensor_parallel_size=world, kvcache_block_size=BLOCK, max_num_seqs=BATCH, max_model_len=4096,
+    kw = dict(tensor_parallel_size=tp, kvcache_block_size=BLOCK, max_num_seqs=BATCH, max_model_len=4096,
               max_num_batched_tokens=16384,
               num_kvcache_blocks=int(os.environ.get("BENCH_NBLK", max(blocks_needed, 4096))), hccl_port=port + 1,
-              synthetic_seed=0, warmup=os.environ.get("BENCH_NO_WARMUP") is None,
+              synthetic_seed=0, sampling_seed=0, warmup=os.environ.get("BENCH_NO_WARMUP") is None,
               quantization=os.environ.get("BENCH_QUANT") or None,  # "fp8": side experiment, never the default line
               enforce_eager=os.environ.get("BENCH_EAGER") is not None)
-    if rank != 0:
+    if tp > 1 and rank != 0:
         run_worker(model_dir, **kw)
         return
 
     llm = LLM(model_dir, **kw)
-    random.seed(0)
+    random.seed(rank if tp == 1 else 0)  # replicas: every rank its own prompts
     prompts = [[random.randint(0, 10000) for _ in range(PROMPT_LEN)] for _ in range(BATCH)]
     sp = SamplingParams(temperature=1.0, max_tokens=total_new, ignore_eos=True, greedy=True)
     seqs = [llm.add_request(p, sp) for p in prompts]
@@ -218,6 +309,9 @@ def main():
     ttft = sorted(llm.ttft[s.seq_id] for s in seqs)
     for _ in range(args.warmup):
         llm.step()
+    replicas = world > 1 and tp == 1
+    if replicas:
+        dist.barrier()
     torch.cuda.synchronize()
     ctx0 = len(seqs[0])
     t0 = time.perf_counter()
@@ -225,19 +319,40 @@ def main():
         _, n = llm.step()
         assert n == -BATCH
     torch.cuda.synchronize()
+    if replicas:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     ctx1 = len(seqs[0])
-    algo = sum(step_bytes(BATCH, c) for c in range(ctx0 + 1, ctx1 + 1))
-    value = BATCH * args.steps / elapsed
+    n_rep = 1
+    if replicas:  # the slowest rank's clock; TTFTs of all ranks
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tt = torch.tensor(ttft, dtype=torch.float64, device=dev)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        ttft = sorted(float(x) for x in torch.cat(allt).cpu())
+        n_rep = world
+    algo = n_rep * sum(step_bytes(BATCH, c) for c in range(ctx0 + 1, ctx1 + 1))
+    value = n_rep * BATCH * args.steps / elapsed
+    if world == 1:
+        par, agg = "tp1", "one GPU"
+    elif replicas:
+        par = f"dp{world} (independent replicas of bs {BATCH}; no data-path collective)"
+        agg = f"sum over {world} replicas, global batch {BATCH * world} (--mode tp: Megatron TP at fixed bs {BATCH})"
+    else:
+        par, agg = f"tp{world}", f"one model sharded over {world} GPUs at fixed bs {BATCH} (--mode replicas: weak scaling)"
     result = {
         "metric": "decode tokens/s, Qwen3-0.6B bs=32 seq=1024 (p50 TTFT in ttft_p50_ms)",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "strong" if tp > 1 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "mode": "tp" if tp > 1 else ("replicas" if replicas else "single"), "aggregate": agg,
         "config": {"workload": "Qwen3-0.6B bf16 paged decode under hipGraph, bs=32, 1024-token prompts, "
                                "block_size=16 (BASELINE.json configs[1])",
-                   "batch": BATCH, "prompt_len": PROMPT_LEN, "ctx_first": ctx0 + 1, "ctx_last": ctx1,
-                   "block_size": BLOCK, "parallelism": f"tp{world}", "greedy": True,
+                   "batch": BATCH, "global_batch": BATCH * n_rep, "prompt_len": PROMPT_LEN, "ctx_first": ctx0 + 1,
+                   "ctx_last": ctx1, "block_size": BLOCK, "parallelism": par, "greedy": True,
                    **({"weights": os.environ["BENCH_QUANT"]} if os.environ.get("BENCH_QUANT") else {})},
         "ttft_p50_ms": statistics.median(ttft) * 1e3, "ttft_max_ms": ttft[-1] * 1e3,
         "prefill_steps": prefill_steps,
@@ -245,11 +360,15 @@ def main():
                           "unit": "GB/s", "frac": algo / elapsed / (HBM_PEAK * world),
                           "bytes_per_step": algo / args.steps},
     }
+    mr = llm.model_runner
+    if tp > 1:  # what the ranks really ran on: visible to the driver
+        result["tp"] = {"world_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                        "xgmi_exchange": mr.xgmi is not None, "xgmi_selftest": getattr(mr, "xgmi_selftest", None),
+                        "decode_graphs": sorted(mr.graphs)}
     # device time of the captured decode step alone (graph replays back to back, HIP events):
     # ms_per_step minus this is the host share of a step (scheduler, metadata, sampling, sync)
-    mr = llm.model_runner
     bucket = mr._bucket_for(BATCH) if mr.graphs else None
-    if bucket is not None and world == 1:  # with TP the graph holds exchanges: rank 0 must not replay it alone
+    if bucket is not None and tp == 1:  # with TP the graph holds exchanges: rank 0 must not replay it alone
         g = mr.graphs[bucket]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g.replay()
@@ -260,8 +379,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         result["step_roofline"]["graph_replay_ms"] = e0.elapsed_time(e1) / 20
-    result["roofline"] = attention_roofline(llm, seqs) if world == 1 else None
+    if tp == 1 and rank == 0:
+        result["roofline"] = attention_roofline(llm, seqs)
+        result["chain_roofline"] = chain_roofline(llm, BATCH)
+    else:
+        result["roofline"] = None
     llm.exit()
+    if rank != 0:
+        return
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     print(json.dumps(result), flush=True)

@@ -45,6 +45,7 @@ class Config:
     device: str = "cuda"
     trust_remote_code: bool = False
     synthetic_seed: int = 0
+    sampling_seed: int | None = None  # seed of the temperature sampler; None: drawn from os.urandom per engine
     quantization: str | None = None  # "fp8": e4m3 weights + per-row scales for the decode GEMMs (no reference counterpart)
     prefix_aware_prefill: bool = True  # skip the tokens of cache-hit prefix blocks in prefill (False: recompute, as the reference)
 
@@ -54,6 +55,8 @@ class Config:
         assert 1 <= self.tensor_parallel_size <= 8
         assert self.graph_mode in {m.value for m in GraphMode}, self.graph_mode
         assert self.quantization in (None, "fp8"), self.quantization
+        if self.sampling_seed is None:
+            self.sampling_seed = int.from_bytes(os.urandom(8), "little") >> 1
         if self.hf_config is None:
             from transformers import AutoConfig
 

@@ -85,10 +85,12 @@ class ModelRunner:
             self.xgmi = xgmi_comm.create_if_enabled(rank, self.world_size, rows * self.hf_config.hidden_size * 2,
                                                     self.device)
             parallel.set_xgmi_comm(self.xgmi)
+            self.xgmi_selftest = xgmi_comm.LAST_STATUS
 
         dtype = _torch_dtype_of(self.hf_config)
         if dtype != torch.bfloat16:
             raise NotImplementedError(f"the gfx950 kernels are bf16; checkpoint dtype is {dtype}")
+        self._check_supported_shapes()
         from nanovllm.layers.linear import set_weight_quantization
 
         set_weight_quantization(config.quantization)
@@ -108,7 +110,7 @@ class ModelRunner:
             init_synthetic_weights(self.model, self.hf_config, seed=config.synthetic_seed)
             self.synthetic = True
         self.model.eval()
-        self.sampler = Sampler(seed=config.synthetic_seed)
+        self.sampler = Sampler(seed=config.sampling_seed)
         torch.cuda.empty_cache()
         self.allocate_kv_cache()
         self._alloc_staging()
@@ -116,6 +118,8 @@ class ModelRunner:
         self.graph_logits: dict[int, torch.Tensor] = {}
         # with TP the captured graph holds the xGMI exchange kernels; without them (RCCL all-reduce inside)
         # capture is only attempted on the nccl backend
+        if self.world_size > 1:
+            dist.barrier()  # weight loading can skew the ranks by more than the exchange kernels' patience
         if config.use_graphs and (self.world_size == 1 or self.xgmi is not None or dist.get_backend() == "nccl"):
             try:
                 self.capture_decode_graphs()
@@ -128,6 +132,21 @@ class ModelRunner:
                 reset_context()
         if self.world_size > 1:
             dist.barrier()
+
+    def _check_supported_shapes(self):
+        """What the attention kernels are compiled for, checked before the model is built and before any
+        graph capture (a failure there would surface as a bare MI_EUNSUPPORTED inside warm-up)."""
+        hf = getattr(self.hf_config, "text_config", self.hf_config)
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        hq, hkv = hf.num_attention_heads, hf.num_key_value_heads
+        if head_dim != 128:
+            raise NotImplementedError(f"head_dim {head_dim}: the paged-attention kernels are built for head_dim 128 "
+                                      "(all Qwen3 sizes)")
+        if hq % hkv or hq // hkv not in (1, 2, 4, 8, 16):
+            raise NotImplementedError(f"{hq} query heads over {hkv} kv heads: the attention kernels are built for "
+                                      "GQA group sizes 1, 2, 4, 8 and 16")
+        if hq % self.world_size or hkv % self.world_size:
+            raise ValueError(f"tensor_parallel_size {self.world_size} does not divide {hq} query / {hkv} kv heads")
 
     # ------------------------------------------------------------------ lifecycle / RPC
     def exit(self):
@@ -159,6 +178,8 @@ class ModelRunner:
             self.run(seqs, is_prefill)
 
     def call(self, method_name: str, *args):
+        if method_name == "run" and not args[0]:
+            return []  # nothing scheduled (everything preempted): no message, no collective, on any rank
         if self.channel is not None and self.rank == 0:
             self.channel.send(method_name, *args)
         return getattr(self, method_name)(*args)
@@ -181,6 +202,14 @@ class ModelRunner:
         if cfg.num_kvcache_blocks <= 0:
             available = total * cfg.gpu_memory_utilization - used - peak + current
             cfg.num_kvcache_blocks = int(available) // block_bytes
+            if self.world_size > 1:
+                # rank 0's scheduler hands out block ids to every rank: all ranks must allocate the same
+                # number of blocks, i.e. what the rank with the least free memory can hold (the reference
+                # sizes per rank, model_runner.py:195-214, and would index past the smaller caches)
+                n = torch.tensor([cfg.num_kvcache_blocks], dtype=torch.int64,
+                                 device=self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(n, op=dist.ReduceOp.MIN)
+                cfg.num_kvcache_blocks = int(n.item())
         assert cfg.num_kvcache_blocks > 0, "no memory left for even one KV cache block"
         # an odd number of allocated blocks keeps the per-layer stride (and with it the distance between
         # a tile's K and V copies, which one wavefront loads together) off large powers of two: with
@@ -345,13 +374,14 @@ class ModelRunner:
             torch.cuda.current_stream().synchronize()
             tokens = self.tokens_host[:real].tolist()
         self._steps_run += 1
-        if self.xgmi is not None and self._steps_run % 64 == 1:
+        if self.xgmi is not None:  # every step: tokens computed behind a timed-out exchange must never be returned
             self._check_xgmi()
         reset_context()
         return tokens
 
     def _check_xgmi(self):
         """The exchange kernel gives up on a peer after ~1 minute instead of hanging the GPU; what it
-        returned then is not a sum.  Surface that as an error (checked every 64 steps and at exit)."""
+        returned then is not a sum.  Surface that as an error (checked after every step - the stream has just
+        been synchronised for the token copy - and at exit)."""
         if self.xgmi is not None and self.xgmi.timed_out():
             raise RuntimeError(f"rank {self.rank}: xGMI all-reduce timed out waiting for a peer; results are invalid")

@@ -9,8 +9,11 @@ message:
 
     [generation, method, is_prefill, n_seqs, payload_len, payload...]
 
-Workers spin on `generation`; no acknowledgement is needed because a step cannot
-finish on rank 0 before every worker has joined its collectives, i.e. has read it.
+Workers spin on `generation`; no acknowledgement is needed because a published step
+cannot finish on rank 0 before every worker has joined its collectives, i.e. has read
+it.  Steps without collectives are therefore never published (ModelRunner.call drops
+empty `run` calls on every rank), and a reader that sees the generation move while it
+copies the payload reads again (seqlock).
 """
 from __future__ import annotations
 
@@ -75,9 +78,13 @@ class StepChannel:
             spins += 1
             if spins > 2000:
                 time.sleep(0)  # yield, keep latency in the microsecond range
-        self.generation = int(b[0])
-        method, is_prefill, n_seqs, n = _METHODS[int(b[1])], bool(b[2]), int(b[3]), int(b[4])
-        data = b[_HEADER:_HEADER + n].copy()
+        while True:
+            gen = int(b[0])
+            method, is_prefill, n_seqs, n = _METHODS[int(b[1])], bool(b[2]), int(b[3]), int(b[4])
+            data = b[_HEADER:_HEADER + n].copy()
+            if int(b[0]) == gen:  # nothing was published while the message was copied
+                break
+        self.generation = gen
         seqs, pos = [], 0
         for _ in range(n_seqs):
             s, pos = Sequence.from_wire(data, pos)

@@ -134,9 +134,14 @@ class XgmiComm:
             self._own = ctypes.c_void_p()
 
 
+LAST_STATUS = "not attempted"  # why the path is on or off (bench.py prints it with the N > 1 line)
+
+
 def create_if_enabled(rank: int, world: int, max_bytes: int, device: torch.device) -> XgmiComm | None:
     """None when disabled by MI355_XGMI_ALLREDUCE=0, when set-up fails or when the self-test fails."""
+    global LAST_STATUS
     if world < 2 or world > 8 or os.environ.get("MI355_XGMI_ALLREDUCE", "1") == "0":
+        LAST_STATUS = "disabled"
         return None
     comm = None
     try:
@@ -151,10 +156,13 @@ def create_if_enabled(rank: int, world: int, max_bytes: int, device: torch.devic
     if not agree.item():
         if comm is not None:
             comm.close()
+        LAST_STATUS = "set-up failed on some rank: RCCL all-reduce"
         return None
     if not comm.self_test():
         if rank == 0:
             warnings.warn("xGMI all-reduce self-test failed; using the RCCL all-reduce")
         comm.close()
+        LAST_STATUS = "self-test failed: RCCL all-reduce"
         return None
+    LAST_STATUS = f"self-test passed on {world} ranks"
     return comm

@@ -72,7 +72,7 @@ def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfl
     c = hf_config
     d = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
     hq, hkv, h, inter = c.num_attention_heads, c.num_key_value_heads, c.hidden_size, c.intermediate_size
-    bias = getattr(c, "attention_bias", False)
+    bias = getattr(c, "attention_bias", True)  # the default of Qwen3DecoderLayer (and of the reference, qwen3.py:126)
 
     def mat(*shape):
         return (torch.randn(*shape, generator=g, dtype=torch.float32) * std).to(dtype)

@@ -49,7 +49,7 @@ class OracleConfig:
             rope_theta=float(rope),
             max_position_embeddings=hf.max_position_embeddings,
             tie_word_embeddings=bool(getattr(hf, "tie_word_embeddings", False)),
-            attention_bias=bool(getattr(hf, "attention_bias", False)),
+            attention_bias=bool(getattr(hf, "attention_bias", True)),  # qwen3.py:126 default
         )
 
 
@@ -97,7 +97,11 @@ class OracleQwen3:
 
     # -- one decoder stack pass over T tokens -------------------------------------------------
     def _forward(self, input_ids, positions, slot_flat, attend):
+        """self.trace (a list, optional): gets one dict per layer with every intermediate tensor of the layer
+        (x, qkv, o, o_proj, x2, residual, act, mlp_out) and finally the normalised hidden states, for
+        teacher-forced per-stage and per-layer comparisons."""
         c, w = self.cfg, self.w
+        trace = getattr(self, "trace", None)
         hq, hkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
         h = L.embedding(input_ids, w["model.embed_tokens.weight"])
         residual = None
@@ -117,11 +121,20 @@ class OracleQwen3:
             k = L.apply_rope(positions, k, self.cos_sin)
             L.kv_scatter(k, v, self.k_cache[li], self.v_cache[li], slot_flat)
             o = attend(li, q)
+            stage = {"x": x, "qkv": qkv, "o": o.reshape(o.shape[0], -1)} if trace is not None else None
             h = L.linear(o, w[p + "self_attn.o_proj.weight"])
             x, residual = L.add_rms_norm(h, residual, w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
             gu = L.linear(x, w[p + "mlp.gate_up_proj.weight"])
-            h = L.linear(L.silu_and_mul(gu), w[p + "mlp.down_proj.weight"])
+            act = L.silu_and_mul(gu)
+            if trace is not None:
+                stage.update(o_proj=h, x2=x, residual=residual, act=act)
+            h = L.linear(act, w[p + "mlp.down_proj.weight"])
+            if trace is not None:
+                stage["mlp_out"] = h
+                trace.append({k: v.clone() for k, v in stage.items()})
         x, _ = L.add_rms_norm(h, residual, w["model.norm.weight"], c.rms_norm_eps)
+        if trace is not None:
+            trace.append(x.clone())
         return x
 
     def _logits(self, hidden, fp32: bool):
