@@ -39,7 +39,8 @@ def rope_theta_of(config) -> float:
 class Qwen3Attention(nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, num_kv_heads: int, max_position: int = 4096 * 32,
                  head_dim: int | None = None, rms_norm_eps: float = 1e-06, qkv_bias: bool = False,
-                 rope_theta: float = 10000, rope_scaling: tuple | None = None, fused: bool = True) -> None:
+                 rope_theta: float = 10000, rope_scaling: tuple | None = None, fused: bool = True,
+                 qk_norm: bool | None = None, o_bias: bool = False) -> None:
         super().__init__()
         world = tp_size()
         self.total_num_heads = num_heads
@@ -52,15 +53,17 @@ class Qwen3Attention(nn.Module):
         self.kv_size = self.num_kv_heads * self.head_dim
         self.scaling = self.head_dim ** -0.5
         self.qkv_bias = qkv_bias
+        # Qwen3: per-head q/k RMSNorm instead of qkv biases (qwen3.py:70-72); Llama: neither (llama.py:80-93)
+        self.qk_norm = (not qkv_bias) if qk_norm is None else qk_norm
         self.fused = fused
         self.rms_norm_eps = rms_norm_eps
 
         self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=qkv_bias)
-        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=False)
+        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias)
         self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim, max_position=max_position,
                                    base=rope_theta)
         self.attn = Attention(self.num_heads, self.head_dim, None, self.num_kv_heads)
-        if not qkv_bias:  # Qwen3: per-head q/k RMSNorm instead of qkv biases (qwen3.py:70-72)
+        if self.qk_norm:
             self.q_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
             self.k_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
 
@@ -73,7 +76,7 @@ class Qwen3Attention(nn.Module):
             q = q.view(-1, self.num_heads, self.head_dim)
             k = k.view(-1, self.num_kv_heads, self.head_dim)
             v = v.view(-1, self.num_kv_heads, self.head_dim)
-            if not self.qkv_bias:
+            if self.qk_norm:
                 q = self.q_norm(q)
                 k = self.k_norm(k)
             q, k = self.rotary_emb(positions, q, k)
@@ -86,8 +89,8 @@ class Qwen3Attention(nn.Module):
         rope = self.rotary_emb
         if rope.cos_sin_cache.device != qkv.device:
             rope.cos_sin_cache = rope.cos_sin_cache.to(qkv.device)
-        qw = None if self.qkv_bias else self.q_norm.weight
-        kw = None if self.qkv_bias else self.k_norm.weight
+        qw = self.q_norm.weight if self.qk_norm else None
+        kw = self.k_norm.weight if self.qk_norm else None
         q = ops.qknorm_rope_store(qkv, qw, kw, self.rms_norm_eps, positions, rope.cos_sin_cache, attn.k_cache,
                                   attn.v_cache, ctx.slot_mapping, self.num_heads, self.num_kv_heads,
                                   ctx.block_size)
@@ -103,11 +106,11 @@ class Qwen3Attention(nn.Module):
 
 
 class Qwen3MLP(nn.Module):
-    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str) -> None:
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str, bias: bool = False) -> None:
         super().__init__()
         assert hidden_act == "silu"
-        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=False)
-        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=False)
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=bias)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=bias)
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
@@ -115,9 +118,11 @@ class Qwen3MLP(nn.Module):
 
 
 class Qwen3DecoderLayer(nn.Module):
-    def __init__(self, config, fused: bool = True) -> None:
+    def __init__(self, config, fused: bool = True, **attn_overrides) -> None:
+        """attn_overrides / mlp_bias: the Llama wiring (models/llama.py) of the same layer."""
         super().__init__()
-        self.self_attn = Qwen3Attention(
+        mlp_bias = attn_overrides.pop("mlp_bias", False)
+        attn_kw = dict(
             hidden_size=config.hidden_size,
             num_heads=config.num_attention_heads,
             num_kv_heads=config.num_key_value_heads,
@@ -129,7 +134,9 @@ class Qwen3DecoderLayer(nn.Module):
             rope_scaling=getattr(config, "rope_scaling", None),
             fused=fused,
         )
-        self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act)
+        attn_kw.update(attn_overrides)
+        self.self_attn = Qwen3Attention(**attn_kw)
+        self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act, bias=mlp_bias)
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
@@ -145,11 +152,12 @@ class Qwen3DecoderLayer(nn.Module):
 
 
 class Qwen3Model(nn.Module):
-    def __init__(self, config, fused: bool = True) -> None:
+    def __init__(self, config, fused: bool = True, **layer_overrides) -> None:
         super().__init__()
         self.fused = fused
         self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
-        self.layers = nn.ModuleList([Qwen3DecoderLayer(config, fused) for _ in range(config.num_hidden_layers)])
+        self.layers = nn.ModuleList([Qwen3DecoderLayer(config, fused, **layer_overrides)
+                                     for _ in range(config.num_hidden_layers)])
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
@@ -167,7 +175,9 @@ class Qwen3Model(nn.Module):
         l0 = self.layers[0]
         return (l0.self_attn.attn.k_cache.numel() > 0 and l0.self_attn.qkv_proj.weight_packed is not None
                 and l0.self_attn.o_proj.weight_packed is not None and l0.mlp.down_proj.weight_packed is not None
-                and l0.mlp.gate_up_proj.weight_packed is not None and l0.self_attn.qkv_proj.bias is None)
+                and l0.mlp.gate_up_proj.weight_packed is not None and l0.self_attn.qkv_proj.bias is None
+                and l0.self_attn.o_proj.bias is None and l0.mlp.gate_up_proj.bias is None
+                and l0.mlp.down_proj.bias is None)
 
     @staticmethod
     def _ksplit(weight: torch.Tensor) -> int:
@@ -211,8 +221,8 @@ class Qwen3Model(nn.Module):
             a.block_size = ctx.block_size
             if rope.cos_sin_cache.device != qkv.device:
                 rope.cos_sin_cache = rope.cos_sin_cache.to(qkv.device)
-            qw = None if attn.qkv_bias else attn.q_norm.weight
-            kw = None if attn.qkv_bias else attn.k_norm.weight
+            qw = attn.q_norm.weight if attn.qk_norm else None
+            kw = attn.k_norm.weight if attn.qk_norm else None
             return ops.paged_attn_decode_fused(qkv, qw, kw, attn.rms_norm_eps, positions, rope.cos_sin_cache,
                                                ctx.slot_mapping, a.k_cache, a.v_cache, ctx.block_tables,
                                                ctx.context_lens, attn.num_heads, attn.num_kv_heads, ctx.block_size,
@@ -268,9 +278,9 @@ class Qwen3ForCausalLM(nn.Module):
         "up_proj": ("gate_up_proj", 1),
     }
 
-    def __init__(self, config, fused: bool = True) -> None:
+    def __init__(self, config, fused: bool = True, **layer_overrides) -> None:
         super().__init__()
-        self.model = Qwen3Model(config, fused)
+        self.model = Qwen3Model(config, fused, **layer_overrides)
         self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
         if getattr(config, "tie_word_embeddings", False):
             self.lm_head.weight.data = self.model.embed_tokens.weight.data

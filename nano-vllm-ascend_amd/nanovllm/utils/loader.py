@@ -72,7 +72,10 @@ def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfl
     c = hf_config
     d = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
     hq, hkv, h, inter = c.num_attention_heads, c.num_key_value_heads, c.hidden_size, c.intermediate_size
-    bias = getattr(c, "attention_bias", True)  # the default of Qwen3DecoderLayer (and of the reference, qwen3.py:126)
+    llama = getattr(c, "model_type", "") == "llama"
+    # Qwen3DecoderLayer's default (and the reference's, qwen3.py:126) is True; Llama's is False (llama.py:138)
+    bias = bool(getattr(c, "attention_bias", not llama))
+    qk_norm = not bias and not llama
 
     def mat(*shape):
         return (torch.randn(*shape, generator=g, dtype=torch.float32) * std).to(dtype)
@@ -90,7 +93,7 @@ def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfl
             yield p + "self_attn.q_proj.bias", b[: hq * d]
             yield p + "self_attn.k_proj.bias", b[hq * d: (hq + hkv) * d]
             yield p + "self_attn.v_proj.bias", b[(hq + hkv) * d:]
-        else:
+        if qk_norm:
             yield p + "self_attn.q_norm.weight", torch.ones(d, dtype=dtype)
             yield p + "self_attn.k_norm.weight", torch.ones(d, dtype=dtype)
         yield p + "self_attn.o_proj.weight", mat(h, hq * d)

@@ -30,6 +30,7 @@ class OracleConfig:
     max_position_embeddings: int = 40960
     tie_word_embeddings: bool = True
     attention_bias: bool = False
+    qk_norm: bool | None = None  # None: Qwen3 rule, norm iff no qkv bias (qwen3.py:70-72); Llama: False (llama.py:80-93)
 
     @classmethod
     def from_hf(cls, hf) -> "OracleConfig":
@@ -49,8 +50,13 @@ class OracleConfig:
             rope_theta=float(rope),
             max_position_embeddings=hf.max_position_embeddings,
             tie_word_embeddings=bool(getattr(hf, "tie_word_embeddings", False)),
-            attention_bias=bool(getattr(hf, "attention_bias", True)),  # qwen3.py:126 default
+            attention_bias=bool(getattr(hf, "attention_bias", getattr(hf, "model_type", "") != "llama")),
+            qk_norm=False if getattr(hf, "model_type", "") == "llama" else None,
         )
+
+    @property
+    def has_qk_norm(self) -> bool:
+        return (not self.attention_bias) if self.qk_norm is None else self.qk_norm
 
 
 def random_weights(cfg: OracleConfig, seed: int = 0, std: float = 0.02, dtype=torch.bfloat16) -> dict:
@@ -71,7 +77,7 @@ def random_weights(cfg: OracleConfig, seed: int = 0, std: float = 0.02, dtype=to
         w[p + "self_attn.qkv_proj.weight"] = mat((hq + 2 * hkv) * d, h)
         if cfg.attention_bias:
             w[p + "self_attn.qkv_proj.bias"] = mat((hq + 2 * hkv) * d)
-        else:
+        if cfg.has_qk_norm:
             w[p + "self_attn.q_norm.weight"] = torch.ones(d, dtype=dtype)
             w[p + "self_attn.k_norm.weight"] = torch.ones(d, dtype=dtype)
         w[p + "self_attn.o_proj.weight"] = mat(h, hq * d)
@@ -114,7 +120,7 @@ class OracleQwen3:
             qkv = L.linear(x, w[p + "self_attn.qkv_proj.weight"], w.get(p + "self_attn.qkv_proj.bias"))
             q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
             q, k, v = q.reshape(-1, hq, d), k.reshape(-1, hkv, d), v.reshape(-1, hkv, d)
-            if not c.attention_bias:
+            if c.has_qk_norm:
                 q = L.rms_norm(q, w[p + "self_attn.q_norm.weight"], c.rms_norm_eps)
                 k = L.rms_norm(k, w[p + "self_attn.k_norm.weight"], c.rms_norm_eps)
             q = L.apply_rope(positions, q, self.cos_sin)

@@ -51,3 +51,9 @@ def golden_tiny():
 def golden_tiny_bias():
     """The same run with attention_bias=True: qkv bias, no q/k norm (the Qwen2 wiring)."""
     return np.load(os.path.join(GOLDEN, "tiny_model_bias.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tiny_llama():
+    """The reference's LlamaForCausalLM (no q/k norm, no bias) on the tiny shapes."""
+    return np.load(os.path.join(GOLDEN, "tiny_model_llama.npz"))

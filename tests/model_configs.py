@@ -13,6 +13,9 @@ QWEN3_0_6B = dict(
 TINY = dict(QWEN3_0_6B, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
             intermediate_size=256, vocab_size=256, max_position_embeddings=512, eos_token_id=255, bos_token_id=0)
 
+# the reference's Llama wiring (models/llama.py) on the tiny shapes: no q/k norm, no biases, rope_theta 1e4
+TINY_LLAMA = dict(TINY, architectures=["LlamaForCausalLM"], model_type="llama", rope_theta=10000.0, mlp_bias=False)
+
 MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
            bos_token_id=0)
 

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import bf16_from_bits as bf
-from model_configs import QWEN3_32B_2L, MID, TINY, make_model_dir
+from model_configs import QWEN3_32B_2L, MID, TINY, TINY_LLAMA, make_model_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -19,19 +19,20 @@ def _split(flat, lens):
     return out
 
 
-@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias"])
+@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias", "llama"])
 @pytest.mark.parametrize("enforce_eager", [True, False])
-def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, enforce_eager, variant):
+def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, golden_tiny_llama, enforce_eager, variant):
     """Same prompts, same weights, greedy: block tables follow the same FIFO order, logits
     agree with the reference's bf16 CPU pipeline to a bf16-ulp-scale bound, tokens agree
     wherever the reference's top-2 margin exceeds that bound.  Both wirings of qwen3.py:70-72:
-    q/k norm without bias (Qwen3) and qkv bias without norm (attention_bias=True)."""
+    q/k norm without bias (Qwen3) and qkv bias without norm (attention_bias=True), and the reference's
+    LlamaForCausalLM (models/llama.py: neither), which runs the fused decode launch with null norm weights."""
     from nanovllm import LLM, SamplingParams
     from nanovllm.utils.loader import load_state_dict_packed
 
-    g = golden_tiny if variant == "qwen3" else golden_tiny_bias
+    g = {"qwen3": golden_tiny, "qkv_bias": golden_tiny_bias, "llama": golden_tiny_llama}[variant]
     block_size, nblk = (int(v) for v in g["meta"])
-    tiny = TINY if variant == "qwen3" else dict(TINY, attention_bias=True)
+    tiny = {"qwen3": TINY, "qkv_bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA}[variant]
     llm = LLM(make_model_dir(tiny), kvcache_block_size=block_size, max_num_seqs=4, max_num_batched_tokens=128,
               max_model_len=128, num_kvcache_blocks=nblk, enforce_eager=enforce_eager, warmup=False)
     try:

@@ -449,3 +449,71 @@ def test_block_manager_invariants_under_random_traffic():
         live.clear()
         check()
         assert len(bm.free_block_ids) == nblk
+
+
+# --------------------------------------------------------------------------- serving harness
+def test_serving_harness_metrics_against_scripted_engine():
+    """bench/serving_bench.py: arrivals interleave with steps, TTFT / TPOT / latency follow the reference's
+    definitions (serving_bench.py:35-58) - checked against a scripted engine with a virtual clock."""
+    import importlib.util
+    import os
+    import sys
+
+    from conftest import PKG
+
+    spec = importlib.util.spec_from_file_location("serving_bench", os.path.join(PKG, "bench", "serving_bench.py"))
+    sb = importlib.util.module_from_spec(spec)
+    sys.modules["serving_bench"] = sb  # dataclasses resolve their module through sys.modules
+    spec.loader.exec_module(sb)
+
+    now = [0.0]
+    clock = lambda: now[0]  # noqa: E731
+
+    class Engine:
+        """every step takes 10 ms; a request's first step is its prefill (first token), each later step one token"""
+        def __init__(self):
+            self.seqs, self.ttft, self.next_id = [], {}, 7
+
+        def add_request(self, prompt, sp):
+            s = SimpleNamespace(seq_id=self.next_id, arrival_time=clock(), out=[], max_tokens=sp.max_tokens)
+            self.next_id += 1
+            self.seqs.append(s)
+            return s
+
+        def is_finished(self):
+            return not self.seqs
+
+        def step(self):
+            now[0] += 0.010
+            finished = []
+            for s in list(self.seqs):
+                s.out.append(1)
+                if len(s.out) == 1:
+                    self.ttft[s.seq_id] = clock() - s.arrival_time
+                if len(s.out) == s.max_tokens:
+                    finished.append((s.seq_id, s.out, 3, 0))
+                    self.seqs.remove(s)
+            return finished, -1
+
+    def sleep(dt):
+        now[0] += max(dt, 1e-3)
+
+    prompts = [[1, 2, 3]] * 3
+    sps = [SimpleNamespace(max_tokens=n) for n in (4, 2, 1)]
+    arrivals = np.array([0.0, 0.015, 0.5])  # the third arrives long after the others have finished
+    res = sb.run_serving(Engine(), prompts, sps, arrivals, clock=clock, sleep=sleep)
+    m = res.metrics
+    assert sorted(m) == [7, 8, 9]
+    assert abs(m[7].ttft - 0.010) < 1e-9 and abs(m[7].latency - 0.040) < 1e-9 and abs(m[7].tpot - 0.010) < 1e-9
+    # the second request is picked up at the first loop turn after t = 15 ms, i.e. behind step 2 (t = 20 ms)
+    assert abs(m[8].submission_time - 0.020) < 1e-9 and abs(m[8].ttft - 0.010) < 1e-9 and m[8].output_len == 2
+    assert m[9].output_len == 1 and np.isnan(m[9].tpot) and m[9].submission_time >= 0.5
+    s = res.summary()
+    assert s["completed"] == 3 and s["output_tokens"] == 7 and s["engine_steps"] == 5
+    assert abs(s["ttft_ms"]["p50"] - 10.0) < 1e-6
+    # arrival processes: exponential gaps have the right mean; the reference's integer gaps are mostly zero
+    rng = np.random.default_rng(0)
+    a = sb.arrival_times(4000, 8.0, rng)
+    assert abs(np.diff(a).mean() - 0.125) < 0.01 and (np.diff(a) > 0).all()
+    b = sb.arrival_times(4000, 8.0, rng, reference_style=True)
+    assert (np.diff(b) == 0).mean() > 0.8

@@ -104,28 +104,30 @@ def test_sampler_probabilities(golden_layers):
     assert torch.equal(p, torch.from_numpy(g["samp_probs"]))
 
 
-def _tiny_oracle(g):
-    from transformers import Qwen3Config
+def _tiny_oracle(g, llama=False):
+    from transformers import LlamaConfig, Qwen3Config
 
     weights = {k[3:]: bf(g[k]) for k in g.files if k.startswith("w::")}
-    from model_configs import TINY
+    from model_configs import TINY, TINY_LLAMA
 
     tiny = dict(TINY, attention_bias=True) if "attention_bias" in g.files and int(g["attention_bias"]) else TINY
-    hf = Qwen3Config(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
+    tiny = TINY_LLAMA if llama else tiny
+    hf = (LlamaConfig if llama else Qwen3Config)(**{k: v for k, v in tiny.items()
+                                                    if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
     block_size, nblk = (int(v) for v in g["meta"])
     return OracleQwen3(cfg, weights, nblk, block_size), block_size
 
 
-@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias"])
-def test_tiny_model_matches_reference_run(golden_tiny, golden_tiny_bias, variant):
+@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias", "llama"])
+def test_tiny_model_matches_reference_run(golden_tiny, golden_tiny_bias, golden_tiny_llama, variant):
     """Replay the reference's own greedy run (its scheduler, block manager, prepare_*,
     model) through the oracle model with the same token stream.  The reference
     pipeline is bf16 end to end with bf16 S/P in attention, so logits agree to a
     bf16-ulp-scale bound, and greedy tokens agree wherever the reference's top-2
     margin exceeds that bound."""
-    g = golden_tiny if variant == "qwen3" else golden_tiny_bias
-    model, bs = _tiny_oracle(g)
+    g = {"qwen3": golden_tiny, "qkv_bias": golden_tiny_bias, "llama": golden_tiny_llama}[variant]
+    model, bs = _tiny_oracle(g, llama=variant == "llama")
     lens = g["prompt_lens"].tolist()
     flat = g["prompts"].tolist()
     prompts, o = [], 0

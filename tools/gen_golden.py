@@ -15,7 +15,9 @@ Fixtures
   attention.npz      layers/attention_torch_native.py store + prefill + decode I/O
   engine_traces.json Scheduler + BlockManager + Sequence + ModelRunner.prepare_* traces
   tiny_model.npz     2-layer random Qwen3 driven through the reference's model,
-                     scheduler and prepare_* (greedy = argmax of the reference logits)
+                     scheduler and prepare_* (greedy = argmax of the reference logits);
+                     tiny_model_bias.npz / tiny_model_llama.npz: the same run with attention_bias=True
+                     and with the reference's LlamaForCausalLM
 """
 from __future__ import annotations
 
@@ -374,9 +376,11 @@ def gen_engine_fuzz(n_scenarios=14):
 # --------------------------------------------------------------------------- E. tiny model
 def gen_tiny_model(variant: str = ""):
     """variant "": Qwen3 wiring (q/k norm, no bias); "bias": attention_bias=True - qkv bias, no q/k norm
-    (the Qwen2 wiring of qwen3.py:70-72,135)."""
-    from transformers import Qwen3Config
+    (the Qwen2 wiring of qwen3.py:70-72,135); "llama": the reference's LlamaForCausalLM (models/llama.py:
+    neither q/k norm nor bias) on the same tiny shapes."""
+    from transformers import LlamaConfig, Qwen3Config
 
+    import nanovllm.models.llama as ref_llama
     import nanovllm.models.qwen3 as ref_qwen3
     from nanovllm.engine.scheduler import Scheduler
     from nanovllm.engine.sequence import Sequence
@@ -400,20 +404,22 @@ def gen_tiny_model(variant: str = ""):
             return super().forward(q, k, v)
 
     ref_qwen3.Attention = NativeAdapter
+    ref_llama.Attention = NativeAdapter
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from model_configs import TINY  # the same dict the tests build their model directory from
+    from model_configs import TINY, TINY_LLAMA  # the same dicts the tests build their model directories from
 
-    tiny = dict(TINY, attention_bias=True) if variant == "bias" else TINY
-    hf = Qwen3Config(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
+    tiny = {"bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA}.get(variant, TINY)
+    cfg_cls = LlamaConfig if variant == "llama" else Qwen3Config
+    hf = cfg_cls(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
-    weights = random_weights(cfg, seed=3 if not variant else 13, std=0.08)
+    weights = random_weights(cfg, seed={"": 3, "bias": 13, "llama": 23}[variant], std=0.08)
     # non-trivial norm weights so the norm multiplies are exercised
     g = torch.Generator().manual_seed(5)
     for name in list(weights):
         if "norm" in name:
             weights[name] = (1.0 + 0.1 * torch.randn(weights[name].shape, generator=g)).to(torch.bfloat16)
     torch.set_default_dtype(torch.bfloat16)
-    model = ref_qwen3.Qwen3ForCausalLM(hf)
+    model = ref_llama.LlamaForCausalLM(hf) if variant == "llama" else ref_qwen3.Qwen3ForCausalLM(hf)
     torch.set_default_dtype(torch.float32)
     sd = dict(model.named_parameters())
     for name, w in weights.items():
@@ -473,7 +479,8 @@ def main():
     only = sys.argv[1:]  # e.g. `gen_golden.py engine_fuzz` regenerates one fixture
     for name, fn in (("hashes", gen_hashes), ("layers", gen_layers), ("attention", gen_attention),
                      ("engine", gen_engine), ("engine_fuzz", gen_engine_fuzz), ("tiny_model", gen_tiny_model),
-                     ("tiny_model_bias", lambda: gen_tiny_model("bias"))):
+                     ("tiny_model_bias", lambda: gen_tiny_model("bias")),
+                     ("tiny_model_llama", lambda: gen_tiny_model("llama"))):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
