@@ -311,6 +311,35 @@ int mi_gemm_fp8w_packed(const mi_bf16* x, const uint8_t* w_packed, const float* 
 int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
                                float* partials, int M, int N, int K, int ksplit, mi_stream stream);
 
+/* ---- mixture of experts (reference: models/qwen3_moe.py:125-185, BASELINE.json configs[3]) -------------
+ * Qwen3MoeSparseMoeBlock.forward as five launches over expert-sorted (token, expert) pairs; P = n_tokens * top_k.
+ * The reference loops over the selected experts in Python with three library GEMMs each (:171-184).
+ * Expert weights: one fragment-native slab (mi_pack_weight layout) per expert, stacked: gate_up
+ * [E][2*inter][hidden] with rows gate | up (MergedColumnParallelLinear, :104-108), down [E][hidden][inter];
+ * under tensor parallelism `inter` is this rank's shard and the bf16 outputs of mi_moe_down are partial sums
+ * to be all-reduced before mi_moe_combine (RowParallelLinear, :109-113). */
+/* Routing (:153-161): softmax over the experts in fp32, top-k, renormalise by the top-k sum, cast to bf16.
+ * topk_ids / topk_w [n_tokens][top_k], each token's picks in ASCENDING expert id (the order the reference's
+ * expert loop adds them in, :171-172); equal probabilities: lower expert id first.  n_experts <= 512. */
+int mi_moe_route(const mi_bf16* router_logits, int n_tokens, int n_experts, int top_k,
+                 int32_t* topk_ids, mi_bf16* topk_w, mi_stream stream);
+/* Group the pairs by expert: expert_offsets [n_experts + 1] (run of expert e = [off[e], off[e+1])),
+ * pair_token [P] (token of the pair at each sorted position), pair_pos [n_tokens][top_k] (where each pair went). */
+int mi_moe_sort(const int32_t* topk_ids, int n_tokens, int top_k, int n_experts,
+                int32_t* expert_offsets, int32_t* pair_token, int32_t* pair_pos, mi_stream stream);
+/* act[pos][inter] = SiluAndMul(x[pair_token[pos]] @ W_gate_up[e]^T) for every pair of every expert, rounding
+ * points of mi_gemm_bf16_packed(epilogue 1).  hidden = 64 * {1,2,3,4,6,8,12,16}, 128 * {5,10,12,16} or 256 * {10,16}. */
+int mi_moe_gate_up(const mi_bf16* x, const mi_bf16* w_gate_up_packed, const int32_t* expert_offsets,
+                   const int32_t* pair_token, mi_bf16* act, int n_experts, int hidden, int inter,
+                   mi_stream stream);
+/* y[pos][hidden] = bf16(act[pos] @ W_down[e]^T): the expert MLP's output (:121).  inter: same set as above. */
+int mi_moe_down(const mi_bf16* act, const mi_bf16* w_down_packed, const int32_t* expert_offsets,
+                mi_bf16* y, int n_experts, int hidden, int inter, mi_stream stream);
+/* out[t] = sum over the token's pairs j (ascending expert id) of bf16(y[pair_pos[t][j]] * topk_w[t][j]), every
+ * partial sum rounded to bf16 - `index_add_` into a bf16 tensor (:178-184). */
+int mi_moe_combine(const mi_bf16* y, const int32_t* pair_pos, const mi_bf16* topk_w, mi_bf16* out,
+                   int n_tokens, int top_k, int hidden, mi_stream stream);
+
 /* ---- tensor-parallel exchange over xGMI -----------------------------------
  * Stands in for the HCCL all-reduce after every row-parallel projection and the
  * vocab-parallel embedding (linear.py:152-153, embed_head.py:41-42).  One process

@@ -173,11 +173,17 @@ class Qwen3Model(nn.Module):
     # -- decode-regime fast path ------------------------------------------------------------------
     def _can_stream(self) -> bool:
         l0 = self.layers[0]
-        return (l0.self_attn.attn.k_cache.numel() > 0 and l0.self_attn.qkv_proj.weight_packed is not None
-                and l0.self_attn.o_proj.weight_packed is not None and l0.mlp.down_proj.weight_packed is not None
-                and l0.mlp.gate_up_proj.weight_packed is not None and l0.self_attn.qkv_proj.bias is None
-                and l0.self_attn.o_proj.bias is None and l0.mlp.gate_up_proj.bias is None
-                and l0.mlp.down_proj.bias is None)
+        ok = (l0.self_attn.attn.k_cache.numel() > 0 and l0.self_attn.qkv_proj.weight_packed is not None
+              and l0.self_attn.o_proj.weight_packed is not None and l0.self_attn.qkv_proj.bias is None
+              and l0.self_attn.o_proj.bias is None)
+        for layer in self.layers:  # dense MLPs need their packed weights and no biases; sparse blocks their packed experts
+            mlp = layer.mlp
+            if hasattr(mlp, "experts"):
+                ok = ok and mlp.gate_up_packed is not None
+            else:
+                ok = ok and (mlp.down_proj.weight_packed is not None and mlp.gate_up_proj.weight_packed is not None
+                             and mlp.gate_up_proj.bias is None and mlp.down_proj.bias is None)
+        return ok
 
     @staticmethod
     def _ksplit(weight: torch.Tensor) -> int:
@@ -207,7 +213,7 @@ class Qwen3Model(nn.Module):
         h = self.embed_tokens(input_ids)
         rows = h.shape[0]
         l0 = self.layers[0]
-        rows4 = tp > 1 and l0.self_attn.o_proj.weight_rows4 is not None and l0.mlp.down_proj.weight_rows4 is not None
+        rows4 = tp > 1 and l0.self_attn.o_proj.weight_rows4 is not None
         fuse_attn = not ctx.is_prefill and os.environ.get("MI355_ATTN_FUSED", "1") != "0"
 
         xgmi = get_xgmi_comm() if tp > 1 else None
@@ -263,8 +269,13 @@ class Qwen3Model(nn.Module):
                 qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj.weight_packed)
             o = attend(attn, qkv)
             parts, is_partials = row_parallel(o, attn.o_proj)
-            act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj.weight_packed, silu_mul=True)
-            parts, is_partials = row_parallel(act, mlp.down_proj)
+            if hasattr(mlp, "experts"):  # sparse block (models/qwen3_moe.py): five launches over expert-sorted pairs
+                x, residual = add_norm(parts, is_partials, residual, ln2)
+                parts, is_partials = mlp(x), False
+            else:
+                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj.weight_packed,
+                                            silu_mul=True)
+                parts, is_partials = row_parallel(act, mlp.down_proj)
         x, _ = add_norm(parts, is_partials, residual, self.norm)
         return x
 

@@ -453,3 +453,47 @@ def sample(logits, temperatures, seed: int, step: int, out=None) -> torch.Tensor
         "mi_sample",
     )
     return out
+
+
+# --------------------------------------------------------------------------- mixture of experts
+def pack_expert_weights(w, out=None) -> torch.Tensor:
+    """[E, N, K] expert weights -> one fragment-native slab per expert (mi_pack_weight), same shape."""
+    require_gpu(w)
+    _bf16(w)
+    assert w.dim() == 3 and w.is_contiguous() and w.shape[1] % 16 == 0 and w.shape[2] % 32 == 0
+    if out is None or out.shape != w.shape or out.device != w.device:
+        out = torch.empty_like(w)
+    for e in range(w.shape[0]):
+        check(lib.mi_pack_weight(ptr(w[e]), ptr(out[e]), w.shape[1], w.shape[2], stream()), "mi_pack_weight")
+    return out
+
+
+def moe_forward(x, router_logits, gate_up_packed, down_packed, top_k: int, all_reduce=None):
+    """Qwen3MoeSparseMoeBlock.forward (qwen3_moe.py:150-185) behind the router GEMM: route -> group the pairs by
+    expert -> grouped gate_up+SwiGLU -> grouped down (-> all-reduce of the ranks' partial sums) -> combine.
+    x [T, H], router_logits [T, E] bf16; returns [T, H] bf16."""
+    require_gpu(x, router_logits, gate_up_packed, down_packed)
+    _bf16(x, router_logits, gate_up_packed, down_packed)
+    assert x.is_contiguous() and router_logits.is_contiguous()
+    T, H = x.shape
+    E, two_i, _ = gate_up_packed.shape
+    inter = two_i // 2
+    assert router_logits.shape == (T, E) and down_packed.shape == (E, H, inter)
+    dev = x.device
+    ids = torch.empty((T, top_k), dtype=torch.int32, device=dev)
+    w = torch.empty((T, top_k), dtype=_BF16, device=dev)
+    check(lib.mi_moe_route(ptr(router_logits), T, E, top_k, ptr(ids), ptr(w), stream()), "mi_moe_route")
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    pair_token = torch.empty(T * top_k, dtype=torch.int32, device=dev)
+    pair_pos = torch.empty((T, top_k), dtype=torch.int32, device=dev)
+    check(lib.mi_moe_sort(ptr(ids), T, top_k, E, ptr(offsets), ptr(pair_token), ptr(pair_pos), stream()), "mi_moe_sort")
+    act = torch.empty((T * top_k, inter), dtype=_BF16, device=dev)
+    check(lib.mi_moe_gate_up(ptr(x), ptr(gate_up_packed), ptr(offsets), ptr(pair_token), ptr(act), E, H, inter,
+                             stream()), "mi_moe_gate_up")
+    y = torch.empty((T * top_k, H), dtype=_BF16, device=dev)
+    check(lib.mi_moe_down(ptr(act), ptr(down_packed), ptr(offsets), ptr(y), E, H, inter, stream()), "mi_moe_down")
+    if all_reduce is not None:
+        y = all_reduce(y)
+    out = torch.empty((T, H), dtype=_BF16, device=dev)
+    check(lib.mi_moe_combine(ptr(y), ptr(pair_pos), ptr(w), ptr(out), T, top_k, H, stream()), "mi_moe_combine")
+    return out, ids, w

@@ -75,7 +75,7 @@ def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfl
     llama = getattr(c, "model_type", "") == "llama"
     # Qwen3DecoderLayer's default (and the reference's, qwen3.py:126) is True; Llama's is False (llama.py:138)
     bias = bool(getattr(c, "attention_bias", not llama))
-    qk_norm = not bias and not llama
+    qk_norm = (not bias and not llama) or bool(getattr(c, "num_experts", 0))  # the MoE attention always norms
 
     def mat(*shape):
         return (torch.randn(*shape, generator=g, dtype=torch.float32) * std).to(dtype)
@@ -97,10 +97,22 @@ def synthetic_state(hf_config, seed: int = 0, std: float = 0.02, dtype=torch.bfl
             yield p + "self_attn.q_norm.weight", torch.ones(d, dtype=dtype)
             yield p + "self_attn.k_norm.weight", torch.ones(d, dtype=dtype)
         yield p + "self_attn.o_proj.weight", mat(h, hq * d)
-        gu = mat(2 * inter, h)
-        yield p + "mlp.gate_proj.weight", gu[:inter]
-        yield p + "mlp.up_proj.weight", gu[inter:]
-        yield p + "mlp.down_proj.weight", mat(h, inter)
+        n_exp = int(getattr(c, "num_experts", 0) or 0)
+        sparse = (n_exp > 0 and i not in (getattr(c, "mlp_only_layers", None) or [])
+                  and (i + 1) % int(getattr(c, "decoder_sparse_step", 1) or 1) == 0)
+        if sparse:  # router, then the stacked expert weights (oracle.model.random_weights draws them the same way)
+            mi = c.moe_intermediate_size
+            yield p + "mlp.gate.weight", mat(n_exp, h)
+            gu, dn = mat(n_exp, 2 * mi, h), mat(n_exp, h, mi)
+            for e in range(n_exp):
+                yield p + f"mlp.experts.{e}.gate_proj.weight", gu[e, :mi]
+                yield p + f"mlp.experts.{e}.up_proj.weight", gu[e, mi:]
+                yield p + f"mlp.experts.{e}.down_proj.weight", dn[e]
+        else:
+            gu = mat(2 * inter, h)
+            yield p + "mlp.gate_proj.weight", gu[:inter]
+            yield p + "mlp.up_proj.weight", gu[inter:]
+            yield p + "mlp.down_proj.weight", mat(h, inter)
         yield p + "input_layernorm.weight", torch.ones(h, dtype=dtype)
         yield p + "post_attention_layernorm.weight", torch.ones(h, dtype=dtype)
     yield "model.norm.weight", torch.ones(h, dtype=dtype)
@@ -120,7 +132,16 @@ def load_state_dict_packed(model: nn.Module, weights: dict) -> None:
     cfg_attn = model.model.layers[0].self_attn
     hq, hkv, d = cfg_attn.total_num_heads, cfg_attn.total_num_kv_heads, cfg_attn.head_dim
     for name, t in weights.items():
-        if "qkv_proj" in name:
+        if ".mlp.experts." in name and t.dim() == 3:  # stacked [E, ...] expert weights (oracle naming)
+            for e in range(t.shape[0]):
+                pe = name.replace(".experts.", f".experts.{e}.")
+                if "gate_up_proj" in pe:
+                    gate, up = t[e].chunk(2, dim=0)
+                    _route(model, pe.replace("gate_up_proj", "gate_proj"), gate)
+                    _route(model, pe.replace("gate_up_proj", "up_proj"), up)
+                else:
+                    _route(model, pe, t[e])
+        elif "qkv_proj" in name:
             parts = t.split([hq * d, hkv * d, hkv * d], dim=0)
             for tag, part in zip(("q_proj", "k_proj", "v_proj"), parts):
                 _route(model, name.replace("qkv_proj", tag), part)

@@ -97,6 +97,41 @@ def embedding(ids: torch.Tensor, w: torch.Tensor, vocab_start: int = 0) -> torch
     return out * mask.unsqueeze(1).to(w.dtype)
 
 
+# --------------------------------------------------------------------------- mixture of experts
+def moe_route(router_logits: torch.Tensor, top_k: int):
+    """Qwen3MoeSparseMoeBlock.forward, routing part — nanovllm/models/qwen3_moe.py:150-161.
+
+    softmax over the experts in fp32 (of the bf16 router logits), top-k probabilities, renormalised by their
+    sum in fp32, then cast to the activation dtype.  Returns (weights [T, k] in router_logits.dtype, expert ids
+    [T, k] int64).  Equal probabilities: the lower expert id first (torch.topk leaves ties unspecified; the
+    restatement fixes the order so that CPU and GPU agree)."""
+    p = torch.softmax(router_logits.float(), dim=1)
+    order = torch.argsort(p, dim=-1, descending=True, stable=True)[:, :top_k]
+    w = torch.gather(p, 1, order)
+    w = w / w.sum(dim=-1, keepdim=True)
+    return w.to(router_logits.dtype), order
+
+
+def moe_block(x: torch.Tensor, gate_w: torch.Tensor, gate_up_w: torch.Tensor, down_w: torch.Tensor, top_k: int,
+              return_routing: bool = False):
+    """Qwen3MoeSparseMoeBlock.forward — nanovllm/models/qwen3_moe.py:150-185.
+
+    gate_w [E, H] (nn.Linear, :138); gate_up_w [E, 2I, H] / down_w [E, H, I]: the experts' Qwen3MoeMLP weights
+    (:96-122).  For every expert that was selected by some token, in ascending expert id (:171-172): its MLP on
+    those tokens (bf16 output), times the routing weight in bf16 (:178-180), added into a bf16 accumulator
+    (`index_add_` on a bf16 tensor, :182-184): one rounding per expert a token selected, in that order."""
+    T, H = x.shape
+    logits = linear(x, gate_w)
+    w, ids = moe_route(logits, top_k)
+    out = torch.zeros_like(x)
+    for e in torch.unique(ids).tolist():  # ascending, hit experts only
+        tok, slot = torch.where(ids == e)
+        y = linear(silu_and_mul(linear(x[tok], gate_up_w[e])), down_w[e])
+        cur = y * w[tok, slot, None]  # bf16 * bf16 -> bf16
+        out.index_add_(0, tok, cur.to(x.dtype))
+    return (out, w, ids) if return_routing else out
+
+
 # --------------------------------------------------------------------------- paged KV
 def kv_scatter(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                slot_flat: torch.Tensor) -> None:

@@ -31,6 +31,17 @@ class OracleConfig:
     tie_word_embeddings: bool = True
     attention_bias: bool = False
     qk_norm: bool | None = None  # None: Qwen3 rule, norm iff no qkv bias (qwen3.py:70-72); Llama: False (llama.py:80-93)
+    # mixture of experts (models/qwen3_moe.py); num_experts == 0: dense model
+    num_experts: int = 0
+    num_experts_per_tok: int = 0
+    moe_intermediate_size: int = 0
+    decoder_sparse_step: int = 1
+    mlp_only_layers: tuple = ()
+
+    def is_sparse_layer(self, layer_idx: int) -> bool:
+        """qwen3_moe.py:208-212"""
+        return (layer_idx not in self.mlp_only_layers and self.num_experts > 0
+                and (layer_idx + 1) % self.decoder_sparse_step == 0)
 
     @classmethod
     def from_hf(cls, hf) -> "OracleConfig":
@@ -51,7 +62,13 @@ class OracleConfig:
             max_position_embeddings=hf.max_position_embeddings,
             tie_word_embeddings=bool(getattr(hf, "tie_word_embeddings", False)),
             attention_bias=bool(getattr(hf, "attention_bias", getattr(hf, "model_type", "") != "llama")),
-            qk_norm=False if getattr(hf, "model_type", "") == "llama" else None,
+            qk_norm=False if getattr(hf, "model_type", "") == "llama"
+            else (True if getattr(hf, "num_experts", 0) else None),  # the MoE attention always norms (qwen3_moe.py:76-77)
+            num_experts=int(getattr(hf, "num_experts", 0) or 0),
+            num_experts_per_tok=int(getattr(hf, "num_experts_per_tok", 0) or 0),
+            moe_intermediate_size=int(getattr(hf, "moe_intermediate_size", 0) or 0),
+            decoder_sparse_step=int(getattr(hf, "decoder_sparse_step", 1) or 1),
+            mlp_only_layers=tuple(getattr(hf, "mlp_only_layers", None) or ()),
         )
 
     @property
@@ -81,8 +98,14 @@ def random_weights(cfg: OracleConfig, seed: int = 0, std: float = 0.02, dtype=to
             w[p + "self_attn.q_norm.weight"] = torch.ones(d, dtype=dtype)
             w[p + "self_attn.k_norm.weight"] = torch.ones(d, dtype=dtype)
         w[p + "self_attn.o_proj.weight"] = mat(h, hq * d)
-        w[p + "mlp.gate_up_proj.weight"] = mat(2 * i, h)
-        w[p + "mlp.down_proj.weight"] = mat(h, i)
+        if cfg.is_sparse_layer(li):  # router + stacked expert weights [E, ...]
+            mi = cfg.moe_intermediate_size
+            w[p + "mlp.gate.weight"] = mat(cfg.num_experts, h)
+            w[p + "mlp.experts.gate_up_proj.weight"] = mat(cfg.num_experts, 2 * mi, h)
+            w[p + "mlp.experts.down_proj.weight"] = mat(cfg.num_experts, h, mi)
+        else:
+            w[p + "mlp.gate_up_proj.weight"] = mat(2 * i, h)
+            w[p + "mlp.down_proj.weight"] = mat(h, i)
         w[p + "input_layernorm.weight"] = torch.ones(h, dtype=dtype)
         w[p + "post_attention_layernorm.weight"] = torch.ones(h, dtype=dtype)
     w["model.norm.weight"] = torch.ones(h, dtype=dtype)
@@ -130,11 +153,18 @@ class OracleQwen3:
             stage = {"x": x, "qkv": qkv, "o": o.reshape(o.shape[0], -1)} if trace is not None else None
             h = L.linear(o, w[p + "self_attn.o_proj.weight"])
             x, residual = L.add_rms_norm(h, residual, w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
-            gu = L.linear(x, w[p + "mlp.gate_up_proj.weight"])
-            act = L.silu_and_mul(gu)
-            if trace is not None:
-                stage.update(o_proj=h, x2=x, residual=residual, act=act)
-            h = L.linear(act, w[p + "mlp.down_proj.weight"])
+            if c.is_sparse_layer(li):
+                act = x  # no single activation tensor: the block's input stands in for the trace
+                if trace is not None:
+                    stage.update(o_proj=h, x2=x, residual=residual, act=act)
+                h = L.moe_block(x, w[p + "mlp.gate.weight"], w[p + "mlp.experts.gate_up_proj.weight"],
+                                w[p + "mlp.experts.down_proj.weight"], c.num_experts_per_tok)
+            else:
+                gu = L.linear(x, w[p + "mlp.gate_up_proj.weight"])
+                act = L.silu_and_mul(gu)
+                if trace is not None:
+                    stage.update(o_proj=h, x2=x, residual=residual, act=act)
+                h = L.linear(act, w[p + "mlp.down_proj.weight"])
             if trace is not None:
                 stage["mlp_out"] = h
                 trace.append({k: v.clone() for k, v in stage.items()})

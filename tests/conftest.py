@@ -57,3 +57,14 @@ def golden_tiny_bias():
 def golden_tiny_llama():
     """The reference's LlamaForCausalLM (no q/k norm, no bias) on the tiny shapes."""
     return np.load(os.path.join(GOLDEN, "tiny_model_llama.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tiny_moe():
+    """The reference's Qwen3MoeForCausalLM (8 experts, top-2) on the tiny shapes."""
+    return np.load(os.path.join(GOLDEN, "tiny_model_moe.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_moe_block():
+    return np.load(os.path.join(GOLDEN, "moe_block.npz"))

@@ -16,6 +16,11 @@ TINY = dict(QWEN3_0_6B, hidden_size=128, num_hidden_layers=2, num_attention_head
 # the reference's Llama wiring (models/llama.py) on the tiny shapes: no q/k norm, no biases, rope_theta 1e4
 TINY_LLAMA = dict(TINY, architectures=["LlamaForCausalLM"], model_type="llama", rope_theta=10000.0, mlp_bias=False)
 
+# the reference's Qwen3-MoE wiring (models/qwen3_moe.py): 8 experts, top-2, every layer sparse
+TINY_MOE = dict(TINY, architectures=["Qwen3MoeForCausalLM"], model_type="qwen3_moe", num_experts=8,
+                num_experts_per_tok=2, moe_intermediate_size=64, decoder_sparse_step=1, mlp_only_layers=[],
+                norm_topk_prob=True)
+
 MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
            bos_token_id=0)
 

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import bf16_from_bits as bf
-from model_configs import QWEN3_32B_2L, MID, TINY, TINY_LLAMA, make_model_dir
+from model_configs import QWEN3_32B_2L, MID, TINY, TINY_LLAMA, TINY_MOE, make_model_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -19,20 +19,21 @@ def _split(flat, lens):
     return out
 
 
-@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias", "llama"])
+@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias", "llama", "moe"])
 @pytest.mark.parametrize("enforce_eager", [True, False])
-def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, golden_tiny_llama, enforce_eager, variant):
+def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, golden_tiny_llama, golden_tiny_moe, enforce_eager, variant):
     """Same prompts, same weights, greedy: block tables follow the same FIFO order, logits
     agree with the reference's bf16 CPU pipeline to a bf16-ulp-scale bound, tokens agree
     wherever the reference's top-2 margin exceeds that bound.  Both wirings of qwen3.py:70-72:
     q/k norm without bias (Qwen3) and qkv bias without norm (attention_bias=True), and the reference's
-    LlamaForCausalLM (models/llama.py: neither), which runs the fused decode launch with null norm weights."""
+    LlamaForCausalLM (models/llama.py: neither), which runs the fused decode launch with null norm weights, and
+    its Qwen3MoeForCausalLM (models/qwen3_moe.py: 8 experts, top-2), whose sparse blocks run csrc/moe.hip."""
     from nanovllm import LLM, SamplingParams
     from nanovllm.utils.loader import load_state_dict_packed
 
-    g = {"qwen3": golden_tiny, "qkv_bias": golden_tiny_bias, "llama": golden_tiny_llama}[variant]
+    g = {"qwen3": golden_tiny, "qkv_bias": golden_tiny_bias, "llama": golden_tiny_llama, "moe": golden_tiny_moe}[variant]
     block_size, nblk = (int(v) for v in g["meta"])
-    tiny = {"qwen3": TINY, "qkv_bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA}[variant]
+    tiny = {"qwen3": TINY, "qkv_bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA, "moe": TINY_MOE}[variant]
     llm = LLM(make_model_dir(tiny), kvcache_block_size=block_size, max_num_seqs=4, max_num_batched_tokens=128,
               max_model_len=128, num_kvcache_blocks=nblk, enforce_eager=enforce_eager, warmup=False)
     try:
@@ -63,11 +64,12 @@ def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, golden_tiny_llama,
 
 
 def _oracle_for(llm, cfg_dict, seed):
-    from transformers import Qwen3Config
+    from transformers import Qwen3Config, Qwen3MoeConfig
 
     from oracle.model import OracleConfig, OracleQwen3, random_weights
 
-    hf = Qwen3Config(**{k: v for k, v in cfg_dict.items() if k not in ("architectures", "model_type", "torch_dtype")})
+    cls = Qwen3MoeConfig if cfg_dict.get("model_type") == "qwen3_moe" else Qwen3Config
+    hf = cls(**{k: v for k, v in cfg_dict.items() if k not in ("architectures", "model_type", "torch_dtype")})
     ocfg = OracleConfig.from_hf(hf)
     return OracleQwen3(ocfg, random_weights(ocfg, seed=seed), llm.config.num_kvcache_blocks,
                        llm.config.kvcache_block_size)
@@ -137,6 +139,22 @@ def test_engine_matches_oracle_qkv_bias_variant():
     """attention_bias=True (the Qwen2 wiring of qwen3.py:70-72,135: bias on the qkv projection, no q/k
     norm): takes the module-by-module decode path (bias epilogue of the skinny GEMM, RoPE without norm)."""
     _engine_vs_oracle(dict(MID, attention_bias=True), [5, 16, 17, 63, 31], enforce_eager=False, seed=4, tol=4e-2)
+
+
+# BASELINE.json configs[3] as a parity case: Qwen3-30B-A3B widths (hidden 2048, 32 q / 4 kv heads, 128 experts,
+# top-8, moe_intermediate 768), 2 layers, small vocabulary - the CPU oracle follows in seconds
+QWEN3_30B_A3B_2L = dict(MID, architectures=["Qwen3MoeForCausalLM"], model_type="qwen3_moe", hidden_size=2048,
+                        num_hidden_layers=2, num_attention_heads=32, num_key_value_heads=4, intermediate_size=6144,
+                        num_experts=128, num_experts_per_tok=8, moe_intermediate_size=768, decoder_sparse_step=1,
+                        mlp_only_layers=[], norm_topk_prob=True, tie_word_embeddings=False)
+
+
+def test_engine_matches_oracle_qwen3_30b_a3b_widths():
+    """Engine (eager prefill through the grouped kernels, hipGraph decode) vs the oracle for the MoE widths.
+    A routing decision is a discrete choice: where two experts' probabilities are within bf16 noise the two
+    pipelines may pick differently, so - exactly as for greedy tokens - logits are compared per step on a
+    bound that allows for it (1.3e-1 at logits up to ~10)."""
+    _engine_vs_oracle(QWEN3_30B_A3B_2L, [5, 17, 64, 33], enforce_eager=False, seed=6, tol=1.3e-1, max_tokens=4)
 
 
 def test_engine_fp8_weights_match_oracle_on_dequantised_weights():

@@ -690,3 +690,76 @@ def test_kernels_capture_into_hipgraph(ops):
     want = oracle.rms_norm(oracle.linear(want, w.cpu()), nw.cpu(), 1e-6)
     assert_bf16_close(res, want, max_ulp=2, max_frac=5e-2, atol=1e-3)
     assert eager.shape == res.shape
+
+
+# --------------------------------------------------------------------------- mixture of experts
+def _assert_moe_close(got, want):
+    """An output is a chain of top_k bf16 additions (`index_add_` on a bf16 tensor): every partial sum is rounded
+    at ITS magnitude, so a one-ulp difference in one expert's contribution moves the result by an ulp of the
+    partial sums, which for a token can be as large as its largest output.  Bound: 2 bf16 ulps of the element,
+    or 2 ulps at the scale of the token's largest output; at most 5 % of the elements off at all."""
+    g, w = got.cpu().float(), want.float()
+    row_ulp = torch.exp2(torch.floor(torch.log2(w.abs().amax(dim=1, keepdim=True).clamp_min(1e-6))) - 7)
+    bad = (ulp_diff(got, want) > 2) & ((g - w).abs() > 2 * row_ulp)
+    assert not bool(bad.any()), f"{int(bad.sum())} elements off, worst {float(((g - w).abs() / row_ulp)[bad].max()):.1f} row-ulps"
+    assert float((ulp_diff(got, want) > 0).float().mean()) <= 5e-2
+
+
+def _moe_case(ops, x, gate_w, gu, dn, top_k):
+    """the five MoE launches behind the router GEMM vs oracle.moe_block (restatement of qwen3_moe.py:150-185)"""
+    from oracle import layers as L
+
+    want, w_o, ids_o = L.moe_block(x, gate_w, gu, dn, top_k, return_routing=True)
+    logits = oracle.linear(x, gate_w)  # the router GEMM itself is mi_gemm_bf16_* (tested above)
+    gup, dnp = ops.pack_expert_weights(gu.to(DEV)), ops.pack_expert_weights(dn.to(DEV))
+    got, ids, w = ops.moe_forward(x.to(DEV), logits.to(DEV), gup, dnp, top_k)
+    ids, w = ids.cpu().long(), w.cpu()
+    # routing: every token's picks ascending by expert id; same experts as the oracle, weights to one bf16 ulp
+    assert bool((ids[:, 1:] > ids[:, :-1]).all())
+    order = ids_o.argsort(-1)
+    assert torch.equal(ids, torch.gather(ids_o, 1, order))
+    assert int(ulp_diff(w, torch.gather(w_o, 1, order)).max()) <= 1
+    _assert_moe_close(got, want)
+
+
+def test_moe_block_golden(ops, golden_moe_block):
+    """vs the reference's own Qwen3MoeSparseMoeBlock run (tests/golden/moe_block.npz) and vs the oracle"""
+    g = golden_moe_block
+    for tag in ("small", "wide"):
+        T, H, E, K, I = (int(v) for v in g[f"{tag}_meta"])
+        x, gw = bf(g[f"{tag}_x"]), bf(g[f"{tag}_gate_w"])
+        gu, dn = bf(g[f"{tag}_gate_up_w"]).view(E, 2 * I, H).contiguous(), bf(g[f"{tag}_down_w"]).view(E, H, I).contiguous()
+        _moe_case(ops, x, gw, gu, dn, K)
+        logits = oracle.linear(x, gw)
+        got, ids, _ = ops.moe_forward(x.to(DEV), logits.to(DEV), ops.pack_expert_weights(gu.to(DEV)),
+                                      ops.pack_expert_weights(dn.to(DEV)), K)
+        assert torch.equal(ids.cpu().long(), torch.from_numpy(g[f"{tag}_topk_ids"]).sort(-1).values)
+        _assert_moe_close(got, bf(g[f"{tag}_y"]))
+
+
+@pytest.mark.parametrize("T", [1, 32, 64, 100])
+@pytest.mark.parametrize("inter", [768, 192])
+def test_moe_block_qwen3_30b_a3b_shapes(ops, T, inter):
+    """BASELINE.json configs[3]: hidden 2048, 128 experts, top-8, moe_intermediate 768 (TP=4 shard: 192);
+    decode-sized batches and a prefill-sized one (several 16-pair passes per expert)."""
+    gen = torch.Generator().manual_seed(T + inter)
+    H, E, K = 2048, 128, 8
+    x = torch.randn(T, H, generator=gen).bfloat16()
+    gate_w = (torch.randn(E, H, generator=gen) * 0.1).bfloat16()
+    gu = (torch.randn(E, 2 * inter, H, generator=gen) * 0.03).bfloat16()
+    dn = (torch.randn(E, H, inter, generator=gen) * 0.03).bfloat16()
+    _moe_case(ops, x, gate_w, gu, dn, K)
+
+
+def test_moe_route_ties_and_uniform_logits(ops):
+    """equal router logits: the lower expert ids win (the restatement's tie rule), weights are exactly 1/k"""
+    T, E, K, H, I = 5, 64, 4, 128, 64
+    logits = torch.zeros(T, E).bfloat16()
+    logits[1, 40] = 3.0
+    x = torch.randn(T, H).bfloat16()
+    gu = (torch.randn(E, 2 * I, H) * 0.05).bfloat16()
+    dn = (torch.randn(E, H, I) * 0.05).bfloat16()
+    _, ids, w = ops.moe_forward(x.to(DEV), logits.to(DEV), ops.pack_expert_weights(gu.to(DEV)),
+                                ops.pack_expert_weights(dn.to(DEV)), K)
+    assert ids[0].tolist() == [0, 1, 2, 3] and ids[1].tolist() == [0, 1, 2, 40]
+    assert torch.equal(w[0].cpu().float(), torch.full((K,), 0.25))

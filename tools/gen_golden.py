@@ -13,6 +13,7 @@ Fixtures
   hash_kats.json     xxh64 chained block hashes   (engine/block_manager.py:38-44)
   layers.npz         RMSNorm / add-RMSNorm / RoPE / SiluAndMul / Sampler-softmax I/O
   attention.npz      layers/attention_torch_native.py store + prefill + decode I/O
+  moe_block.npz      models/qwen3_moe.py Qwen3MoeSparseMoeBlock I/O (router top-k captured, block output)
   engine_traces.json Scheduler + BlockManager + Sequence + ModelRunner.prepare_* traces
   tiny_model.npz     2-layer random Qwen3 driven through the reference's model,
                      scheduler and prepare_* (greedy = argmax of the reference logits);
@@ -373,15 +374,61 @@ def gen_engine_fuzz(n_scenarios=14):
           f"steps: {sum(len(sc['steps']) for sc in out)}")
 
 
+# --------------------------------------------------------------------------- D2. mixture-of-experts block
+def gen_moe_block():
+    """Qwen3MoeSparseMoeBlock (models/qwen3_moe.py:125-185) on random inputs: router logits, the top-k the block
+    drew (captured from its torch.topk call), and its output, for two shapes (decode-sized and prefill-sized)."""
+    import nanovllm.models.qwen3_moe as ref_moe
+
+    out = {}
+    for tag, (T, H, E, K, I) in {"small": (19, 128, 8, 2, 64), "wide": (70, 128, 16, 4, 64)}.items():
+        g = torch.Generator().manual_seed({"small": 11, "wide": 12}[tag])
+        cfg = SimpleNamespace(hidden_size=H, intermediate_size=4 * H, hidden_act="silu", num_experts=E,
+                              num_experts_per_tok=K, moe_intermediate_size=I)
+        torch.set_default_dtype(torch.bfloat16)
+        blk = ref_moe.Qwen3MoeSparseMoeBlock(cfg)
+        torch.set_default_dtype(torch.float32)
+        gate_w = (torch.randn(E, H, generator=g) * 0.5).bfloat16()
+        gu = (torch.randn(E, 2 * I, H, generator=g) * 0.08).bfloat16()
+        dn = (torch.randn(E, H, I, generator=g) * 0.08).bfloat16()
+        blk.gate.weight.data.copy_(gate_w)
+        for e in range(E):
+            blk.experts[e].gate_up_proj.weight.data.copy_(gu[e])
+            blk.experts[e].down_proj.weight.data.copy_(dn[e])
+        x = (torch.randn(T, H, generator=g) * 1.5).bfloat16()
+        captured = {}
+        real_topk = torch.topk
+
+        def spy(*a, **kw):
+            r = real_topk(*a, **kw)
+            captured["w"], captured["ids"] = r[0].clone(), r[1].clone()
+            return r
+
+        torch.topk = spy
+        try:
+            with torch.inference_mode():
+                y = blk(x)
+        finally:
+            torch.topk = real_topk
+        out[f"{tag}_meta"] = np.array([T, H, E, K, I])
+        out[f"{tag}_x"], out[f"{tag}_gate_w"], out[f"{tag}_gate_up_w"], out[f"{tag}_down_w"] = bits(x), bits(gate_w), bits(gu), bits(dn)
+        out[f"{tag}_y"] = bits(y)
+        out[f"{tag}_topk_ids"] = captured["ids"].numpy().astype(np.int64)
+        out[f"{tag}_topk_prob"] = captured["w"].float().numpy()  # before the renormalisation (qwen3_moe.py:158-159)
+    np.savez_compressed(os.path.join(OUT, "moe_block.npz"), **out)
+
+
 # --------------------------------------------------------------------------- E. tiny model
 def gen_tiny_model(variant: str = ""):
     """variant "": Qwen3 wiring (q/k norm, no bias); "bias": attention_bias=True - qkv bias, no q/k norm
     (the Qwen2 wiring of qwen3.py:70-72,135); "llama": the reference's LlamaForCausalLM (models/llama.py:
-    neither q/k norm nor bias) on the same tiny shapes."""
-    from transformers import LlamaConfig, Qwen3Config
+    neither q/k norm nor bias) on the same tiny shapes; "moe": its Qwen3MoeForCausalLM (models/qwen3_moe.py)
+    with 8 experts, top-2, every layer sparse."""
+    from transformers import LlamaConfig, Qwen3Config, Qwen3MoeConfig
 
     import nanovllm.models.llama as ref_llama
     import nanovllm.models.qwen3 as ref_qwen3
+    import nanovllm.models.qwen3_moe as ref_moe
     from nanovllm.engine.scheduler import Scheduler
     from nanovllm.engine.sequence import Sequence
     from nanovllm.layers.attention_torch_native import Attention as NativeAttention
@@ -405,25 +452,35 @@ def gen_tiny_model(variant: str = ""):
 
     ref_qwen3.Attention = NativeAdapter
     ref_llama.Attention = NativeAdapter
+    ref_moe.Attention = NativeAdapter
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from model_configs import TINY, TINY_LLAMA  # the same dicts the tests build their model directories from
+    from model_configs import TINY, TINY_LLAMA, TINY_MOE  # the same dicts the tests build their model directories from
 
-    tiny = {"bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA}.get(variant, TINY)
-    cfg_cls = LlamaConfig if variant == "llama" else Qwen3Config
+    tiny = {"bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA, "moe": TINY_MOE}.get(variant, TINY)
+    cfg_cls = {"llama": LlamaConfig, "moe": Qwen3MoeConfig}.get(variant, Qwen3Config)
     hf = cfg_cls(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
-    weights = random_weights(cfg, seed={"": 3, "bias": 13, "llama": 23}[variant], std=0.08)
+    weights = random_weights(cfg, seed={"": 3, "bias": 13, "llama": 23, "moe": 33}[variant], std=0.08)
+    if variant == "moe":  # a wider router so that the top-2 choice is not a coin flip between near-equal logits
+        for name in list(weights):
+            if name.endswith("mlp.gate.weight"):
+                weights[name] = (weights[name].float() * 6).to(torch.bfloat16)
     # non-trivial norm weights so the norm multiplies are exercised
     g = torch.Generator().manual_seed(5)
     for name in list(weights):
         if "norm" in name:
             weights[name] = (1.0 + 0.1 * torch.randn(weights[name].shape, generator=g)).to(torch.bfloat16)
     torch.set_default_dtype(torch.bfloat16)
-    model = ref_llama.LlamaForCausalLM(hf) if variant == "llama" else ref_qwen3.Qwen3ForCausalLM(hf)
+    model = {"llama": ref_llama.LlamaForCausalLM, "moe": ref_moe.Qwen3MoeForCausalLM}.get(
+        variant, ref_qwen3.Qwen3ForCausalLM)(hf)
     torch.set_default_dtype(torch.float32)
     sd = dict(model.named_parameters())
     for name, w in weights.items():
-        sd[name].data.copy_(w)
+        if ".mlp.experts." in name:  # stacked [E, ...] in the fixture, one module per expert in the reference
+            for e in range(w.shape[0]):
+                sd[name.replace(".experts.", f".experts.{e}.")].data.copy_(w[e])
+        else:
+            sd[name].data.copy_(w)
     # rope table must be fp32 (default dtype was bf16 while constructing)
     from nanovllm.layers.rotary_embedding import RotaryEmbedding
     rope = RotaryEmbedding(128, 128, 512, cfg.rope_theta)
@@ -480,7 +537,8 @@ def main():
     for name, fn in (("hashes", gen_hashes), ("layers", gen_layers), ("attention", gen_attention),
                      ("engine", gen_engine), ("engine_fuzz", gen_engine_fuzz), ("tiny_model", gen_tiny_model),
                      ("tiny_model_bias", lambda: gen_tiny_model("bias")),
-                     ("tiny_model_llama", lambda: gen_tiny_model("llama"))):
+                     ("tiny_model_llama", lambda: gen_tiny_model("llama")), ("moe_block", gen_moe_block),
+                     ("tiny_model_moe", lambda: gen_tiny_model("moe"))):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
