@@ -297,6 +297,25 @@ int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatur
               int64_t* out, int rows, int vocab, uint64_t seed, uint64_t step,
               mi_stream stream);
 
+/* The head GEMM and the sampler in one pass (decode, one GPU: embed_head.py:57-61
+ * followed by sampler.py:9-17).  y = x @ W^T as mi_gemm_bf16_packed, and every
+ * workgroup also reports the best sampling key of its columns per row - the key
+ * mi_argmax / mi_sample would form from the ROUNDED logit, bit for bit - into
+ * candidates [mi_gemm_pick_groups(M, N)][M] x 8 bytes.  mi_pick_final reduces
+ * them to out[rows] (ties -> lowest column): the same tokens as mi_sample over y
+ * with the same (seed, step), without reading y again.  rng points to
+ * {seed, step} in DEVICE memory so that a captured graph picks up the step the
+ * host wrote before replaying it.  temperatures may be NULL (all rows greedy). */
+int mi_gemm_pick_groups(int M, int N);
+int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y,
+                             int M, int N, int K, const float* temperatures,
+                             const uint64_t* rng, void* candidates, mi_stream stream);
+int mi_gemm_fp8w_packed_pick(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
+                             mi_bf16* y, int M, int N, int K, const float* temperatures,
+                             const uint64_t* rng, void* candidates, mi_stream stream);
+int mi_pick_final(const void* candidates, int n_groups, int rows, int64_t* out,
+                  mi_stream stream);
+
 /* ---- fp8 (e4m3) weights, bf16 activations (BASELINE.json configs[4]) --------
  * No reference semantics exist (the reference is bf16 only): y = x @ (w_q * scale[:, None])^T with
  * w_q OCP e4m3 values and one fp32 scale per weight row (output feature).  Decode GEMMs are bound

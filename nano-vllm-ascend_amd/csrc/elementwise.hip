@@ -496,20 +496,6 @@ __global__ __launch_bounds__(256) void row_gather_kernel(const int64_t* __restri
 // argmax / Gumbel-max sampling over [rows][vocab] bf16 logits (sampler.py:9-17)
 // one 1024-thread workgroup per row; key = (value, lowest index)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {
-  z += 0x9e3779b97f4a7c15ull;
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
-}
-
-__device__ __forceinline__ float gumbel_key(float logit, float inv_t, uint64_t rkey, int col) {
-  // u in (0,1): 24 random bits, never 0 or 1
-  const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  return logit * inv_t - logf(-logf(u));
-}
-
 // scan one row: 4 independent 16-byte loads per thread and iteration are issued before any compare
 template <bool NOISY>
 __device__ __forceinline__ void scan_row(const uint16_t* __restrict__ p, int vocab, float inv_t, uint64_t rkey,
@@ -569,7 +555,7 @@ __global__ __launch_bounds__(1024) void pick_kernel(const uint16_t* __restrict__
     noisy = t > 0.f;
     inv_t = noisy ? 1.0f / t : 1.0f;
   }
-  const uint64_t rkey = seed * 0x9e3779b97f4a7c15ull + step * 0xd1342543de82ef95ull + (uint64_t)row * 0x2545f4914f6cdd1dull;
+  const uint64_t rkey = sample_row_key(seed, step, row);
   float best = -INFINITY;
   int best_i = 0x7fffffff;
   if (SAMPLE && noisy) scan_row<true>(p, vocab, inv_t, rkey, best, best_i);

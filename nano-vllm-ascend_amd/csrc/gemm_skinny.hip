@@ -27,7 +27,17 @@
 
 namespace mi {
 
-enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2, EPI_PICK = 3 };
+
+// EPI_PICK (the head GEMM of a decode step): besides the bf16 logits every workgroup reports, per activation
+// row, the best sampling key among its columns - the logit itself for greedy rows, logit / T + Gumbel noise
+// for sampled ones (the keys of mi_argmax / mi_sample, bit for bit) - so that the token choice needs one
+// small launch over [workgroups][rows] candidates (mi_pick_final) instead of a second pass over the logits.
+struct PickArgs {
+  const float* temperatures;  // [M]; nullptr or <= 0: greedy
+  const uint64_t* rng;        // {seed, step} in device memory (a captured graph reads the current step)
+  uint2* cand;                // [gridDim.x][M] {key bits, column}
+};
 
 // B fragments (the activations x^T) of one wave for STEPS k-steps starting at xk = x + k0:
 //   bfrag[m][s] of lane (g, c) = x[16 m + c][k0 + 32 s + 8 g .. +7]   (rows >= M clamped to M - 1).
@@ -76,7 +86,8 @@ constexpr int x_slab_bytes(int MT) { return MT * 16 * 64 * 2; }
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K) {
+    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K,
+    PickArgs pk) {
   // [WAVES][RT*MT][256] fp32 K-slice sums; before that, each wave's slot doubles as its x slab
   extern __shared__ __attribute__((aligned(16))) float red[];
   constexpr int SLOT = RT * MT * 1024 > x_slab_bytes(MT) ? RT * MT * 1024 : x_slab_bytes(MT);  // bytes per wave
@@ -177,6 +188,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   __syncthreads();
   // each (row tile, m-tile, lane) result is finished by one thread, summing K-slices in wave order
   constexpr int ITEMS = (EPI == EPI_SILU ? 1 : RT) * MT * 64;
+  __shared__ float pick_key[EPI == EPI_PICK ? MT * 16 : 1][RT * 4];
+  __shared__ int pick_col[EPI == EPI_PICK ? MT * 16 : 1][RT * 4];
   for (int item = threadIdx.x; item < ITEMS; item += WAVES * 64) {
     const int l = item & 63, m = (item >> 6) % MT, t = (item >> 6) / MT;
     auto total = [&](int tt) {
@@ -191,7 +204,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
       return s;
     };
     const int row = 16 * m + (l & 15);
-    if (row >= M) continue;
+    if (row >= M) {
+      if (EPI == EPI_PICK) {
+        pick_key[row][t * 4 + (l >> 4)] = -INFINITY;
+        pick_col[row][t * 4 + (l >> 4)] = 0x7fffffff;
+      }
+      continue;
+    }
     if (EPI == EPI_SILU) {
       const f32x4 gt = total(0), up = total(1);
       const int col = (int)blockIdx.x * 16 + 4 * (l >> 4);
@@ -223,8 +242,86 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
         o[0] = pack_bf(s[0], s[1]);
         o[1] = pack_bf(s[2], s[3]);
         *reinterpret_cast<u32x2*>(y + (int64_t)row * N + col) = o;
+        if (EPI == EPI_PICK) {  // keys of the ROUNDED logits, as a sampler reading y would form them
+          const float tmp = pk.temperatures ? pk.temperatures[row] : 0.f;
+          const bool noisy = tmp > 0.f;
+          const float inv_t = noisy ? 1.0f / tmp : 1.0f;
+          const uint64_t rkey = sample_row_key(pk.rng[0], pk.rng[1], row);
+          const float v[4] = {lo_bf(o[0]), hi_bf(o[0]), lo_bf(o[1]), hi_bf(o[1])};
+          float best = -INFINITY;
+          int best_c = 0x7fffffff;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float key = noisy ? gumbel_key(v[i], inv_t, rkey, col + i) : v[i];
+            if (key > best) {  // ascending columns: the first of equal keys stays
+              best = key;
+              best_c = col + i;
+            }
+          }
+          pick_key[row][t * 4 + (l >> 4)] = best;
+          pick_col[row][t * 4 + (l >> 4)] = best_c;
+        }
       }
     }
+  }
+  if (EPI == EPI_PICK) {
+    __syncthreads();
+    if ((int)threadIdx.x < M) {
+      const int row = threadIdx.x;
+      float best = pick_key[row][0];
+      int best_c = pick_col[row][0];
+#pragma unroll
+      for (int j = 1; j < RT * 4; ++j) {
+        const float k2 = pick_key[row][j];
+        const int c2 = pick_col[row][j];
+        if (k2 > best || (k2 == best && c2 < best_c)) {
+          best = k2;
+          best_c = c2;
+        }
+      }
+      pk.cand[(int64_t)blockIdx.x * M + row] = uint2{__float_as_uint(best), (uint32_t)best_c};
+    }
+  }
+}
+
+// token of every row from the candidates of EPI_PICK: one workgroup per row
+__global__ __launch_bounds__(256) void pick_final_kernel(const uint2* __restrict__ cand, int n_groups, int M,
+                                                         int64_t* __restrict__ out) {
+  const int row = blockIdx.x;
+  float best = -INFINITY;
+  int best_c = 0x7fffffff;
+  for (int gidx = threadIdx.x; gidx < n_groups; gidx += 256) {
+    const uint2 c = cand[(int64_t)gidx * M + row];
+    const float k2 = __uint_as_float(c.x);
+    const int c2 = (int)c.y;
+    if (k2 > best || (k2 == best && c2 < best_c)) {
+      best = k2;
+      best_c = c2;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oc = __shfl_xor(best_c, o, 64);
+    if (ob > best || (ob == best && oc < best_c)) {
+      best = ob;
+      best_c = oc;
+    }
+  }
+  __shared__ float sb[4];
+  __shared__ int sc[4];
+  if ((threadIdx.x & 63) == 0) {
+    sb[threadIdx.x >> 6] = best;
+    sc[threadIdx.x >> 6] = best_c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sb[w] > best || (sb[w] == best && sc[w] < best_c)) {
+        best = sb[w];
+        best_c = sc[w];
+      }
+    out[row] = best_c == 0x7fffffff ? 0 : best_c;
   }
 }
 
@@ -363,6 +460,7 @@ struct GemmArgs {
   int M, N, K, ksplit;
   hipStream_t st;
   const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
+  PickArgs pick = PickArgs{nullptr, nullptr, nullptr};
 };
 
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
@@ -373,10 +471,10 @@ static void launch(const GemmArgs& a) {
   const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
   if (a.bias && EPI == EPI_NONE)
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
-                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K);
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
   else
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false>), grid, dim3(WAVES * 64), lds,
-                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K);
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
 }
 
 // choose STEPS (k-steps in flight per wave and iteration) from the K-slice and the register budget
@@ -490,6 +588,48 @@ extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, co
   // two row tiles per workgroup halve the x traffic per weight byte once there are plenty of tiles
   if (N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32) return pick_mt<2, 1, EPI_NONE>(a);
   return pick_mt<1, 1, EPI_NONE>(a);
+}
+
+// head GEMM with the pick epilogue: the same workgroup geometry as mi_gemm_bf16_packed for this (M, N)
+static bool pick_two_tiles(int M, int N) { return N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32; }
+
+extern "C" int mi_gemm_pick_groups(int M, int N) {
+  if (M <= 0 || N <= 0 || N % 16) return 0;
+  return pick_two_tiles(M, N) ? N / 32 : N / 16;
+}
+
+extern "C" int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K,
+                                        const float* temperatures, const uint64_t* rng, void* candidates,
+                                        mi_stream stream) {
+  int rc = check_gemm(x, w_packed, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (!rng || !candidates) return MI_EINVAL;
+  if (M == 0) return MI_OK;
+  GemmArgs a{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)};
+  a.pick = PickArgs{temperatures, rng, static_cast<uint2*>(candidates)};
+  return pick_two_tiles(M, N) ? pick_mt<2, 1, EPI_PICK>(a) : pick_mt<1, 1, EPI_PICK>(a);
+}
+
+extern "C" int mi_gemm_fp8w_packed_pick(const mi_bf16* x, const uint8_t* w_packed, const float* scale, mi_bf16* y,
+                                        int M, int N, int K, const float* temperatures, const uint64_t* rng,
+                                        void* candidates, mi_stream stream) {
+  int rc = check_gemm(x, w_packed, y, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (!scale || !aligned16(scale) || !rng || !candidates) return MI_EINVAL;
+  if (K % 64) return MI_EUNSUPPORTED;
+  if (M == 0) return MI_OK;
+  GemmArgs a{x, reinterpret_cast<const uint16_t*>(w_packed), nullptr, y, nullptr, M, N, K, 1, S(stream)};
+  a.scale = scale;
+  a.pick = PickArgs{temperatures, rng, static_cast<uint2*>(candidates)};
+  return pick_two_tiles(M, N) ? pick_mt<2, 2, EPI_PICK>(a) : pick_mt<1, 2, EPI_PICK>(a);
+}
+
+extern "C" int mi_pick_final(const void* candidates, int n_groups, int rows, int64_t* out, mi_stream stream) {
+  if (!candidates || !out || n_groups <= 0 || rows < 0) return MI_EINVAL;
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(pick_final_kernel, dim3(rows), dim3(256), 0, S(stream), static_cast<const uint2*>(candidates),
+                     n_groups, rows, out);
+  return check_launch();
 }
 
 extern "C" int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream) {

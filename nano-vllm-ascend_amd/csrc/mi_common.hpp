@@ -44,6 +44,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- counter-based random numbers of the sampler (mi_sample, and the pick epilogue of the head GEMM) ----
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
+__device__ __forceinline__ float gumbel_key(float logit, float inv_t, uint64_t rkey, int col) {
+#pragma clang fp contract(off)  // the same bits in every translation unit
+  // u in (0,1): 24 random bits, never 0 or 1
+  const float u = ((float)(mix32(rkey + (uint64_t)col) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return logit * inv_t - logf(-logf(u));
+}
+
+// key of one sampling row: (seed, step, row) -> 64 bits mixed per column by gumbel_key
+__device__ __forceinline__ uint64_t sample_row_key(uint64_t seed, uint64_t step, int row) {
+  return seed * 0x9e3779b97f4a7c15ull + step * 0xd1342543de82ef95ull + (uint64_t)row * 0x2545f4914f6cdd1dull;
+}
+
 // ---- fragment-native KV tile addressing (see include/mi355_nanovllm.h) -----
 // element offset of (t, d) inside a 16-token x 128-dim K tile
 __host__ __device__ __forceinline__ int k_tile_off(int t, int d) {

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from nanovllm import ops
 from nanovllm.config import Config
 from nanovllm.engine import batch_meta
 from nanovllm.engine.rpc import StepChannel
@@ -115,6 +116,7 @@ class ModelRunner:
         self.allocate_kv_cache()
         self._alloc_staging()
         self.graphs: dict[int, torch.cuda.CUDAGraph] = {}
+        self.graph_samples: set[int] = set()  # buckets whose graph ends in the token choice, not in the logits
         self.graph_logits: dict[int, torch.Tensor] = {}
         # with TP the captured graph holds the xGMI exchange kernels; without them (RCCL all-reduce inside)
         # capture is only attempted on the nccl backend
@@ -231,9 +233,9 @@ class ModelRunner:
         B = cfg.max_num_seqs
         W = -(-(cfg.max_model_len + 1) // self.block_size)  # a max-length prompt still decodes one token
         self.table_cols = W
-        # [ids i64 B][pos i64 B][temps f32 B][ctx i32 B][slots i32 2B][tables i32 B*W]
+        # [ids i64 B][pos i64 B][rng u64 2][temps f32 B][ctx i32 B][slots i32 2B][tables i32 B*W]
         off, spans = 0, {}
-        for name, nbytes in (("ids", 8 * B), ("pos", 8 * B), ("temps", 4 * B), ("ctx", 4 * B),
+        for name, nbytes in (("ids", 8 * B), ("pos", 8 * B), ("rng", 16), ("temps", 4 * B), ("ctx", 4 * B),
                              ("slots", 8 * B), ("tables", 4 * B * W)):
             spans[name] = (off, nbytes)
             off += (nbytes + 15) // 16 * 16
@@ -246,7 +248,7 @@ class ModelRunner:
                 o, n = spans[name]
                 return buf[o:o + n].view(dtype).view(shape)
             return {"ids": v("ids", torch.int64, (B,)), "pos": v("pos", torch.int64, (B,)),
-                    "temps": v("temps", torch.float32, (B,)), "ctx": v("ctx", torch.int32, (B,)),
+                    "rng": v("rng", torch.int64, (2,)), "temps": v("temps", torch.float32, (B,)), "ctx": v("ctx", torch.int32, (B,)),
                     "slots": v("slots", torch.int32, (B, 2)), "tables": v("tables", torch.int32, (B, W))}
 
         self.dev = views(self.dev_stage)
@@ -264,6 +266,9 @@ class ModelRunner:
         """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the pinned
         staging buffer (incremental block-table rows), then ONE async copy to the device."""
         self.stager.fill(seqs, bucket, self.config.num_kvcache_blocks - 1)
+        rng = self.host["rng"].view(np.uint64)  # what THIS step's sampler uses (a captured graph reads it here)
+        rng[0] = self.sampler.seed & 0xFFFFFFFFFFFFFFFF
+        rng[1] = (self.sampler.step + 1) & 0xFFFFFFFFFFFFFFFF
         self.dev_stage.copy_(self.host_stage, non_blocking=True)
 
     # ------------------------------------------------------------------ metadata -> context
@@ -316,6 +321,9 @@ class ModelRunner:
     @torch.inference_mode()
     def capture_decode_graphs(self):
         cfg, d = self.config, self.dev
+        pick = (self.world_size == 1 and os.environ.get("MI355_GRAPH_SAMPLER", "1") != "0"
+                and self.model.lm_head.can_pick())
+        self.graph_samples = {bs for bs in graph_buckets(cfg.max_num_seqs) if pick and bs <= ops.SKINNY_MAX_M}
         # neutral metadata: every row padded (context_len 0, dummy slot)
         self._fill_decode_stage([], cfg.max_num_seqs)
         pool = None
@@ -323,15 +331,23 @@ class ModelRunner:
             set_context(False, slot_mapping=d["slots"][:bs], context_lens=d["ctx"][:bs],
                         block_tables=d["tables"][:bs], is_enforce_eager=False, real_bs=bs,
                         block_size=self.block_size)
+
+            def body(bs=bs):
+                hidden = self.model(d["ids"][:bs], d["pos"][:bs])
+                if bs in self.graph_samples:  # one GPU: the head GEMM picks the tokens as it writes the logits
+                    return self.model.lm_head.local_logits_pick(hidden, d["temps"][:bs], d["rng"],
+                                                                self.tokens_dev[:bs])
+                return self.model.lm_head.local_logits(hidden)
+
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # warm-up run outside capture (workspaces, exchange epochs)
-                self.model.lm_head.local_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
+                body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=pool):  # kernels only: the logits gather of TP stays outside
-                logits = self.model.lm_head.local_logits(self.model(d["ids"][:bs], d["pos"][:bs]))
+                logits = body()
             pool = pool or graph.pool()
             self.graphs[bs] = graph
             self.graph_logits[bs] = logits
@@ -369,7 +385,11 @@ class ModelRunner:
         self.last_logits = logits  # debugging / parity hook (a reference, not a copy)
         tokens = None
         if self.rank == 0:
-            self.sampler(logits, temps, out=self.tokens_dev[:real])
+            sampled_in_graph = not is_prefill and bucket in self.graphs and bucket in self.graph_samples
+            if sampled_in_graph:
+                self.sampler.step += 1  # the replayed graph sampled with this step (see _fill_decode_stage)
+            else:
+                self.sampler(logits, temps, out=self.tokens_dev[:real])
             self.tokens_host[:real].copy_(self.tokens_dev[:real], non_blocking=True)
             torch.cuda.current_stream().synchronize()
             tokens = self.tokens_host[:real].tolist()

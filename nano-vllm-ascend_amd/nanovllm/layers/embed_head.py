@@ -51,6 +51,17 @@ class ParallelLMHead(VocabParallelEmbedding):
             x = ops.gather_last_tokens(x, context.cu_seqlens_q)
         return linear_forward(x, self.weight, None, self.weight_packed)
 
+    def can_pick(self) -> bool:
+        return self.tp_size == 1 and self.weight_packed is not None
+
+    def local_logits_pick(self, x: torch.Tensor, temperatures: torch.Tensor, rng: torch.Tensor,
+                          out_tokens: torch.Tensor) -> torch.Tensor:
+        """Decode on one GPU: the logits AND the sampler's tokens (sampler.py:9-17 on the key scheme of
+        layers/sampler.py here) from one pass over the head weight; `rng` = {seed, step} on the device."""
+        assert not get_context().is_prefill and self.can_pick()
+        logits, _ = ops.gemm_packed_pick(x, self.weight_packed, temperatures, rng, out_tokens)
+        return logits
+
     def gather(self, logits: torch.Tensor):
         """Vocabulary shards -> rank 0 (embed_head.py:62-65); None on the other ranks.  A collective of the
         process group (RCCL), kept outside captured graphs - as the reference keeps compute_logits

@@ -455,6 +455,38 @@ def sample(logits, temperatures, seed: int, step: int, out=None) -> torch.Tensor
     return out
 
 
+def gemm_packed_pick(x, w_packed, temperatures, rng, out_tokens, logits=None, candidates=None):
+    """logits = x @ w.T (as gemm_packed) and, in the same pass, the sampler's token per row
+    (as sample(logits, temperatures, seed, step) with {seed, step} = the two uint64 of the device tensor `rng`).
+    Returns (logits, tokens)."""
+    require_gpu(x, rng, out_tokens)
+    _bf16(x)
+    assert x.is_contiguous() and rng.dtype == torch.int64 and rng.numel() == 2 and out_tokens.dtype == torch.int64
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w_packed.shape[0]
+    assert w_packed.shape[1] == K and out_tokens.numel() >= M
+    assert temperatures is None or (temperatures.dtype == torch.float32 and temperatures.numel() >= M)
+    groups = lib.mi_gemm_pick_groups(M, N)
+    assert groups > 0
+    if logits is None:
+        logits = torch.empty((M, N), dtype=_BF16, device=x.device)
+    if candidates is None:
+        candidates = torch.empty((groups, M, 2), dtype=torch.int32, device=x.device)
+    assert candidates.numel() >= groups * M * 2
+    if isinstance(w_packed, Fp8Weight):
+        check(lib.mi_gemm_fp8w_packed_pick(ptr(x), ptr(w_packed.data), ptr(w_packed.scale), ptr(logits), M, N, K,
+                                           ptr(temperatures), ptr(rng), ptr(candidates), stream()),
+              "mi_gemm_fp8w_packed_pick")
+    else:
+        require_gpu(w_packed)
+        _bf16(w_packed)
+        check(lib.mi_gemm_bf16_packed_pick(ptr(x), ptr(w_packed), ptr(logits), M, N, K, ptr(temperatures),
+                                           ptr(rng), ptr(candidates), stream()), "mi_gemm_bf16_packed_pick")
+    check(lib.mi_pick_final(ptr(candidates), groups, M, ptr(out_tokens), stream()), "mi_pick_final")
+    return logits, out_tokens
+
+
 # --------------------------------------------------------------------------- mixture of experts
 def pack_expert_weights(w, out=None) -> torch.Tensor:
     """[E, N, K] expert weights -> one fragment-native slab per expert (mi_pack_weight), same shape."""

@@ -194,6 +194,32 @@ def test_generate_api_and_prefix_cache_accounting():
         llm.exit()
 
 
+def test_graph_sampler_draws_the_tokens_of_the_eager_sampler(monkeypatch):
+    """Decode graphs on one GPU end in the token choice (head GEMM pick epilogue).  With the same sampling seed
+    the temperature-sampled streams are identical to the ones the standalone sampler draws from the same logits:
+    graph sampler vs graph + separate sampler launch, mixed greedy / sampled rows, several steps."""
+    from nanovllm import LLM, SamplingParams
+
+    prompts = [[3, 4, 5, 6], list(range(10, 45)), [7] * 17]
+    sps = [SamplingParams(temperature=0.9, max_tokens=12, ignore_eos=True),
+           SamplingParams(max_tokens=12, ignore_eos=True, greedy=True),
+           SamplingParams(temperature=1.4, max_tokens=9, ignore_eos=True)]
+
+    def run(flag):
+        monkeypatch.setenv("MI355_GRAPH_SAMPLER", flag)
+        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=4, max_num_batched_tokens=256,
+                  max_model_len=128, num_kvcache_blocks=40, warmup=False, sampling_seed=1234)
+        try:
+            assert bool(llm.model_runner.graph_samples) == (flag == "1")
+            return [o["token_ids"] for o in llm.generate(prompts, sps, use_tqdm=False)]
+        finally:
+            llm.exit()
+
+    fused, separate = run("1"), run("0")
+    assert fused == separate
+    assert len(set(fused[0])) > 3  # the sampled stream is not stuck on one token
+
+
 @pytest.mark.parametrize("enforce_eager", [True, False])
 def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, enforce_eager):
     """Functional tensor-parallel run on a 1-GPU box: two rank processes share cuda:0 and talk over

@@ -659,6 +659,40 @@ def test_sample_distribution(ops, golden_layers):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("M,N,K,fp8", [(32, 151936, 1024, False), (5, 4096, 5120, False), (17, 256, 128, False),
+                                        (64, 32768, 1024, False), (32, 151936, 1024, True)])
+def test_head_gemm_pick_equals_sampler_over_logits(ops, M, N, K, fp8):
+    """The head GEMM's pick epilogue + mi_pick_final choose exactly the tokens mi_sample / mi_argmax choose from
+    the logits the same GEMM writes (greedy rows, sampled rows, ties, the last column), and those logits are
+    bit-identical to the plain packed GEMM's."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    w[N - 1] = w[3]  # a tie between column 3 and the last column for every row
+    w = w.to(DEV)
+    wp = ops.pack_weight_fp8(w) if fp8 else ops.pack_weight(w)
+    plain = ops.gemm_packed(x, wp)
+    temps = torch.zeros(M)
+    temps[1::2] = torch.linspace(0.3, 1.7, len(temps[1::2]))  # odd rows sampled, even rows greedy
+    temps = temps.to(DEV)
+    for seed, step in ((0, 1), (2**63 + 12345, 77), (9, 2**40)):
+        rng = torch.tensor([seed - 2**64 if seed >= 2**63 else seed, step], dtype=torch.int64, device=DEV)
+        out = torch.full((M,), -1, dtype=torch.int64, device=DEV)
+        logits, tokens = ops.gemm_packed_pick(x, wp, temps, rng, out)
+        assert torch.equal(logits, plain)
+        want = ops.sample(plain, temps, seed=seed, step=step)
+        assert torch.equal(tokens, want), (tokens.cpu(), want.cpu())
+    rng = torch.tensor([5, 6], dtype=torch.int64, device=DEV)
+    _, greedy = ops.gemm_packed_pick(x, wp, None, rng, torch.empty(M, dtype=torch.int64, device=DEV))
+    assert torch.equal(greedy, ops.argmax(plain))
+    # rows whose maximum sits on the duplicated columns take the lower index
+    boost = x.clone()
+    boost[0] = (w[3].float() * 40).bfloat16()
+    lg, tk = ops.gemm_packed_pick(boost, wp, None, rng, torch.empty(M, dtype=torch.int64, device=DEV))
+    assert int(tk[0]) == int(ops.argmax(lg)[0])
+    assert lg[0, 3] == lg[0, N - 1]
+
+
 # --------------------------------------------------------------------------- hipGraph capture
 def test_kernels_capture_into_hipgraph(ops):
     gen = torch.Generator().manual_seed(8)

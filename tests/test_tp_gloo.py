@@ -1,4 +1,4 @@
-"""Tensor-parallel host logic on CPU: world_size-2 `gloo` process groups.
+"""Tensor-parallel host logic on CPU: world_size 2 / 4 / 8 `gloo` process groups.
 Covers the N > 1 path without GPUs: sharded weight loaders, vocab-parallel masks, the
 row-parallel all-reduce identity (against the CPU oracle), and the rank-RPC channel."""
 import os
@@ -57,7 +57,8 @@ def _body_sharded_layers(rank, world, port):
     from nanovllm.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 
     g = torch.Generator().manual_seed(0)  # same full tensors on every rank
-    H, hq, hkv, d, inter, vocab = 256, 4, 2, 128, 512, 1024
+    # two q heads and ONE kv head per rank: at world 8 these are Qwen3-0.6B's 16 / 8 heads
+    H, hq, hkv, d, inter, vocab = 256, 2 * world, world, 128, 512, 1024
     torch.set_default_dtype(torch.bfloat16)
     qkv = QKVParallelLinear(H, d, hq, hkv)
     o = RowParallelLinear(hq * d, H)
@@ -176,9 +177,63 @@ def _body_replicated_scheduling(rank, world, port):
     assert mine.tolist() == [49, 49, 50, 2, 1, 9, 4, 7, 2]
 
 
+def _body_moe_expert_shards(rank, world, port):
+    """Qwen3MoeSparseMoeBlock under TP (qwen3_moe.py:104-115): every rank holds all experts, sharded along the
+    intermediate dimension; the router is replicated; per-rank partial expert outputs sum to the full expert."""
+    from types import SimpleNamespace
+
+    import oracle
+    from nanovllm.models.qwen3_moe import Qwen3MoeSparseMoeBlock
+
+    g = torch.Generator().manual_seed(1)
+    H, E, K, I = 128, 8, 2, 64 * world
+    cfg = SimpleNamespace(hidden_size=H, num_experts=E, num_experts_per_tok=K, moe_intermediate_size=I)
+    torch.set_default_dtype(torch.bfloat16)
+    blk = Qwen3MoeSparseMoeBlock(cfg)
+    torch.set_default_dtype(torch.float32)
+
+    def full(*shape):
+        return (torch.randn(*shape, generator=g) * 0.05).bfloat16()
+
+    wg, wu, wd, wr = full(E, I, H), full(E, I, H), full(E, H, I), full(E, H)
+    blk.gate.weight.data.copy_(wr)
+    for e in range(E):
+        ex = blk.experts[e]
+        ex.gate_up_proj.weight.weight_loader(ex.gate_up_proj.weight, wg[e], 0)
+        ex.gate_up_proj.weight.weight_loader(ex.gate_up_proj.weight, wu[e], 1)
+        ex.down_proj.weight.weight_loader(ex.down_proj.weight, wd[e])
+    il = I // world
+    assert blk.gate_up_stacked.shape == (E, 2 * il, H) and blk.down_stacked.shape == (E, H, il)
+    for e in (0, E - 1):
+        assert torch.equal(blk.gate_up_stacked[e, :il], wg[e, rank * il:(rank + 1) * il])
+        assert torch.equal(blk.gate_up_stacked[e, il:], wu[e, rank * il:(rank + 1) * il])
+        assert torch.equal(blk.down_stacked[e], wd[e][:, rank * il:(rank + 1) * il])
+    x = full(6, H) * 20
+    e = 3
+    part = oracle.linear(oracle.silu_and_mul(oracle.linear(x, blk.gate_up_stacked[e])), blk.down_stacked[e], keep_fp32=True)
+    dist.all_reduce(part)
+    want = oracle.linear(oracle.silu_and_mul(oracle.linear(x, torch.cat([wg[e], wu[e]]))), wd[e], keep_fp32=True)
+    assert (part - want).abs().max().item() < 2e-2
+    # the replicated router takes the same decisions on every rank
+    w, ids = oracle.layers.moe_route(oracle.linear(x, blk.gate.weight.data), K)
+    gathered = [torch.empty_like(ids) for _ in range(world)]
+    dist.all_gather(gathered, ids)
+    assert all(torch.equal(t, gathered[0]) for t in gathered)
+
+
 # ----------------------------------------------------------------------------- tests
 def test_tp2_sharded_layers_match_oracle():
     _run("_body_sharded_layers")
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_tp4_tp8_sharded_layers_match_oracle(world):
+    """BASELINE configs[2]/[3] degrees: at 8 ranks every rank owns exactly one kv head"""
+    _run("_body_sharded_layers", world)
+
+
+def test_tp4_moe_expert_shards():
+    _run("_body_moe_expert_shards", 4)
 
 
 def test_tp2_rpc_channel():

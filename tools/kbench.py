@@ -64,9 +64,33 @@ def prefill_attention():
           f"({flops / t / 2.5e15:.3f} of 2.5 PFLOP/s bf16)")
 
 
+def head_and_sampler():
+    """The head GEMM (151936 x 1024, 32 rows) alone, with the pick epilogue, and the standalone sampler."""
+    M, N, K = 32, 151936, 1024
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    w = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    wp = ops.pack_weight(w)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    toks = torch.empty(M, dtype=torch.int64, device=DEV)
+    rng = torch.tensor([1, 2], dtype=torch.int64, device=DEV)
+    cand = torch.empty(N // 16 * M * 2, dtype=torch.int32, device=DEV)
+    res = {}
+    byt = N * K * 2
+    for name, temps in (("greedy", torch.zeros(M, device=DEV)), ("sampled", torch.full((M,), 0.8, device=DEV))):
+        t = timeit(lambda l: ops.gemm_packed_pick(x, wp, temps, rng, toks, logits=y, candidates=cand), 1, reps=4)
+        res[f"head GEMM + pick ({name})"] = {"us": t * 1e6, "frac": byt / t / PEAK}
+        t = timeit(lambda l: ops.sample(y, temps, 1, 2, out=toks), 1, reps=4)
+        res[f"standalone sampler ({name})"] = {"us": t * 1e6}
+    t = timeit(lambda l: ops.gemm_packed(x, wp, out=y), 1, reps=4)
+    res["head GEMM"] = {"us": t * 1e6, "frac": byt / t / PEAK}
+    print(json.dumps(res, indent=1))
+
+
 def main():
     if os.environ.get("KBENCH_ONLY") == "prefill":
         return prefill_attention()
+    if os.environ.get("KBENCH_ONLY") == "head":
+        return head_and_sampler()
     B, ctx, bs, hq, hkv, L = 32, int(os.environ.get("CTX", 1024)), 16, 16, 8, 28
     res = {}
     nb_seq = (ctx + bs - 1) // bs
