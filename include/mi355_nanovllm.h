@@ -277,6 +277,16 @@ int mi_embedding(const int64_t* ids, const mi_bf16* w, mi_bf16* out,
                  int n_tokens, int hidden, int64_t vocab_start, int64_t vocab_local,
                  mi_stream stream);
 
+/* The same lookup for a decode step queued before the previous step's tokens
+ * have reached the host: row i takes its id from prev_tokens[src_rows[i]] (the
+ * previous step's sampled tokens, device memory) when src_rows[i] >= 0, from
+ * ids[i] otherwise.  Lets the engine launch step k+1 behind step k without a
+ * host round trip (model_runner.py:344-366 builds input_ids on the host). */
+int mi_embedding_from_prev(const int64_t* ids, const int32_t* src_rows,
+                           const int64_t* prev_tokens, const mi_bf16* w, mi_bf16* out,
+                           int n_tokens, int hidden, int64_t vocab_start,
+                           int64_t vocab_local, mi_stream stream);
+
 /* ParallelLMHead last-token select in prefill (embed_head.py:58-60):
  * out[s] = x[cu_seqlens_q[s+1]-1]. */
 int mi_gather_last_tokens(const mi_bf16* x, const int32_t* cu_seqlens_q,

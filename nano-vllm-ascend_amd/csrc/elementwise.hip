@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) void row_gather_kernel(const int64_t* __restri
                                                          const int32_t* __restrict__ cu,
                                                          const uint16_t* __restrict__ w,
                                                          uint16_t* __restrict__ out, int n, int hidden,
-                                                         int64_t vocab_start, int64_t vocab_local) {
+                                                         int64_t vocab_start, int64_t vocab_local,
+                                                         const int64_t* __restrict__ prev) {
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (row >= n) return;
@@ -481,7 +482,10 @@ __global__ __launch_bounds__(256) void row_gather_kernel(const int64_t* __restri
   if (FROM_CU) {
     src = (int64_t)cu[row + 1] - 1;
   } else {
-    src = ids[row] - vocab_start;
+    // prev != nullptr: `cu` holds, per row, the row of `prev` (the previous step's tokens, still on the
+    // device) to take the id from, or -1 for "use ids[row]"
+    const int from = prev ? cu[row] : -1;
+    src = (from >= 0 ? prev[from] : ids[row]) - vocab_start;
     valid = src >= 0 && src < vocab_local;
   }
   const int nvec = hidden >> 3;
@@ -777,7 +781,19 @@ extern "C" int mi_embedding(const int64_t* ids, const mi_bf16* w, mi_bf16* out, 
   if (!aligned16(w) || !aligned16(out)) return MI_EINVAL;
   if (n_tokens == 0) return MI_OK;
   hipLaunchKernelGGL((row_gather_kernel<false>), dim3((n_tokens + 3) / 4), dim3(256), 0, S(stream), ids,
-                     nullptr, w, out, n_tokens, hidden, vocab_start, vocab_local);
+                     nullptr, w, out, n_tokens, hidden, vocab_start, vocab_local, (const int64_t*)nullptr);
+  return check_launch();
+}
+
+extern "C" int mi_embedding_from_prev(const int64_t* ids, const int32_t* src_rows, const int64_t* prev_tokens,
+                                      const mi_bf16* w, mi_bf16* out, int n_tokens, int hidden,
+                                      int64_t vocab_start, int64_t vocab_local, mi_stream stream) {
+  if (!ids || !src_rows || !prev_tokens || !w || !out || n_tokens < 0 || hidden <= 0) return MI_EINVAL;
+  if (hidden % 8) return MI_EUNSUPPORTED;
+  if (!aligned16(w) || !aligned16(out)) return MI_EINVAL;
+  if (n_tokens == 0) return MI_OK;
+  hipLaunchKernelGGL((row_gather_kernel<false>), dim3((n_tokens + 3) / 4), dim3(256), 0, S(stream), ids,
+                     src_rows, w, out, n_tokens, hidden, vocab_start, vocab_local, prev_tokens);
   return check_launch();
 }
 
@@ -788,7 +804,7 @@ extern "C" int mi_gather_last_tokens(const mi_bf16* x, const int32_t* cu_seqlens
   if (!aligned16(x) || !aligned16(out)) return MI_EINVAL;
   if (n_seqs == 0) return MI_OK;
   hipLaunchKernelGGL((row_gather_kernel<true>), dim3((n_seqs + 3) / 4), dim3(256), 0, S(stream), nullptr,
-                     cu_seqlens_q, x, out, n_seqs, hidden, (int64_t)0, (int64_t)0);
+                     cu_seqlens_q, x, out, n_seqs, hidden, (int64_t)0, (int64_t)0, (const int64_t*)nullptr);
   return check_launch();
 }
 

@@ -45,6 +45,7 @@ class Config:
     device: str = "cuda"
     trust_remote_code: bool = False
     synthetic_seed: int = 0
+    decode_lookahead: bool = True  # one GPU: queue decode step k+1 before step k's tokens reach the host
     sampling_seed: int | None = None  # seed of the temperature sampler; None: drawn from os.urandom per engine
     quantization: str | None = None  # "fp8": e4m3 weights + per-row scales for the decode GEMMs (no reference counterpart)
     prefix_aware_prefill: bool = True  # skip the tokens of cache-hit prefix blocks in prefill (False: recompute, as the reference)

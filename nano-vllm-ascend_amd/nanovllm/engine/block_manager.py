@@ -132,9 +132,11 @@ class BlockManager:
         needs_block = len(seq) % self.block_size == 1
         return len(self.free_block_ids) >= int(needs_block)
 
-    def may_append(self, seq: Sequence) -> None:
+    def may_append(self, seq: Sequence, defer_seal: bool = False) -> bool:
         """Called after the previous step's append_token: len(seq) already counts the token
-        whose KV row this step writes."""
+        whose KV row this step writes.  defer_seal: the last token of the block being filled is not on the
+        host yet (engine lookahead) - leave the block open and return True; the caller seals it with
+        seal_tail() once the token has arrived."""
         table = seq.block_table
         tail = self.blocks[table[-1]]
         rem = len(seq) % self.block_size
@@ -144,11 +146,20 @@ class BlockManager:
             self._take(new_id)
             table.append(new_id)
         elif rem == 0:  # the new token fills the tail block: seal it
-            assert tail.hash == _NO_HASH
-            toks = seq.block(seq.num_blocks - 1)
-            prev = self.blocks[table[-2]].hash if len(table) > 1 else _NO_HASH
-            h = self.compute_hash(toks, prev)
-            tail.update(h, toks)
-            self.hash_to_block_id[h] = tail.block_id
+            if defer_seal:
+                return True
+            self.seal_tail(seq)
         else:
             assert tail.hash == _NO_HASH
+        return False
+
+    def seal_tail(self, seq: Sequence) -> None:
+        """Hash and register the (just filled) last block of the sequence."""
+        table = seq.block_table
+        tail = self.blocks[table[-1]]
+        assert len(seq) % self.block_size == 0 and tail.hash == _NO_HASH
+        toks = seq.block(seq.num_blocks - 1)
+        prev = self.blocks[table[-2]].hash if len(table) > 1 else _NO_HASH
+        h = self.compute_hash(toks, prev)
+        tail.update(h, toks)
+        self.hash_to_block_id[h] = tail.block_id

@@ -67,6 +67,11 @@ class LLMEngine:
             config.eos = self.tokenizer.eos_token_id
         self.scheduler = Scheduler(config)
         self.ttft: dict[int, float] = {}
+        # lookahead decode (one GPU, decode graphs that end in the token choice): the step after the one
+        # running is scheduled and queued on the device before the running one's tokens reach the host
+        self.lookahead = (config.decode_lookahead and config.tensor_parallel_size == 1
+                          and os.environ.get("MI355_LOOKAHEAD", "1") != "0")
+        self._inflight = None  # (handle, sequences, rows dropped after launch) of a queued decode step
         self._exited = False
         if kwargs.get("warmup", True):
             self.warmup_model()
@@ -117,13 +122,22 @@ class LLMEngine:
         return seq
 
     def abort_request(self, request_id: str) -> None:
+        if self._inflight is not None:  # rows of a queued step that belong to the request are dropped
+            _, seqs, dropped = self._inflight
+            for s in seqs:
+                if s.request_id == request_id and not s.is_finished:
+                    dropped.add(id(s))
         self.scheduler.abort_seq_group(request_id)
 
     def is_finished(self) -> bool:
-        return self.scheduler.is_finished()
+        return self.scheduler.is_finished() and self._inflight is None
 
     def step(self):
+        if self._inflight is not None:
+            return self._step_lookahead(*self._inflight)
         seqs, is_prefill = self.scheduler.schedule()
+        if self.lookahead and not is_prefill and seqs and self.model_runner.can_launch_decode(len(seqs)):
+            return self._step_lookahead(self.model_runner.launch_decode(seqs), seqs, set())
         token_ids = self.model_runner.call("run", seqs, is_prefill)
         if is_prefill:
             now = perf_counter()
@@ -136,6 +150,33 @@ class LLMEngine:
                    for s in seqs if s.is_finished]
         num_tokens = sum(len(s) for s in seqs) if is_prefill else -len(seqs)
         return outputs, num_tokens
+
+    def _step_lookahead(self, handle, seqs, dropped):
+        """One decode step whose launch is already queued (`handle`): decide and queue the NEXT step first
+        (Scheduler.lookahead - everything that depends on lengths only; input ids stay on the device), then
+        wait for this step's tokens and finish what depends on their values (Scheduler.resolve).  The device
+        goes from one step to the next without waiting for the host's scheduling, metadata upload and launch."""
+        runner, sched = self.model_runner, self.scheduler
+        live = [s for s in seqs if id(s) not in dropped]
+        plan = sched.lookahead(live, runner.max_launch_rows)
+        queued = None
+        if plan is not None:
+            nxt, deferred = plan
+            row_of = {id(s): i for i, s in enumerate(seqs)}
+            src = [row_of[id(s)] if s.token_pending else -1 for s in nxt]
+            queued = (runner.launch_decode(nxt, src), nxt, set())
+        tokens = runner.collect(handle)
+        if len(live) != len(seqs):
+            tokens = [t for s, t in zip(seqs, tokens) if id(s) not in dropped]
+        if plan is not None:
+            for s in sched.resolve(live, tokens, deferred, nxt):
+                queued[2].add(id(s))
+        else:
+            sched.postprocess(live, tokens)
+        self._inflight = queued
+        outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
+                   for s in live if s.is_finished]
+        return outputs, -len(live)
 
     def generate(self, prompts, sampling_params, use_tqdm: bool = True):
         pbar = None

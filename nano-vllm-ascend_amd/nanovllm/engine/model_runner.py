@@ -233,14 +233,13 @@ class ModelRunner:
         B = cfg.max_num_seqs
         W = -(-(cfg.max_model_len + 1) // self.block_size)  # a max-length prompt still decodes one token
         self.table_cols = W
-        # [ids i64 B][pos i64 B][rng u64 2][temps f32 B][ctx i32 B][slots i32 2B][tables i32 B*W]
+        # [ids i64 B][pos i64 B][rng u64 2][temps f32 B][ctx i32 B][src i32 B][slots i32 2B][tables i32 B*W]
         off, spans = 0, {}
         for name, nbytes in (("ids", 8 * B), ("pos", 8 * B), ("rng", 16), ("temps", 4 * B), ("ctx", 4 * B),
-                             ("slots", 8 * B), ("tables", 4 * B * W)):
+                             ("src", 4 * B), ("slots", 8 * B), ("tables", 4 * B * W)):
             spans[name] = (off, nbytes)
             off += (nbytes + 15) // 16 * 16
         self._stage_bytes = off
-        self.host_stage = torch.empty(off, dtype=torch.uint8, pin_memory=True)
         self.dev_stage = torch.zeros(off, dtype=torch.uint8, device=self.device)
 
         def views(buf):
@@ -248,28 +247,53 @@ class ModelRunner:
                 o, n = spans[name]
                 return buf[o:o + n].view(dtype).view(shape)
             return {"ids": v("ids", torch.int64, (B,)), "pos": v("pos", torch.int64, (B,)),
-                    "rng": v("rng", torch.int64, (2,)), "temps": v("temps", torch.float32, (B,)), "ctx": v("ctx", torch.int32, (B,)),
+                    "rng": v("rng", torch.int64, (2,)), "temps": v("temps", torch.float32, (B,)),
+                    "ctx": v("ctx", torch.int32, (B,)), "src": v("src", torch.int32, (B,)),
                     "slots": v("slots", torch.int32, (B, 2)), "tables": v("tables", torch.int32, (B, W))}
 
         self.dev = views(self.dev_stage)
-        self.host = {k: t.numpy() for k, t in views(self.host_stage).items()}
-        h = self.host
-        self.stager = batch_meta.DecodeStager(h["ids"], h["pos"], h["ctx"], h["slots"], h["tables"], h["temps"])
+        # TWO pinned staging buffers (+ token landing buffers and events), used alternately: a step queued
+        # behind the one still running (launch_decode) must not overwrite metadata whose upload has not run yet
+        self.host_stages, self.hosts, self.stagers = [], [], []
+        for _ in range(2):
+            buf = torch.empty(off, dtype=torch.uint8, pin_memory=True)
+            h = {k: t.numpy() for k, t in views(buf).items()}
+            h["src"][:] = -1
+            self.host_stages.append(buf)
+            self.hosts.append(h)
+            self.stagers.append(batch_meta.DecodeStager(h["ids"], h["pos"], h["ctx"], h["slots"], h["tables"],
+                                                        h["temps"]))
+        self._flip = 0
+        self._src_dirty = [False, False]
         self.tokens_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
-        self.tokens_host = torch.zeros(B, dtype=torch.int64, pin_memory=True)
+        self.tokens_hosts = [torch.zeros(B, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        self.step_events = [torch.cuda.Event() for _ in range(2)]
         # prefill metadata staging: ids + positions (8 B) + slots (4 B) per token, per-sequence vectors, tables
         nbytes = cfg.max_num_batched_tokens * 20 + B * (W + 4) * 4 + 4096
         self.prefill_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
         self.prefill_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
-    def _fill_decode_stage(self, seqs: list[Sequence], bucket: int):
-        """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the pinned
-        staging buffer (incremental block-table rows), then ONE async copy to the device."""
-        self.stager.fill(seqs, bucket, self.config.num_kvcache_blocks - 1)
-        rng = self.host["rng"].view(np.uint64)  # what THIS step's sampler uses (a captured graph reads it here)
+    def _fill_decode_stage(self, seqs: list[Sequence], bucket: int, src_rows=None) -> int:
+        """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the next pinned
+        staging buffer (incremental block-table rows), then ONE async copy to the device.  src_rows[i] >= 0:
+        row i's input id is the token the previous step sampled in that row (still on the device).
+        Returns the index of the staging buffer used."""
+        self._flip ^= 1
+        b = self._flip
+        self.stagers[b].fill(seqs, bucket, self.config.num_kvcache_blocks - 1)
+        h = self.hosts[b]
+        rng = h["rng"].view(np.uint64)  # what THIS step's sampler uses (a captured graph reads it here)
         rng[0] = self.sampler.seed & 0xFFFFFFFFFFFFFFFF
         rng[1] = (self.sampler.step + 1) & 0xFFFFFFFFFFFFFFFF
-        self.dev_stage.copy_(self.host_stage, non_blocking=True)
+        if src_rows is not None:
+            h["src"][:len(src_rows)] = src_rows
+            h["src"][len(src_rows):bucket] = -1
+            self._src_dirty[b] = True
+        elif self._src_dirty[b]:
+            h["src"][:] = -1
+            self._src_dirty[b] = False
+        self.dev_stage.copy_(self.host_stages[b], non_blocking=True)
+        return b
 
     # ------------------------------------------------------------------ metadata -> context
     def prepare_prefill(self, seqs: list[Sequence]):
@@ -330,7 +354,9 @@ class ModelRunner:
         for bs in reversed(graph_buckets(cfg.max_num_seqs)):
             set_context(False, slot_mapping=d["slots"][:bs], context_lens=d["ctx"][:bs],
                         block_tables=d["tables"][:bs], is_enforce_eager=False, real_bs=bs,
-                        block_size=self.block_size)
+                        block_size=self.block_size,
+                        token_src=d["src"][:bs] if bs in self.graph_samples else None,
+                        prev_tokens=self.tokens_dev if bs in self.graph_samples else None)
 
             def body(bs=bs):
                 hidden = self.model(d["ids"][:bs], d["pos"][:bs])
@@ -390,14 +416,46 @@ class ModelRunner:
                 self.sampler.step += 1  # the replayed graph sampled with this step (see _fill_decode_stage)
             else:
                 self.sampler(logits, temps, out=self.tokens_dev[:real])
-            self.tokens_host[:real].copy_(self.tokens_dev[:real], non_blocking=True)
+            landing = self.tokens_hosts[self._flip]
+            landing[:real].copy_(self.tokens_dev[:real], non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            tokens = self.tokens_host[:real].tolist()
+            tokens = landing[:real].tolist()
         self._steps_run += 1
         if self.xgmi is not None:  # every step: tokens computed behind a timed-out exchange must never be returned
             self._check_xgmi()
         reset_context()
         return tokens
+
+    # ------------------------------------------------------------------ lookahead decode (one GPU)
+    def can_launch_decode(self, n: int) -> bool:
+        """A decode step of n sequences can be queued without waiting for its tokens: its graph ends in the
+        token choice, so the step after it can read its input ids on the device."""
+        return self.world_size == 1 and self._bucket_for(n) in self.graph_samples
+
+    @property
+    def max_launch_rows(self) -> int:
+        return max(self.graph_samples, default=0)
+
+    @torch.inference_mode()
+    def launch_decode(self, seqs: list[Sequence], src_rows=None):
+        """Queue one decode step and return a handle for collect().  src_rows[i] >= 0 names the row of the
+        step queued just before whose sampled token is row i's input (not on the host yet)."""
+        real = len(seqs)
+        bucket = self._bucket_for(real)
+        assert bucket in self.graph_samples
+        b = self._fill_decode_stage(seqs, bucket, src_rows)
+        self.graphs[bucket].replay()
+        self.sampler.step += 1  # the graph sampled with this step (see _fill_decode_stage)
+        self.tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+        self.step_events[b].record()
+        self.last_logits = self.graph_logits[bucket]
+        self._steps_run += 1
+        return (b, real)
+
+    def collect(self, handle) -> list[int]:
+        b, real = handle
+        self.step_events[b].synchronize()
+        return self.tokens_hosts[b][:real].tolist()
 
     def _check_xgmi(self):
         """The exchange kernel gives up on a peer after ~1 minute instead of hanging the GPU; what it

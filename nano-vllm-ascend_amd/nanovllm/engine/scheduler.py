@@ -54,7 +54,9 @@ class Scheduler:
             budget_used += len(seq) - seq.num_cached_tokens
         return picked
 
-    def _pick_decode(self) -> list[Sequence]:
+    def _pick_decode(self, deferred: list | None = None) -> list[Sequence]:
+        """deferred (lookahead): sequences whose filled block could not be sealed because its last token is
+        still on the device are appended to it instead."""
         bm, picked = self.block_manager, []
         bs = bm.block_size
         while self.running and len(picked) < self.max_num_seqs:
@@ -74,7 +76,8 @@ class Scheduler:
                     evicted_self = True
                     break
             if not evicted_self:
-                bm.may_append(seq)
+                if bm.may_append(seq, defer_seal=deferred is not None and seq.token_pending):
+                    deferred.append(seq)
                 picked.append(seq)
         if picked:
             self.running.extendleft(reversed(picked))
@@ -97,6 +100,67 @@ class Scheduler:
         seq.status = SequenceStatus.FINISHED
         seq.finish_reason = reason
         self.block_manager.deallocate(seq)
+
+    # -- lookahead: schedule step k+1 while step k's tokens are still on the device -------------------
+    def _ends_by_length(self, seq: Sequence) -> bool:
+        """Will the token now being sampled for `seq` be its last one whatever its value?"""
+        return (seq.num_completion_tokens + 1 == seq.max_tokens) or (seq.num_tokens + 1 >= self.max_model_len)
+
+    def lookahead(self, inflight: list[Sequence], row_limit: int) -> tuple[list[Sequence], list[Sequence]] | None:
+        """The decode step that follows the one in flight over `inflight` (its live sequences), decided
+        before that step's tokens are known: every decision of postprocess() + schedule() that depends only
+        on LENGTHS is taken now (sequences ending by length leave and free their blocks, blocks are opened),
+        what depends on token VALUES is left for resolve() (EOS, sealing a filled block).  Returns
+        (sequences of the next step, sequences with a seal outstanding), or None when the next step must be
+        decided synchronously: a prompt is waiting (prefill has priority), a preemption would be needed, or
+        the step would have more than row_limit rows (what the runner can queue)."""
+        if self.waiting or not inflight:
+            return None
+        bs, flying = self.block_manager.block_size, {id(s) for s in inflight}
+        staying, need = 0, 0
+        for seq in self.running:
+            if staying == self.max_num_seqs:
+                break
+            n = seq.num_tokens
+            if id(seq) in flying:
+                if self._ends_by_length(seq):
+                    continue
+                n += 1
+            staying += 1
+            need += n % bs == 1
+        if staying == 0 or staying > row_limit or need > len(self.block_manager.free_block_ids):
+            return None
+        for seq in inflight:  # the length half of postprocess(), in its order
+            ends = self._ends_by_length(seq)
+            seq.append_pending()
+            if ends:
+                self.free_seq(seq, FinishReason.LENGTH)
+                self.running.remove(seq)
+        deferred: list[Sequence] = []
+        picked = self._pick_decode(deferred)
+        return picked, deferred
+
+    def resolve(self, seqs: list[Sequence], token_ids: list[int], deferred: list[Sequence],
+                queued: list[Sequence] | None) -> list[Sequence]:
+        """The value half of postprocess() for a step whose successor `queued` is already in flight: fill in
+        the tokens, end sequences on EOS, seal the blocks lookahead() left open.  Returns the sequences that
+        ended on EOS although the queued step still computes a row for them (the caller drops that row)."""
+        eos, dropped = self.eos, []
+        in_queue = {id(s) for s in queued} if queued else ()
+        for seq, tok in zip(seqs, token_ids):
+            seq.resolve_pending(tok)
+            if tok == eos and not seq.ignore_eos:
+                if seq.is_finished:  # had already left by length: only the reason changes
+                    seq.finish_reason = FinishReason.EOS
+                    continue
+                self.free_seq(seq, FinishReason.EOS)
+                self.running.remove(seq)
+                if id(seq) in in_queue:
+                    dropped.append(seq)
+        for seq in deferred:
+            if not seq.is_finished:
+                self.block_manager.seal_tail(seq)
+        return dropped
 
     def postprocess(self, seqs: list[Sequence], token_ids: list[int]) -> None:
         eos, max_model_len = self.eos, self.max_model_len

@@ -31,7 +31,8 @@ class Sequence:
 
     __slots__ = ("block_size", "seq_id", "request_id", "status", "token_ids", "last_token", "num_tokens",
                  "num_prompt_tokens", "num_cached_tokens", "block_table", "temperature", "max_tokens",
-                 "ignore_eos", "greedy", "finish_reason", "arrival_time", "first_token_time", "table_gen", "num_prefix_tokens")
+                 "ignore_eos", "greedy", "finish_reason", "arrival_time", "first_token_time", "table_gen", "num_prefix_tokens",
+                 "token_pending")
 
     def __init__(self, token_ids: list[int], sampling_params: SamplingParams | None = None,
                  request_id: str | None = None, block_size: int = 256, **_ignored_multimodal):
@@ -53,6 +54,7 @@ class Sequence:
         self.arrival_time = 0.0
         self.first_token_time = 0.0
         self.num_prefix_tokens = 0  # leading tokens whose KV rows the current block table already holds (cache hits)
+        self.token_pending = False  # the last entry of token_ids stands for a token still on the device (lookahead)
         self.table_gen = 0  # bumped every time the block table is rebuilt (allocate after a preemption)
 
     # -- container protocol ------------------------------------------------------------------
@@ -105,6 +107,18 @@ class Sequence:
         self.last_token = token_id
         self.num_tokens += 1
 
+    def append_pending(self) -> None:
+        """Count a token that has been sampled on the device but has not reached the host (engine lookahead)."""
+        assert not self.token_pending
+        self.append_token(0)
+        self.token_pending = True
+
+    def resolve_pending(self, token_id: int) -> None:
+        assert self.token_pending
+        self.token_ids[-1] = token_id
+        self.last_token = token_id
+        self.token_pending = False
+
     # -- rank-RPC wire format -------------------------------------------------------------------
     # header: [seq_id, num_tokens, num_prompt_tokens, num_cached_tokens, block_size, n_blocks,
     #          n_tokens_sent, temperature_bits, greedy, table_gen, num_prefix_tokens]; then block ids; then the token ids the
@@ -141,4 +155,5 @@ class Sequence:
         s.table_gen, s.num_prefix_tokens = table_gen, num_prefix
         s.max_tokens, s.ignore_eos, s.finish_reason = 0, True, None
         s.arrival_time = s.first_token_time = 0.0
+        s.token_pending = False
         return s, pos

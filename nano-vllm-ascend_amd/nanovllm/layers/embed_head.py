@@ -31,7 +31,11 @@ class VocabParallelEmbedding(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """embed_head.py:34-42: the kernel applies the vocab-range mask (rows owned by other
         ranks come out zero), then the partial embeddings are summed over ranks."""
-        y = ops.embedding(x, self.weight, self.vocab_start_idx)
+        ctx = get_context()
+        if ctx.token_src is not None and not ctx.is_prefill:
+            y = ops.embedding_from_prev(x, ctx.token_src, ctx.prev_tokens, self.weight, self.vocab_start_idx)
+        else:
+            y = ops.embedding(x, self.weight, self.vocab_start_idx)
         return all_reduce_sum(y)
 
 

@@ -415,6 +415,21 @@ def embedding(ids, w, vocab_start: int = 0, out=None) -> torch.Tensor:
     return out
 
 
+def embedding_from_prev(ids, src_rows, prev_tokens, w, vocab_start: int = 0, out=None) -> torch.Tensor:
+    """embedding() whose row i reads its id from prev_tokens[src_rows[i]] when src_rows[i] >= 0 (the previous
+    step's sampled tokens, still on the device), from ids[i] otherwise."""
+    require_gpu(ids, src_rows, prev_tokens, w)
+    _bf16(w)
+    assert ids.dtype == torch.int64 and prev_tokens.dtype == torch.int64 and src_rows.dtype == torch.int32
+    assert ids.is_contiguous() and w.is_contiguous() and src_rows.numel() >= ids.numel()
+    n, hidden = ids.numel(), w.shape[1]
+    if out is None:
+        out = torch.empty((n, hidden), dtype=_BF16, device=w.device)
+    check(lib.mi_embedding_from_prev(ptr(ids), ptr(src_rows), ptr(prev_tokens), ptr(w), ptr(out), n, hidden,
+                                     vocab_start, w.shape[0], stream()), "mi_embedding_from_prev")
+    return out
+
+
 def gather_last_tokens(x, cu_seqlens_q) -> torch.Tensor:
     require_gpu(x, cu_seqlens_q)
     _bf16(x)

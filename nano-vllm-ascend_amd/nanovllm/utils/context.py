@@ -2,11 +2,14 @@
 
 The reference keeps one module-level record that `Attention.forward` and `ParallelLMHead.forward`
 read (nanovllm/utils/context.py:5-37); layers written against it expect the attribute names below
-and the three accessor functions, so those are the contract kept here.  One field is added:
+and the three accessor functions, so those are the contract kept here.  Added fields:
 
   kv_lens  [n_seqs] int32 - tokens of each sequence present in the KV cache during prefill.  Equal to
            the query lengths in the reference (it recomputes cached prefixes, model_runner.py:248-249);
            larger when prefix-aware prefill skips cache-hit blocks.
+
+  token_src / prev_tokens - decode steps queued behind a step whose tokens have not reached the host yet
+           read their input ids on the device (engine lookahead; see ModelRunner.launch_decode).
 
 The slot mapping is flat int32 [T] in prefill (model_runner.py:263-270) and [B, 2] = [block, offset]
 in decode (:301,353); consumers tell them apart by `slot_mapping.dim()`.
@@ -27,6 +30,8 @@ _DEFAULTS = {
     "real_bs": -1,
     "block_size": 256,
     "kv_lens": None,
+    "token_src": None,         # int32 [B]: row of prev_tokens a decode row takes its input id from, or -1
+    "prev_tokens": None,       # int64 [>= B]: the previous step's sampled tokens, device-resident
 }
 
 

@@ -517,3 +517,146 @@ def test_serving_harness_metrics_against_scripted_engine():
     assert abs(np.diff(a).mean() - 0.125) < 0.01 and (np.diff(a) > 0).all()
     b = sb.arrival_times(4000, 8.0, rng, reference_style=True)
     assert (np.diff(b) == 0).mean() > 0.8
+
+
+# ----------------------------------------------------------------------------- lookahead decode
+class _ScriptedRunner:
+    """Stands in for ModelRunner on the host: a 'model' whose next token is a hash of (input id, position,
+    first prompt token), evaluated at LAUNCH time from what the device would see - the previous step's token
+    buffer for rows that name one (src >= 0), the host's last_token otherwise.  Records every decode step."""
+    VOCAB = 23
+
+    def __init__(self, max_rows=8):
+        self.max_launch_rows = max_rows
+        self.device_tokens = []  # tokens of the step launched last ("tokens_dev")
+        self.steps = []          # (seq ids, positions, input ids, block tables) per decode step
+
+    @classmethod
+    def _next(cls, seq, input_id, position):
+        return (input_id * 7 + position * 3 + seq.token_ids[0]) % cls.VOCAB
+
+    def can_launch_decode(self, n):
+        return 0 < n <= self.max_launch_rows
+
+    def _decode(self, seqs, src):
+        ids = [self.device_tokens[r] if r >= 0 else s.last_token for s, r in zip(seqs, src)]
+        self.steps.append(([s.seq_id for s in seqs], [s.num_tokens - 1 for s in seqs], ids,
+                           [list(s.block_table) for s in seqs]))
+        self.device_tokens = [self._next(s, i, s.num_tokens - 1) for s, i in zip(seqs, ids)]
+        return list(self.device_tokens)
+
+    def launch_decode(self, seqs, src_rows=None):
+        return self._decode(seqs, src_rows if src_rows is not None else [-1] * len(seqs))
+
+    def collect(self, handle):
+        return handle
+
+    def call(self, name, seqs, is_prefill):
+        assert name == "run"
+        if is_prefill:
+            self.device_tokens = [self._next(s, s.last_token, s.num_tokens - 1) for s in seqs]
+            return list(self.device_tokens)
+        return self._decode(seqs, [-1] * len(seqs))
+
+
+def _scripted_engine(lookahead, **cfg):
+    from nanovllm.engine.llm_engine import LLMEngine
+
+    eng = object.__new__(LLMEngine)
+    eng.scheduler = sched(**cfg)
+    eng.model_runner = _ScriptedRunner()
+    eng.block_size = eng.scheduler.block_manager.block_size
+    eng.tokenizer, eng.ttft, eng.lookahead, eng._inflight = None, {}, lookahead, None
+    return eng
+
+
+def _drain(eng, arrivals=()):
+    """run to completion; arrivals = [(step index, prompt, SamplingParams)] added before that step"""
+    done, step = {}, 0
+    pending = sorted(arrivals, key=lambda a: a[0])
+    while not eng.is_finished() or pending:
+        while pending and pending[0][0] <= step:
+            _, prompt, sp = pending.pop(0)
+            eng.add_request(prompt, sp)
+        for seq_id, toks, _, _ in eng.step()[0]:
+            assert seq_id not in done
+            done[seq_id] = list(toks)
+        step += 1
+    return done
+
+
+@pytest.mark.parametrize("eos", [-1, 5])
+def test_lookahead_decode_reproduces_the_synchronous_engine(eos):
+    """Engine lookahead (step k+1 scheduled and launched before step k's tokens are on the host) against the
+    plain loop on a scripted model: same tokens for every request; without EOS endings also the same decode
+    steps (sequences, positions, input ids, block tables) and the same allocator state - block openings,
+    length endings, deferred block seals and the free list all land where the synchronous order puts them."""
+    rng = np.random.default_rng(3)
+    prompts = [[int(t) for t in rng.integers(0, 23, n)] for n in (5, 9, 4, 13, 7, 3)]
+    lens = (9, 17, 6, 12, 30, 8)
+    Sequence.counter = __import__("itertools").count()
+    outs, engines = [], []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=eos, num_kvcache_blocks=40, max_num_batched_tokens=64, max_num_seqs=4)
+        for p, n in zip(prompts[:4], lens):
+            eng.add_request(p, SamplingParams(max_tokens=n, ignore_eos=False, temperature=1.0))
+        late = [(7, prompts[4], SamplingParams(max_tokens=lens[4], temperature=1.0)),
+                (40, prompts[5], SamplingParams(max_tokens=lens[5], temperature=1.0))]
+        outs.append(_drain(eng, late))
+        engines.append(eng)
+    sync, look = outs
+    assert sorted(sync) == sorted(look) == list(range(6))
+    assert sync == look
+    if eos < 0:
+        assert all(len(sync[i]) == lens[i] for i in range(6))
+    else:
+        assert any(len(sync[i]) < lens[i] for i in range(6))  # the scripted model does hit EOS
+    a, b = (e.scheduler.block_manager for e in engines)
+    assert not a.used_block_ids and not b.used_block_ids
+    # arrivals land one decode step later under lookahead (that step was already queued): steps agree
+    # exactly up to the first late arrival; afterwards the per-request streams above are the contract
+    # (with EOS endings the queued step still carries a row for a sequence that has just ended)
+    sa, sb_ = engines[0].model_runner.steps, engines[1].model_runner.steps
+    if eos < 0:  # ... and the same registrations of sealed blocks (hash -> tokens), whatever the step they happened in
+        assert sa[:5] == sb_[:5]
+        seal = lambda bm: {h: tuple(bm.blocks[i].token_ids) for h, i in bm.hash_to_block_id.items()  # noqa: E731
+                           if bm.blocks[i].hash == h}
+        assert set(seal(a)) == set(seal(b))
+
+
+def test_lookahead_without_arrivals_is_step_for_step_identical():
+    """No arrivals, no EOS: every decode step of the lookahead engine equals the synchronous engine's, and
+    the allocators end in the same state (free-list order included)."""
+    rng = np.random.default_rng(5)
+    prompts = [[int(t) for t in rng.integers(0, 23, n)] for n in (6, 11, 3, 8)]
+    engines = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=-1, num_kvcache_blocks=30, max_num_batched_tokens=64)
+        for p, n in zip(prompts, (14, 5, 22, 9)):
+            eng.add_request(p, SamplingParams(max_tokens=n, ignore_eos=True, temperature=1.0))
+        out = _drain(eng)
+        engines.append((eng, out))
+    (e0, o0), (e1, o1) = engines
+    assert o0 == o1
+    assert e0.model_runner.steps == e1.model_runner.steps
+    b0, b1 = e0.scheduler.block_manager, e1.scheduler.block_manager
+    assert list(b0.free_block_ids) == list(b1.free_block_ids)
+    assert b0.hash_to_block_id == b1.hash_to_block_id
+    assert [(b.hash, b.token_ids) for b in b0.blocks] == [(b.hash, b.token_ids) for b in b1.blocks]
+
+
+def test_lookahead_falls_back_when_a_preemption_is_needed():
+    """Too few blocks for every sequence to open its next block: the lookahead declines (None), the step is
+    scheduled synchronously with the reference's preemption, and the streams still equal the plain loop's."""
+    prompts = [[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]]
+    outs = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=-1, num_kvcache_blocks=6, max_num_batched_tokens=64)  # 5 usable blocks
+        for p in prompts:
+            eng.add_request(p, SamplingParams(max_tokens=7, ignore_eos=True, temperature=1.0))
+        outs.append((_drain(eng), eng.model_runner.steps))
+    assert outs[0][0] == outs[1][0] and all(len(v) == 7 for v in outs[0][0].values())
+    assert outs[0][1] == outs[1][1]  # preemption and re-prefill happen at the same steps
