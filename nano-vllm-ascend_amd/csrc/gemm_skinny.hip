@@ -113,6 +113,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // EPI_PICK: the sampler's per-row inputs are fetched now, under the weight stream, not at the tail
+  float pk_temp = 0.f;
+  uint64_t pk_seed = 0, pk_step = 0;
+  if (EPI == EPI_PICK) {
+    const int row0 = 16 * (((int)threadIdx.x >> 6) % MT) + (lane & 15);  // the row of this thread's first item
+    if (pk.temperatures && row0 < M) pk_temp = pk.temperatures[row0];
+    pk_seed = pk.rng[0];
+    pk_step = pk.rng[1];
+  }
+
   // per-lane weight pointers.  fp8: [N/16][K/64][64 lanes][16 bytes] - a lane's 16 bytes are the A
   // fragments of TWO consecutive 32-deep k-steps (8 e4m3 values each), dequantised to bf16 in registers
   // (exact: e4m3 fits bf16); the per-row scale is applied to the fp32 sums in the epilogue.
@@ -243,10 +253,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
         o[1] = pack_bf(s[2], s[3]);
         *reinterpret_cast<u32x2*>(y + (int64_t)row * N + col) = o;
         if (EPI == EPI_PICK) {  // keys of the ROUNDED logits, as a sampler reading y would form them
-          const float tmp = pk.temperatures ? pk.temperatures[row] : 0.f;
+          const float tmp = item == (int)threadIdx.x ? pk_temp : (pk.temperatures ? pk.temperatures[row] : 0.f);
           const bool noisy = tmp > 0.f;
           const float inv_t = noisy ? 1.0f / tmp : 1.0f;
-          const uint64_t rkey = sample_row_key(pk.rng[0], pk.rng[1], row);
+          const uint64_t rkey = sample_row_key(pk_seed, pk_step, row);
           const float v[4] = {lo_bf(o[0]), hi_bf(o[0]), lo_bf(o[1]), hi_bf(o[1])};
           float best = -INFINITY;
           int best_c = 0x7fffffff;
@@ -556,6 +566,9 @@ static int check_gemm(const void* x, const void* w, const void* y, int M, int N,
 
 using namespace mi;
 
+static bool pick_two_tiles(int M, int N) { return N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32; }
+// (four row tiles per workgroup measured slower for the head: 70.6 vs 64.0 us at 151936 x 1024, 32 rows)
+
 extern "C" int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y, int M,
                                    int N, int K, mi_stream stream) {
   int rc = check_gemm(x, w, y, M, N, K);
@@ -591,8 +604,6 @@ extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, co
 }
 
 // head GEMM with the pick epilogue: the same workgroup geometry as mi_gemm_bf16_packed for this (M, N)
-static bool pick_two_tiles(int M, int N) { return N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32; }
-
 extern "C" int mi_gemm_pick_groups(int M, int N) {
   if (M <= 0 || N <= 0 || N % 16) return 0;
   return pick_two_tiles(M, N) ? N / 32 : N / 16;
