@@ -1,0 +1,510 @@
+// Skinny-GEMM kernels and their launch selection, shared by gemm_skinny.hip (the projection entry points)
+// and gemm_pick.hip (the head GEMM with the sampler's pick epilogue): two translation units so that the
+// template instantiations compile in parallel.  See gemm_skinny.hip for the design notes.
+#pragma once
+#include <stdlib.h>
+
+#include "mi_common.hpp"
+
+namespace mi {
+
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2, EPI_PICK = 3 };
+
+// EPI_PICK (the head GEMM of a decode step): besides the bf16 logits every workgroup reports, per activation
+// row, the best sampling key among its columns - the logit itself for greedy rows, logit / T + Gumbel noise
+// for sampled ones (the keys of mi_argmax / mi_sample, bit for bit) - so that the token choice needs one
+// small launch over [workgroups][rows] candidates (mi_pick_final) instead of a second pass over the logits.
+struct PickArgs {
+  const float* temperatures;  // [M]; nullptr or <= 0: greedy
+  const uint64_t* rng;        // {seed, step} in device memory (a captured graph reads the current step)
+  uint2* cand;                // [gridDim.x][M] {key bits, column}
+};
+
+// B fragments (the activations x^T) of one wave for STEPS k-steps starting at xk = x + k0:
+//   bfrag[m][s] of lane (g, c) = x[16 m + c][k0 + 32 s + 8 g .. +7]   (rows >= M clamped to M - 1).
+// Read straight from memory a fragment load touches sixteen rows with 64 bytes each - sixteen cache
+// lines per instruction, half of each used - and costs the CU's address path as much as the weight
+// stream itself (tools/gemm_exp.py: 4.95 us per qkv launch, 4.16 without any x traffic, 4.23 with x
+// fetched in full lines).  So, for pairs of k-steps, the wave fetches its [16 MT rows][64 k] block as
+// whole 128-byte lines (8 lanes per row, 8 rows per instruction), parks it in its private LDS slab
+// (16-byte units XOR-swizzled by row) and reads the fragments back with ds_read_b128.  LDS operations of
+// one wave execute in order, so the slab needs no barrier and is reused for every pair.
+template <int MT, int STEPS>
+__device__ __forceinline__ void issue_x_lines(const uint16_t* __restrict__ x, int M, int K, int k0, int lane,
+                                              u32x4 (&stage)[(STEPS + 1) / 2][MT * 2]) {
+#pragma unroll
+  for (int sp = 0; sp < STEPS / 2; ++sp)
+#pragma unroll
+    for (int i = 0; i < MT * 2; ++i) {
+      const int row = i * 8 + (lane >> 3), c = lane & 7;
+      stage[sp][i] = *reinterpret_cast<const u32x4*>(x + (int64_t)min(row, M - 1) * K + k0 + 64 * sp + 8 * c);
+    }
+}
+template <int MT, int STEPS>
+__device__ __forceinline__ void x_lines_to_frags(const u32x4 (&stage)[(STEPS + 1) / 2][MT * 2], uint16_t* slab, int lane,
+                                                 u32x4 (&bfrag)[MT][STEPS]) {
+  const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+  for (int sp = 0; sp < STEPS / 2; ++sp) {
+#pragma unroll
+    for (int i = 0; i < MT * 2; ++i) {
+      const int row = i * 8 + (lane >> 3), c = lane & 7;
+      *reinterpret_cast<u32x4*>(slab + (row * 8 + (c ^ (row & 7))) * 8) = stage[sp][i];
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int row = 16 * m + r, c = 4 * h2 + g;
+        bfrag[m][2 * sp + h2] = *reinterpret_cast<const u32x4*>(slab + (row * 8 + (c ^ (row & 7))) * 8);
+      }
+  }
+}
+// bytes of one wave's slab: [16 MT rows][64 k] bf16
+constexpr int x_slab_bytes(int MT) { return MT * 16 * 64 * 2; }
+
+// WF: weight format - 0 row-major bf16, 1 fragment-native bf16, 2 fragment-native fp8 (e4m3) + per-row scale
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
+    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K,
+    PickArgs pk) {
+  // [WAVES][RT*MT][256] fp32 K-slice sums; before that, each wave's slot doubles as its x slab
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  constexpr int SLOT = RT * MT * 1024 > x_slab_bytes(MT) ? RT * MT * 1024 : x_slab_bytes(MT);  // bytes per wave
+  constexpr bool LINES = STEPS % 2 == 0;  // x in whole cache lines through LDS
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  uint16_t* slab = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(red) + wave * SLOT);
+  const int ksplit = gridDim.y;
+  const int kslice = K / (ksplit * WAVES);  // multiple of 32 * STEPS (checked on the host)
+  const int kbeg = (blockIdx.y * WAVES + wave) * kslice;
+  const int ktiles = K >> 5;
+
+  // row tiles of this workgroup
+  int tile[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    tile[t] = EPI == EPI_SILU ? (int)blockIdx.x + t * (N >> 5) : (int)blockIdx.x * RT + t;
+
+  f32x4 acc[RT][MT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // EPI_PICK: the sampler's per-row inputs are fetched now, under the weight stream, not at the tail
+  float pk_temp = 0.f;
+  uint64_t pk_seed = 0, pk_step = 0;
+  if (EPI == EPI_PICK) {
+    const int row0 = 16 * (((int)threadIdx.x >> 6) % MT) + (lane & 15);  // the row of this thread's first item
+    if (pk.temperatures && row0 < M) pk_temp = pk.temperatures[row0];
+    pk_seed = pk.rng[0];
+    pk_step = pk.rng[1];
+  }
+
+  // per-lane weight pointers.  fp8: [N/16][K/64][64 lanes][16 bytes] - a lane's 16 bytes are the A
+  // fragments of TWO consecutive 32-deep k-steps (8 e4m3 values each), dequantised to bf16 in registers
+  // (exact: e4m3 fits bf16); the per-row scale is applied to the fp32 sums in the epilogue.
+  const uint16_t* wp[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    wp[t] = WF == 2   ? w + (((int64_t)tile[t] * (K >> 6) + (kbeg >> 6)) * 1024 + lane * 16) / 2
+            : WF == 1 ? w + ((int64_t)tile[t] * ktiles + (kbeg >> 5)) * 512 + lane * 8
+                      : w + (int64_t)(tile[t] * 16 + r) * K + kbeg + 8 * g;
+  constexpr int WSTEP = WF == 1 ? 512 : 32;  // elements between consecutive k-steps (bf16 formats)
+  // B fragment of column tile m: lane (g, c) <- x[16 m + c][k + 32 s + 8 g .. +8].  Rows >= M are
+  // clamped to row M-1: MFMA output columns are independent, the duplicates are never stored.
+  const uint16_t* xp[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) xp[m] = x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 8 * g;
+
+  for (int k = 0; k < kslice; k += 32 * STEPS) {
+    u32x4 a[RT][STEPS], bfrag[MT][STEPS];
+    // every load of the block is issued before the first MFMA: no branches, no waits in between
+    if (WF == 2) {
+      static_assert(WF != 2 || STEPS % 2 == 0, "an fp8 fragment load covers two k-steps");
+      u32x4 raw[RT][(STEPS + 1) / 2];
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS / 2; ++s2)
+          raw[t][s2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 6) + s2) * 512));
+      u32x4 stage[(STEPS + 1) / 2][MT * 2];
+      issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+      x_lines_to_frags<MT, STEPS>(stage, slab, lane, bfrag);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          const uint32_t lo = raw[t][s >> 1][2 * (s & 1)], hi = raw[t][s >> 1][2 * (s & 1) + 1];
+          const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+          const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+          a[t][s] = u32x4{pack_bf(f0[0], f0[1]), pack_bf(f1[0], f1[1]), pack_bf(f2[0], f2[1]), pack_bf(f3[0], f3[1])};
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+          a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 5) + s) * WSTEP));
+      if (LINES) {
+        u32x4 stage[(STEPS + 1) / 2][MT * 2];
+        issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+        x_lines_to_frags<MT, STEPS>(stage, slab, lane, bfrag);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[t][s]), as_frag(bfrag[m][s]),
+                                                              acc[t][m], 0, 0, 0);
+  }
+
+  // C fragment: lane (g, c) holds y[m-tile col c][16 tile + 4 g + i], i = 0..3
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(red) + wave * SLOT + ((t * MT + m) * 64 + lane) * 16) = acc[t][m];
+  __syncthreads();
+  // each (row tile, m-tile, lane) result is finished by one thread, summing K-slices in wave order
+  constexpr int ITEMS = (EPI == EPI_SILU ? 1 : RT) * MT * 64;
+  __shared__ float pick_key[EPI == EPI_PICK ? MT * 16 : 1][RT * 4];
+  __shared__ int pick_col[EPI == EPI_PICK ? MT * 16 : 1][RT * 4];
+  for (int item = threadIdx.x; item < ITEMS; item += WAVES * 64) {
+    const int l = item & 63, m = (item >> 6) % MT, t = (item >> 6) / MT;
+    auto total = [&](int tt) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(red) + ((tt * MT + m) * 64 + l) * 16);
+#pragma unroll
+      for (int wv = 1; wv < WAVES; ++wv) {
+        const f32x4 u =
+            *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(red) + wv * SLOT + ((tt * MT + m) * 64 + l) * 16);
+        s += u;
+      }
+      if (WF == 2) s *= *reinterpret_cast<const f32x4*>(scale + tile[tt] * 16 + 4 * (l >> 4));  // per weight row
+      return s;
+    };
+    const int row = 16 * m + (l & 15);
+    if (row >= M) {
+      if (EPI == EPI_PICK) {
+        pick_key[row][t * 4 + (l >> 4)] = -INFINITY;
+        pick_col[row][t * 4 + (l >> 4)] = 0x7fffffff;
+      }
+      continue;
+    }
+    if (EPI == EPI_SILU) {
+      const f32x4 gt = total(0), up = total(1);
+      const int col = (int)blockIdx.x * 16 + 4 * (l >> 4);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gb = rbf(gt[i]);  // the gate_up GEMM output, rounded to bf16 as the unfused path
+        const float sb = rbf(gb / (1.0f + expf(-gb)));
+        o[i] = sb * rbf(up[i]);
+      }
+      u32x2 ov;
+      ov[0] = pack_bf(o[0], o[1]);
+      ov[1] = pack_bf(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(y + (int64_t)row * (N >> 1) + col) = ov;
+    } else {
+      f32x4 s = total(t);
+      const int col = tile[0] * 16 + t * 16 + 4 * (l >> 4);
+      if (EPI == EPI_PARTIAL) {
+        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.y * M + row) * N + col) = s;
+      } else {
+        if (BIAS) {
+          const u32x2 bw = *reinterpret_cast<const u32x2*>(bias + col);
+          s[0] += lo_bf(bw[0]);
+          s[1] += hi_bf(bw[0]);
+          s[2] += lo_bf(bw[1]);
+          s[3] += hi_bf(bw[1]);
+        }
+        u32x2 o;
+        o[0] = pack_bf(s[0], s[1]);
+        o[1] = pack_bf(s[2], s[3]);
+        *reinterpret_cast<u32x2*>(y + (int64_t)row * N + col) = o;
+        if (EPI == EPI_PICK) {  // keys of the ROUNDED logits, as a sampler reading y would form them
+          const float tmp = item == (int)threadIdx.x ? pk_temp : (pk.temperatures ? pk.temperatures[row] : 0.f);
+          const bool noisy = tmp > 0.f;
+          const float inv_t = noisy ? 1.0f / tmp : 1.0f;
+          const uint64_t rkey = sample_row_key(pk_seed, pk_step, row);
+          const float v[4] = {lo_bf(o[0]), hi_bf(o[0]), lo_bf(o[1]), hi_bf(o[1])};
+          float best = -INFINITY;
+          int best_c = 0x7fffffff;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float key = noisy ? gumbel_key(v[i], inv_t, rkey, col + i) : v[i];
+            if (key > best) {  // ascending columns: the first of equal keys stays
+              best = key;
+              best_c = col + i;
+            }
+          }
+          pick_key[row][t * 4 + (l >> 4)] = best;
+          pick_col[row][t * 4 + (l >> 4)] = best_c;
+        }
+      }
+    }
+  }
+  if (EPI == EPI_PICK) {
+    __syncthreads();
+    if ((int)threadIdx.x < M) {
+      const int row = threadIdx.x;
+      float best = pick_key[row][0];
+      int best_c = pick_col[row][0];
+#pragma unroll
+      for (int j = 1; j < RT * 4; ++j) {
+        const float k2 = pick_key[row][j];
+        const int c2 = pick_col[row][j];
+        if (k2 > best || (k2 == best && c2 < best_c)) {
+          best = k2;
+          best_c = c2;
+        }
+      }
+      pk.cand[(int64_t)blockIdx.x * M + row] = uint2{__float_as_uint(best), (uint32_t)best_c};
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Row-parallel projections (o_proj, down_proj: N = hidden is small, K large): complete bf16 rows from
+// every workgroup, no split-K partials - the consumer (the next GEMM's add + RMSNorm prologue) then
+// re-reads 2 bytes per element instead of 4 x ksplit.
+//   A workgroup owns FOUR output features and the whole K: N / 4 workgroups (256 for hidden 1024) each
+//   stream 8 K bytes of weights - all CUs pull from HBM, which a 16-feature tile (N / 16 = 64
+//   workgroups) cannot do for these shapes and which split-K only buys with fp32 partials.
+//   Weights are packed [N/4][K/32][4 k-groups][4 features][8]: a wave's K-slice is one contiguous run,
+//   the A fragment row r of v_mfma_f32_16x16x32_bf16 carries feature r % 4 (rows 4..15 are duplicates
+//   whose results are never read), the B fragments are the rows of x as in gemm_skinny_kernel, so lane
+//   (g = 0, c) ends up with features 0..3 of activation row c: one 8-byte store per row.
+//   The WAVES K-slices are summed through LDS in wave order (deterministic) and rounded to bf16 once.
+// ---------------------------------------------------------------------------------------------------
+template <int MT, int WAVES, int STEPS>
+__global__ __launch_bounds__(WAVES * 64) void gemm_rows4_kernel(const uint16_t* __restrict__ x,
+                                                                const uint16_t* __restrict__ w4,
+                                                                uint16_t* __restrict__ y, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float red[WAVES][MT][16][4];
+  __shared__ __attribute__((aligned(16))) uint16_t slabs[WAVES][STEPS % 2 == 0 ? MT * 16 * 64 : 8];  // x in whole lines
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int kslice = K / WAVES;  // multiple of 32 * STEPS (checked on the host)
+  const int kbeg = wave * kslice;
+  const uint16_t* wp = w4 + ((int64_t)blockIdx.x * (K >> 5) + (kbeg >> 5)) * 128 + (g * 4 + (r & 3)) * 8;
+  const uint16_t* xp[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) xp[m] = x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 8 * g;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kslice; k += 32 * STEPS) {
+    u32x4 a[STEPS], bfrag[MT][STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+      a[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((k >> 5) + s) * 128));
+    if (STEPS % 2 == 0) {
+      u32x4 stage[(STEPS + 1) / 2][MT * 2];
+      issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+      x_lines_to_frags<MT, STEPS>(stage, &slabs[wave][0], lane, bfrag);
+    } else {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) bfrag[m][s] = *reinterpret_cast<const u32x4*>(xp[m] + k + 32 * s);
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[s]), as_frag(bfrag[m][s]), acc[m], 0, 0, 0);
+  }
+  // C fragment: lane (g, c) holds rows 4g .. 4g+3 (features) of column c (activation row): g == 0 is real
+  if (g == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(&red[wave][m][r][0]) = acc[m];
+  }
+  __syncthreads();
+  if (threadIdx.x < MT * 16) {
+    const int m = threadIdx.x >> 4, c = threadIdx.x & 15;
+    f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][m][c][0]);
+#pragma unroll
+    for (int wv = 1; wv < WAVES; ++wv) t += *reinterpret_cast<const f32x4*>(&red[wv][m][c][0]);
+    const int row = 16 * m + c;
+    if (row < M)
+      *reinterpret_cast<u32x2*>(y + (int64_t)row * N + 4 * blockIdx.x) = u32x2{pack_bf(t[0], t[1]), pack_bf(t[2], t[3])};
+  }
+}
+
+// dst[((tn * K/32 + tk) * 16 + g * 4 + n) * 8 + e] = src[(4 tn + n) * K + 32 tk + 8 g + e]
+static __global__ __launch_bounds__(256) void pack_weight_rows4_kernel(const uint16_t* __restrict__ src,
+                                                                uint16_t* __restrict__ dst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+  if (idx >= (int64_t)N * K / 8) return;
+  const int u = idx & 15, n = u & 3, g = u >> 2;
+  const int64_t frag = idx >> 4;
+  const int ktiles = K >> 5;
+  const int tk = frag % ktiles;
+  const int64_t tn = frag / ktiles;
+  *reinterpret_cast<u32x4*>(dst + idx * 8) = *reinterpret_cast<const u32x4*>(src + (tn * 4 + n) * K + tk * 32 + g * 8);
+}
+
+template <int MT, int WAVES>
+static bool rows4_steps(const uint16_t* x, const uint16_t* w4, uint16_t* y, int M, int N, int K, hipStream_t st) {
+  if (K % WAVES) return false;
+  const int kslice = K / WAVES;
+#define ROWS4_GO(ST)                                                                                      \
+  do {                                                                                                    \
+    hipLaunchKernelGGL((gemm_rows4_kernel<MT, WAVES, ST>), dim3(N / 4), dim3(WAVES * 64), 0, st, x, w4, y, \
+                       M, N, K);                                                                          \
+    return true;                                                                                          \
+  } while (0)
+  // the whole K-slice in flight when the registers allow (MT + 1 fragments per k-step)
+  if (kslice == 256 && MT <= 2) ROWS4_GO(8);
+  if (kslice == 192 && MT <= 2) ROWS4_GO(6);
+  if (kslice % 128 == 0) ROWS4_GO(4);
+  if (kslice % 96 == 0) ROWS4_GO(3);
+  if (kslice % 64 == 0) ROWS4_GO(2);
+  if (kslice % 32 == 0) ROWS4_GO(1);
+#undef ROWS4_GO
+  return false;
+}
+
+template <int MT>
+static int rows4_waves(const uint16_t* x, const uint16_t* w4, uint16_t* y, int M, int N, int K, hipStream_t st) {
+  // 16 waves when every wave still gets >= 64 of K, else 8 / 4
+  bool ok = false;
+  if (K >= 16 * 64) ok = rows4_steps<MT, 16>(x, w4, y, M, N, K, st);
+  if (!ok && K >= 8 * 32) ok = rows4_steps<MT, 8>(x, w4, y, M, N, K, st);
+  if (!ok) ok = rows4_steps<MT, 4>(x, w4, y, M, N, K, st) || rows4_steps<MT, 1>(x, w4, y, M, N, K, st);
+  return ok ? check_launch() : MI_EUNSUPPORTED;
+}
+
+// fragment-native repack: dst[(tn * K/32 + tk) * 512 + lane * 8 + e] = src[(16 tn + lane%16) * K + 32 tk + 8 (lane/16) + e]
+static __global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t* __restrict__ src,
+                                                          uint16_t* __restrict__ dst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
+  const int64_t total = (int64_t)N * K / 8;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const int64_t frag = idx >> 6;
+  const int ktiles = K >> 5;
+  const int tk = frag % ktiles;
+  const int64_t tn = frag / ktiles;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(src + (tn * 16 + (lane & 15)) * K + tk * 32 + (lane >> 4) * 8);
+  *reinterpret_cast<u32x4*>(dst + idx * 8) = v;
+}
+
+struct GemmArgs {
+  const uint16_t *x, *w, *bias;
+  uint16_t* y;
+  float* part;
+  int M, N, K, ksplit;
+  hipStream_t st;
+  const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
+  PickArgs pick = PickArgs{nullptr, nullptr, nullptr};
+};
+
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
+static void launch(const GemmArgs& a) {
+  const size_t slot = (size_t)RT * MT * 1024 > (size_t)x_slab_bytes(MT) ? (size_t)RT * MT * 1024 : (size_t)x_slab_bytes(MT);
+  const size_t lds = (size_t)WAVES * slot;
+  const int tiles = a.N / 16;
+  const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
+  if (a.bias && EPI == EPI_NONE)
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
+}
+
+// choose STEPS (k-steps in flight per wave and iteration) from the K-slice and the register budget
+template <int MT, int RT, int WAVES, int WF, int EPI>
+static bool try_waves(const GemmArgs& a) {
+  if (a.K % (a.ksplit * WAVES)) return false;
+  const int kslice = a.K / (a.ksplit * WAVES);
+  constexpr int FRAGS = MT + RT;  // fragments (4 VGPRs each) per k-step
+  // k-steps in flight per wave and iteration, bounded by the 128-register budget of a 16-wave workgroup
+  // (x is staged as whole lines: its registers are live twice for a moment)
+  constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 5 ? 4 : 2);
+  if constexpr (MAXS >= 8) {
+    if (kslice % 256 == 0) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
+  }
+  if constexpr (MAXS >= 4) {
+    if (kslice % 128 == 0) return launch<MT, RT, WAVES, 4, WF, EPI>(a), true;
+  }
+  if (kslice % 64 == 0) return launch<MT, RT, WAVES, 2, WF, EPI>(a), true;
+  if constexpr (WF != 2) {  // an fp8 fragment load spans 64 k
+    if (kslice % 32 == 0) return launch<MT, RT, WAVES, 1, WF, EPI>(a), true;
+  }
+  return false;
+}
+
+template <int MT, int RT, int WF, int EPI>
+static int pick_waves(const GemmArgs& a) {
+  // Few row tiles (small N): spread K over many waves so that every CU holds loads in flight -
+  // K-slices of 128 (four 1 KiB fragment loads per row tile and wave) when K allows;
+  // many row tiles (lm_head): fewer, fatter waves.
+  const int wgs = (a.N / 16) / (EPI == EPI_SILU ? 2 : RT) * a.ksplit;
+  const int kper = a.K / a.ksplit;
+  bool ok = false;
+  if (wgs >= 2048) {
+    ok = try_waves<MT, RT, 4, WF, EPI>(a) || try_waves<MT, RT, 2, WF, EPI>(a);
+  } else {
+    // K-slices of 64 (two 1 KiB fragment loads per row tile and wave) when that fits 16 waves, else of
+    // 128: these launches are latency-bound, so the fewer dependent loads a wave issues the better
+    // (64-deep slices measured 1.72 -> 1.69 ms per decode step against 128-deep ones)
+    auto by_waves = [&](int waves) {
+      switch (waves) {
+        case 1: return try_waves<MT, RT, 1, WF, EPI>(a);
+        case 2: return try_waves<MT, RT, 2, WF, EPI>(a);
+        case 3: return try_waves<MT, RT, 3, WF, EPI>(a);
+        case 4: return try_waves<MT, RT, 4, WF, EPI>(a);
+        case 6: return try_waves<MT, RT, 6, WF, EPI>(a);
+        case 8: return try_waves<MT, RT, 8, WF, EPI>(a);
+        case 12: return try_waves<MT, RT, 12, WF, EPI>(a);
+        case 16: return try_waves<MT, RT, 16, WF, EPI>(a);
+        default: return false;
+      }
+    };
+    if (kper % 64 == 0 && kper / 64 <= 16) ok = by_waves(kper / 64);
+    if (!ok && kper % 128 == 0) ok = by_waves(kper / 128 <= 16 ? kper / 128 : (kper / 128 == 24 ? 12 : 16));
+  }
+  if (!ok) ok = try_waves<MT, RT, 8, WF, EPI>(a) || try_waves<MT, RT, 4, WF, EPI>(a) ||
+                try_waves<MT, RT, 2, WF, EPI>(a) || try_waves<MT, RT, 1, WF, EPI>(a);
+  if (!ok) return MI_EUNSUPPORTED;
+  return check_launch();
+}
+
+template <int RT, int WF, int EPI>
+static int pick_mt(const GemmArgs& a) {
+  switch ((a.M + 15) / 16) {
+    case 1: return pick_waves<1, RT, WF, EPI>(a);
+    case 2: return pick_waves<2, RT, WF, EPI>(a);
+    case 3: return pick_waves<3, RT, WF, EPI>(a);
+    default: return pick_waves<4, RT, WF, EPI>(a);
+  }
+}
+
+static int check_gemm(const void* x, const void* w, const void* y, int M, int N, int K) {
+  if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return MI_EINVAL;
+  if (M > 64 || K % 32 || N % 16) return MI_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return MI_EINVAL;
+  return MI_OK;
+}
+
+}  // namespace mi
+
+namespace mi {
+static bool pick_two_tiles(int M, int N) { return N / 16 >= 1024 && (N / 16) % 2 == 0 && M <= 32; }
+}  // namespace mi
