@@ -259,17 +259,22 @@ def test_lookahead_decode_equals_step_by_step_decode():
     assert a[1][:5] == b[1][:5] and a[3][:5] == b[3][:5]
 
 
-@pytest.mark.parametrize("enforce_eager", [True, False])
-def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, enforce_eager):
+@pytest.mark.parametrize("model,enforce_eager,tol", [("MID", True, 6e-2), ("MID", False, 6e-2),
+                                                     ("QWEN3_32B_2L", False, 1.3e-1),
+                                                     ("QWEN3_30B_A3B_2L", False, 1.3e-1)])
+def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol):
     """Functional tensor-parallel run on a 1-GPU box: two rank processes share cuda:0 and talk over
     gloo (MI355_DIST_BACKEND) - the same sharded layers, RPC channel and collectives call sites as
     the RCCL path.  Eager, and with the decode step captured in hipGraphs (the exchange kernels are
     captured; the logits gather stays outside).  Greedy tokens must equal the TP=1 run; logits agree
-    to bf16 noise (the K-sum of the row-parallel projections is split differently)."""
+    to bf16 noise (the K-sum of the row-parallel projections is split differently).  Also at the layer widths
+    of BASELINE.json configs[2] (Qwen3-32B: 64 q / 8 kv heads -> 32 / 4 per rank) and configs[3] (Qwen3-30B-A3B:
+    every rank holds all experts at 1/tp of the intermediate width, qwen3_moe.py:100-128)."""
     import socket
 
     from nanovllm import LLM, SamplingParams
 
+    cfg = {"MID": MID, "QWEN3_32B_2L": QWEN3_32B_2L, "QWEN3_30B_A3B_2L": QWEN3_30B_A3B_2L}[model]
     gen = torch.Generator().manual_seed(5)
     prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in (9, 33, 70)]
     sp = SamplingParams(max_tokens=6, ignore_eos=True, greedy=True)
@@ -278,7 +283,7 @@ def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, enforce_eager):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+        llm = LLM(make_model_dir(cfg), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
                   max_model_len=512, num_kvcache_blocks=64, enforce_eager=enforce_eager, warmup=False,
                   synthetic_seed=3, tensor_parallel_size=tp, hccl_port=port)
         try:
@@ -293,9 +298,10 @@ def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, enforce_eager):
     toks1, logits1 = run(1)
     monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
     toks2, logits2 = run(2)
-    assert (logits1 - logits2).abs().max().item() <= 6e-2
     agree = sum(int(a == b) for x, y in zip(toks1, toks2) for a, b in zip(x, y))
-    assert agree >= 17, (toks1, toks2)  # 18 tokens; allow one near-tie flip
+    assert agree >= (17 if model == "MID" else 15), (toks1, toks2)  # 18 tokens; near-tie flips allowed
+    if model == "MID" or agree == 18:  # wide models: comparable only if both runs fed the same tokens
+        assert (logits1 - logits2).abs().max().item() <= tol
 
 
 def test_config0_bs1_128_token_prompt_greedy_full_qwen3_0p6b():

@@ -36,8 +36,38 @@ def last_n(path, kernel_substr, n):
           f"min {min(tail):.2f} max {max(tail):.2f}")
 
 
+def window(path, anchor_substr, n_anchor, label):
+    """Device timeline between the first and the last of the LAST n_anchor dispatches of the anchor kernel
+    (e.g. the 28 prefill-attention launches of the bench's final prefill step): busy time per kernel, idle gaps."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = list(cur.execute(f"""select s.kernel_name, d.start, d.end from {kd} d join {ks} s
+                                on d.kernel_id = s.id order by d.start"""))
+    anchors = [i for i, r in enumerate(rows) if anchor_substr in r[0]][-n_anchor:]
+    lo, hi = anchors[0], anchors[-1]
+    span = (rows[hi][2] - rows[lo][1]) / 1000.0
+    per, busy, prev_end = {}, 0.0, rows[lo][1]
+    gaps = 0.0
+    for name, st, en in rows[lo:hi + 1]:
+        c = per.setdefault(name, [0, 0.0])
+        c[0] += 1
+        c[1] += (en - st) / 1000.0
+        busy += (en - st) / 1000.0
+        gaps += max(0, st - prev_end) / 1000.0
+        prev_end = max(prev_end, en)
+    print(f"{label}: {n_anchor} x *{anchor_substr}* first start -> last end: {span:.1f} us "
+          f"({span / max(1, n_anchor - 1) :.1f} us per anchor interval), kernels busy {busy:.1f} us, idle gaps {gaps:.1f} us")
+    for name, (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"   {name[:96]:96s} {cnt:5d} {tot / cnt:9.2f} us avg {tot:10.1f} us {100 * tot / span:5.1f} %")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 4 and sys.argv[2] == "--last":
+    if len(sys.argv) > 5 and sys.argv[2] == "--window":
+        window(sys.argv[1], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+    elif len(sys.argv) > 4 and sys.argv[2] == "--last":
         last_n(sys.argv[1], sys.argv[3], int(sys.argv[4]))
     else:
         main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 30)

@@ -14,6 +14,8 @@ grep '^{"metric"' /tmp/log_kt > $O/bench_under_kernel_trace.json
 db=$(find /tmp/prof_kt -name "*.db" | head -1)
 python $R/tools/prof_db.py $db 40 > $O/kernel_trace.txt
 python $R/tools/prof_db.py $db --last paged_attn_decode_kernel 560 >> $O/kernel_trace.txt
+# the bench's last prefill step (16 x 1024 tokens): its 28 attention launches bracket 27 whole layers
+python $R/tools/prof_db.py $db --window paged_attn_prefill_kernel 28 "prefill step, 16 x 1024 tokens" > $O/prefill_step_breakdown.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/prof_$c -- python $R/bench.py --no-cpu-baseline "$@" > /tmp/log_$c 2>&1
   db=$(find /tmp/prof_$c -name "*.db" | head -1)
