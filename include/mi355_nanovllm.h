@@ -353,20 +353,25 @@ int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const 
 int mi_moe_route(const mi_bf16* router_logits, int n_tokens, int n_experts, int top_k,
                  int32_t* topk_ids, mi_bf16* topk_w, mi_stream stream);
 /* Group the pairs by expert: expert_offsets [n_experts + 1] (run of expert e = [off[e], off[e+1])),
- * pair_token [P] (token of the pair at each sorted position), pair_pos [n_tokens][top_k] (where each pair went). */
+ * pair_token [P] (token of the pair at each sorted position), pair_index [P] (its index t * top_k + slot in
+ * topk_ids).  The order of the pairs INSIDE an expert's run is unspecified (it differs between calls and
+ * between tensor-parallel ranks); nothing downstream depends on it. */
 int mi_moe_sort(const int32_t* topk_ids, int n_tokens, int top_k, int n_experts,
-                int32_t* expert_offsets, int32_t* pair_token, int32_t* pair_pos, mi_stream stream);
+                int32_t* expert_offsets, int32_t* pair_token, int32_t* pair_index, mi_stream stream);
 /* act[pos][inter] = SiluAndMul(x[pair_token[pos]] @ W_gate_up[e]^T) for every pair of every expert, rounding
  * points of mi_gemm_bf16_packed(epilogue 1).  hidden = 64 * {1,2,3,4,6,8,12,16}, 128 * {5,10,12,16} or 256 * {10,16}. */
 int mi_moe_gate_up(const mi_bf16* x, const mi_bf16* w_gate_up_packed, const int32_t* expert_offsets,
                    const int32_t* pair_token, mi_bf16* act, int n_experts, int hidden, int inter,
                    mi_stream stream);
-/* y[pos][hidden] = bf16(act[pos] @ W_down[e]^T): the expert MLP's output (:121).  inter: same set as above. */
+/* y[pair_index[pos]][hidden] = bf16(act[pos] @ W_down[e]^T): the expert MLP's output (:121), stored at the
+ * pair's own row t * top_k + slot - the same layout on every tensor-parallel rank, so that the ranks' partial
+ * sums can be all-reduced row by row.  inter: same set as above. */
 int mi_moe_down(const mi_bf16* act, const mi_bf16* w_down_packed, const int32_t* expert_offsets,
-                mi_bf16* y, int n_experts, int hidden, int inter, mi_stream stream);
-/* out[t] = sum over the token's pairs j (ascending expert id) of bf16(y[pair_pos[t][j]] * topk_w[t][j]), every
+                const int32_t* pair_index, mi_bf16* y, int n_experts, int hidden, int inter,
+                mi_stream stream);
+/* out[t] = sum over the token's pairs j (ascending expert id) of bf16(y[t * top_k + j] * topk_w[t][j]), every
  * partial sum rounded to bf16 - `index_add_` into a bf16 tensor (:178-184). */
-int mi_moe_combine(const mi_bf16* y, const int32_t* pair_pos, const mi_bf16* topk_w, mi_bf16* out,
+int mi_moe_combine(const mi_bf16* y, const mi_bf16* topk_w, mi_bf16* out,
                    int n_tokens, int top_k, int hidden, mi_stream stream);
 
 /* ---- tensor-parallel exchange over xGMI -----------------------------------

@@ -2,9 +2,11 @@
 // nanovllm/models/qwen3_moe.py:150-185) as five launches over expert-sorted (token, expert) pairs:
 //
 //   mi_moe_route     router logits -> fp32 softmax, top-k, renormalise, bf16 weights   (:153-161)
-//   mi_moe_sort      pairs grouped by expert: offsets, the token of every pair, where each pair went
+//   mi_moe_sort      pairs grouped by expert: offsets, the token and the (token, slot) index of every sorted pair
 //   mi_moe_gate_up   per expert: act = SwiGLU(x[tokens] @ W_gate_up[e]^T)   (expert MLP, :118-121)
-//   mi_moe_down      per expert: y = act @ W_down[e]^T, rounded to bf16 (the expert's output)
+//   mi_moe_down      per expert: y = act @ W_down[e]^T, rounded to bf16 (the expert's output), written to the
+//                    pair's own row t * top_k + slot: y has the SAME layout on every tensor-parallel rank
+//                    whatever order the sort's atomics produced, so it can be summed over the ranks
 //   mi_moe_combine   out[t] = sum over the token's experts in ascending expert id of bf16(y * w), every
 //                    partial sum rounded to bf16 (`index_add_` on a bf16 tensor, :171-184)
 //
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restri
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restrict__ topk_ids, int n_pairs, int top_k, int E,
                                                         int32_t* __restrict__ offsets, int32_t* __restrict__ pair_token,
-                                                        int32_t* __restrict__ pair_pos) {
+                                                        int32_t* __restrict__ pair_index) {
   __shared__ int cnt[513], cursor[512];
   for (int e = threadIdx.x; e <= E; e += blockDim.x) cnt[e] = 0;
   __syncthreads();
@@ -115,11 +117,12 @@ __global__ __launch_bounds__(1024) void moe_sort_kernel(const int32_t* __restric
   }
   __syncthreads();
   // which slot inside an expert's run a pair gets is irrelevant to every result (the pairs of a run are
-  // independent MFMA columns), so the order the atomics happen to produce is fine
+  // independent MFMA columns, and results are written back by pair index), so the order the atomics happen
+  // to produce - different from rank to rank and run to run - is fine
   for (int i = threadIdx.x; i < n_pairs; i += blockDim.x) {
     const int pos = atomicAdd(&cursor[topk_ids[i]], 1);
     pair_token[pos] = i / top_k;
-    pair_pos[i] = pos;
+    pair_index[pos] = i;
   }
 }
 
@@ -133,6 +136,8 @@ __global__ __launch_bounds__(WAVES * 64) void moe_gemm_kernel(const uint16_t* __
                                                               const int32_t* __restrict__ offsets,
                                                               const int32_t* __restrict__ pair_token,
                                                               uint16_t* __restrict__ y, int N, int K) {
+  // GATE_UP: pair_token = token of each sorted pair (input row); result rows in sorted order.
+  // down:    pair_token = (token, slot) index of each sorted pair (OUTPUT row); input rows in sorted order.
   constexpr int RT = GATE_UP ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float red[WAVES][RT][64][4];
   const int e = blockIdx.y;
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(WAVES * 64) void moe_gemm_kernel(const uint16_t* __
   for (int m0 = 0; m0 < n_e; m0 += 16) {
     const int pr = p0 + min(m0 + r, n_e - 1);  // pairs past the end shadow the last one (results unused)
     const int64_t row = GATE_UP ? (int64_t)pair_token[pr] : (int64_t)pr;
+    const int64_t out_row = GATE_UP ? (int64_t)(p0 + m0 + r) : (int64_t)pair_token[pr];
     f32x4 acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void moe_gemm_kernel(const uint16_t* __
             o[i] = s0[i];
           }
         }
-        *reinterpret_cast<u32x2*>(y + (int64_t)(p0 + m0 + r) * N + (int)blockIdx.x * 16 + 4 * g) =
+        *reinterpret_cast<u32x2*>(y + out_row * N + (int)blockIdx.x * 16 + 4 * g) =
             u32x2{pack_bf(o[0], o[1]), pack_bf(o[2], o[3])};
       }
     }
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64) void moe_gemm_kernel(const uint16_t* __
 }
 
 // out[t] = (((0 + c_0) + c_1) + ...) with c_j = bf16(y[pair j of t] * w_j), every sum rounded to bf16
-__global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __restrict__ y, const int32_t* __restrict__ pair_pos,
+__global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __restrict__ y,
                                                           const uint16_t* __restrict__ topk_w, uint16_t* __restrict__ out,
                                                           int T, int top_k, int H) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   for (int j = 0; j < top_k; ++j) {
     const float wj = bf2f(topk_w[(int64_t)t * top_k + j]);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(y + (int64_t)pair_pos[(int64_t)t * top_k + j] * H + c);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(y + ((int64_t)t * top_k + j) * H + c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       acc[2 * i] = rbf(acc[2 * i] + rbf(lo_bf(v[i]) * wj));
@@ -284,11 +290,11 @@ extern "C" int mi_moe_route(const mi_bf16* router_logits, int n_tokens, int n_ex
 }
 
 extern "C" int mi_moe_sort(const int32_t* topk_ids, int n_tokens, int top_k, int n_experts, int32_t* expert_offsets,
-                           int32_t* pair_token, int32_t* pair_pos, mi_stream stream) {
-  if (!topk_ids || !expert_offsets || !pair_token || !pair_pos || n_tokens < 0) return MI_EINVAL;
+                           int32_t* pair_token, int32_t* pair_index, mi_stream stream) {
+  if (!topk_ids || !expert_offsets || !pair_token || !pair_index || n_tokens < 0) return MI_EINVAL;
   if (n_experts < 1 || n_experts > 512 || top_k < 1) return MI_EUNSUPPORTED;
   hipLaunchKernelGGL(moe_sort_kernel, dim3(1), dim3(1024), 0, S(stream), topk_ids, n_tokens * top_k, top_k, n_experts,
-                     expert_offsets, pair_token, pair_pos);
+                     expert_offsets, pair_token, pair_index);
   return check_launch();
 }
 
@@ -301,22 +307,23 @@ extern "C" int mi_moe_gate_up(const mi_bf16* x, const mi_bf16* w_packed, const i
   return launch_moe_gemm<true>(x, w_packed, expert_offsets, pair_token, act, inter, hidden, n_experts, S(stream));
 }
 
-extern "C" int mi_moe_down(const mi_bf16* act, const mi_bf16* w_packed, const int32_t* expert_offsets, mi_bf16* y,
-                           int n_experts, int hidden, int inter, mi_stream stream) {
-  if (!act || !w_packed || !expert_offsets || !y) return MI_EINVAL;
+extern "C" int mi_moe_down(const mi_bf16* act, const mi_bf16* w_packed, const int32_t* expert_offsets,
+                           const int32_t* pair_index, mi_bf16* y, int n_experts, int hidden, int inter,
+                           mi_stream stream) {
+  if (!act || !w_packed || !expert_offsets || !pair_index || !y) return MI_EINVAL;
   if (n_experts < 1 || inter % 64 || hidden % 16) return MI_EUNSUPPORTED;
   if (!aligned16(act) || !aligned16(w_packed) || !aligned16(y)) return MI_EINVAL;
-  return launch_moe_gemm<false>(act, w_packed, expert_offsets, nullptr, y, hidden, inter, n_experts, S(stream));
+  return launch_moe_gemm<false>(act, w_packed, expert_offsets, pair_index, y, hidden, inter, n_experts, S(stream));
 }
 
-extern "C" int mi_moe_combine(const mi_bf16* y, const int32_t* pair_pos, const mi_bf16* topk_w, mi_bf16* out,
-                              int n_tokens, int top_k, int hidden, mi_stream stream) {
-  if (!y || !pair_pos || !topk_w || !out || n_tokens < 0 || top_k < 1) return MI_EINVAL;
+extern "C" int mi_moe_combine(const mi_bf16* y, const mi_bf16* topk_w, mi_bf16* out, int n_tokens, int top_k,
+                              int hidden, mi_stream stream) {
+  if (!y || !topk_w || !out || n_tokens < 0 || top_k < 1) return MI_EINVAL;
   if (hidden % 8) return MI_EUNSUPPORTED;
   if (!aligned16(y) || !aligned16(out)) return MI_EINVAL;
   if (n_tokens == 0) return MI_OK;
   const int64_t n = (int64_t)n_tokens * (hidden / 8);
-  hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), y, pair_pos, topk_w,
-                     out, n_tokens, top_k, hidden);
+  hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), y, topk_w, out,
+                     n_tokens, top_k, hidden);
   return check_launch();
 }

@@ -106,8 +106,8 @@ _SIGNATURES = {
     "mi_moe_route": (c_int, [_p, c_int, c_int, c_int, _p, _p, _p]),
     "mi_moe_sort": (c_int, [_p, c_int, c_int, c_int, _p, _p, _p, _p]),
     "mi_moe_gate_up": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
-    "mi_moe_down": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p]),
-    "mi_moe_combine": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_moe_down": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_moe_combine": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_comm_region_bytes": (c_size_t, [c_int, c_size_t]),
     "mi_comm_region_alloc": (c_int, [c_size_t, ctypes.POINTER(_p), _p]),
     "mi_comm_region_open": (c_int, [_p, ctypes.POINTER(_p)]),

@@ -244,12 +244,14 @@ class Qwen3Model(nn.Module):
                 y = ops.gemm_packed(x, lin.weight_packed)  # this rank's bf16 partial sums
             if tp > 1 and not fused_seam:
                 y = all_reduce_sum(y)
-            return y, False
+            return y, ("ranks" if fused_seam else False)
 
         def add_norm(y, is_partials, res, ln):
-            if is_partials:
+            """is_partials: True = fp32 split-K partials of this rank (TP 1); "ranks" = bf16 partial sums that
+            still have to be summed over the TP ranks (fused seam); False = a finished bf16 tensor."""
+            if is_partials is True:
                 return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps)
-            if fused_seam:  # all-reduce over xGMI + add + RMSNorm in one launch
+            if is_partials == "ranks":  # all-reduce over xGMI + add + RMSNorm in one launch
                 return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
             return ops.add_rmsnorm(y, res, ln.weight, ln.eps)
 
@@ -271,7 +273,7 @@ class Qwen3Model(nn.Module):
             parts, is_partials = row_parallel(o, attn.o_proj)
             if hasattr(mlp, "experts"):  # sparse block (models/qwen3_moe.py): five launches over expert-sorted pairs
                 x, residual = add_norm(parts, is_partials, residual, ln2)
-                parts, is_partials = mlp(x), False
+                parts, is_partials = mlp(x), False  # summed over the ranks inside the block (before the combine)
             else:
                 act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj.weight_packed,
                                             silu_mul=True)

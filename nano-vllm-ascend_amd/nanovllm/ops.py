@@ -532,15 +532,17 @@ def moe_forward(x, router_logits, gate_up_packed, down_packed, top_k: int, all_r
     check(lib.mi_moe_route(ptr(router_logits), T, E, top_k, ptr(ids), ptr(w), stream()), "mi_moe_route")
     offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
     pair_token = torch.empty(T * top_k, dtype=torch.int32, device=dev)
-    pair_pos = torch.empty((T, top_k), dtype=torch.int32, device=dev)
-    check(lib.mi_moe_sort(ptr(ids), T, top_k, E, ptr(offsets), ptr(pair_token), ptr(pair_pos), stream()), "mi_moe_sort")
+    pair_index = torch.empty(T * top_k, dtype=torch.int32, device=dev)
+    check(lib.mi_moe_sort(ptr(ids), T, top_k, E, ptr(offsets), ptr(pair_token), ptr(pair_index), stream()),
+          "mi_moe_sort")
     act = torch.empty((T * top_k, inter), dtype=_BF16, device=dev)
     check(lib.mi_moe_gate_up(ptr(x), ptr(gate_up_packed), ptr(offsets), ptr(pair_token), ptr(act), E, H, inter,
                              stream()), "mi_moe_gate_up")
-    y = torch.empty((T * top_k, H), dtype=_BF16, device=dev)
-    check(lib.mi_moe_down(ptr(act), ptr(down_packed), ptr(offsets), ptr(y), E, H, inter, stream()), "mi_moe_down")
+    y = torch.empty((T * top_k, H), dtype=_BF16, device=dev)  # row t * top_k + j: the same on every TP rank
+    check(lib.mi_moe_down(ptr(act), ptr(down_packed), ptr(offsets), ptr(pair_index), ptr(y), E, H, inter, stream()),
+          "mi_moe_down")
     if all_reduce is not None:
         y = all_reduce(y)
     out = torch.empty((T, H), dtype=_BF16, device=dev)
-    check(lib.mi_moe_combine(ptr(y), ptr(pair_pos), ptr(w), ptr(out), T, top_k, H, stream()), "mi_moe_combine")
+    check(lib.mi_moe_combine(ptr(y), ptr(w), ptr(out), T, top_k, H, stream()), "mi_moe_combine")
     return out, ids, w

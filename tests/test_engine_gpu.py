@@ -299,8 +299,8 @@ def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, t
     monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
     toks2, logits2 = run(2)
     agree = sum(int(a == b) for x, y in zip(toks1, toks2) for a, b in zip(x, y))
-    assert agree >= (17 if model == "MID" else 15), (toks1, toks2)  # 18 tokens; near-tie flips allowed
-    if model == "MID" or agree == 18:  # wide models: comparable only if both runs fed the same tokens
+    assert agree >= 17, (toks1, toks2)  # 18 tokens; allow one near-tie flip
+    if agree == 18 or model == "MID":  # the last step's logits: comparable if both runs fed the same tokens
         assert (logits1 - logits2).abs().max().item() <= tol
 
 

@@ -785,6 +785,54 @@ def test_moe_block_qwen3_30b_a3b_shapes(ops, T, inter):
     _moe_case(ops, x, gate_w, gu, dn, K)
 
 
+@pytest.mark.parametrize("T,world", [(32, 2), (100, 4)])
+def test_moe_block_expert_shards_sum_to_the_whole(ops, T, world):
+    """Tensor-parallel experts (qwen3_moe.py:100-128: every rank holds 1/world of every expert's intermediate
+    width): the ranks' mi_moe_down outputs are summed row by row, so they must have the SAME row layout on every
+    rank whatever order each rank's mi_moe_sort produced.  Emulated in one process: one moe_forward per shard, the
+    all-reduce hook adds the shards' y (bf16 adds in rank order, as the exchange kernel); result vs the oracle
+    block on the sharded arithmetic (each rank's partial output rounded to bf16 before the sum)."""
+    from oracle import layers as L
+
+    gen = torch.Generator().manual_seed(T)
+    H, E, K, inter = 2048, 128, 8, 768
+    x = torch.randn(T, H, generator=gen).bfloat16()
+    gate_w = (torch.randn(E, H, generator=gen) * 0.1).bfloat16()
+    gu = (torch.randn(E, 2 * inter, H, generator=gen) * 0.03).bfloat16()
+    dn = (torch.randn(E, H, inter, generator=gen) * 0.03).bfloat16()
+    logits = oracle.linear(x, gate_w)
+    il = inter // world
+    ys = []
+
+    def hook(y):
+        ys.append(y.clone())
+        total = ys[0].float()
+        for part in ys[1:]:
+            total = (total + part.float()).bfloat16().float()
+        return total.bfloat16()
+
+    out = None
+    for r in range(world):
+        g_r = torch.cat([gu[:, r * il:(r + 1) * il], gu[:, inter + r * il:inter + (r + 1) * il]], 1).contiguous()
+        d_r = dn[:, :, r * il:(r + 1) * il].contiguous()
+        out, ids, w = ops.moe_forward(x.to(DEV), logits.to(DEV), ops.pack_expert_weights(g_r.to(DEV)),
+                                      ops.pack_expert_weights(d_r.to(DEV)), K, all_reduce=hook)
+    # the oracle on the same sharded arithmetic: per expert and rank act_r @ W_down_r^T rounded to bf16, summed
+    ids_c, w_c = ids.cpu().long(), w.cpu()
+    want = torch.zeros(T, H, dtype=torch.bfloat16)
+    for t in range(T):
+        for j in range(K):
+            e = int(ids_c[t, j])
+            y = None
+            for r in range(world):
+                g_r = torch.cat([gu[e, r * il:(r + 1) * il], gu[e, inter + r * il:inter + (r + 1) * il]], 0)
+                act = L.silu_and_mul(oracle.linear(x[t:t + 1], g_r))
+                part = oracle.linear(act, dn[e][:, r * il:(r + 1) * il])
+                y = part if y is None else (y.float() + part.float()).bfloat16()
+            want[t] = (want[t].float() + (y[0].float() * w_c[t, j].float()).bfloat16().float()).bfloat16()
+    _assert_moe_close(out, want)
+
+
 def test_moe_route_ties_and_uniform_logits(ops):
     """equal router logits: the lower expert ids win (the restatement's tie rule), weights are exactly 1/k"""
     T, E, K, H, I = 5, 64, 4, 128, 64

@@ -86,7 +86,95 @@ def head_and_sampler():
     print(json.dumps(res, indent=1))
 
 
+def moe_block():
+    """The sparse block of a decode step at Qwen3-30B-A3B widths (hidden 2048, 128 experts x 768, top-8), bs 32
+    (TP 1: every expert whole) and as one rank of TP 4 (192 of every expert's 768).  Bytes = the weights of the
+    experts that were hit (each streamed once by each grouped GEMM)."""
+    H, E, topk, T = 2048, 128, 8, 32
+    res = {}
+    for tp in (1, 4):
+        inter = 768 // tp
+        L = 4  # rotate over several layers' weights (TP 1: 1.2 GB per layer, beyond any cache anyway)
+        gu = [ops.pack_expert_weights((torch.randn(E, 2 * inter, H, device=DEV) * 0.02).bfloat16()) for _ in range(L)]
+        dn = [ops.pack_expert_weights((torch.randn(E, H, inter, device=DEV) * 0.02).bfloat16()) for _ in range(L)]
+        x = torch.randn(T, H, device=DEV).bfloat16()
+        logits = torch.randn(T, E, device=DEV).bfloat16()
+        _, ids, _ = ops.moe_forward(x, logits, gu[0], dn[0], topk)
+        hit = int(torch.unique(ids).numel())
+        byt = hit * 3 * inter * H * 2
+        t = timeit(lambda l: ops.moe_forward(x, logits, gu[l], dn[l], topk), L, reps=3)
+        res[f"moe block tp{tp} (route+sort+gate_up+down+combine), {hit}/128 experts hit"] = {
+            "us": t * 1e6, "MB": byt / 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
+    print(json.dumps(res, indent=1))
+
+
+def chain_32b_shard():
+    """The six non-attention launches of a decode layer on ONE RANK of Qwen3-32B at TP 8 (hidden 5120, 8 q / 1 kv
+    heads, intermediate 3200 per rank; all-reduce seams not included), bs 32, over 4 rotating layers."""
+    H, hq, hkv, inter, B, L = 5120, 8, 1, 25600 // 8, 32, 4
+    mk = lambda n, k: ops.pack_weight((torch.randn(n, k, device=DEV) * 0.02).bfloat16())  # noqa: E731
+    qkv = [mk((hq + 2 * hkv) * 128, H) for _ in range(L)]
+    mk4 = lambda n, k: ops.pack_weight_rows4((torch.randn(n, k, device=DEV) * 0.02).bfloat16())  # noqa: E731
+    o = [mk4(H, hq * 128) for _ in range(L)]  # row-parallel projections: complete bf16 rows per rank (TP path)
+    gu = [mk(2 * inter, H) for _ in range(L)]
+    dn = [mk4(H, inter) for _ in range(L)]
+    wn = torch.ones(H, device=DEV).bfloat16()
+    x = torch.randn(B, H, device=DEV).bfloat16()
+    attn_out = torch.randn(B, hq * 128, device=DEV).bfloat16()
+    res_ = torch.randn(B, H, device=DEV).bfloat16()
+
+    def layer(l):
+        xn, r = ops.add_rmsnorm(x, res_, wn, 1e-6)
+        ops.gemm_packed(xn, qkv[l])
+        y = ops.gemm_rows4(attn_out, o[l])
+        xn, r = ops.add_rmsnorm(y, r, wn, 1e-6)
+        a = ops.gemm_packed(xn, gu[l], silu_mul=True)
+        ops.gemm_rows4(a, dn[l])
+
+    byt = ((hq + 2 * hkv) * 128 * H + H * hq * 128 + 2 * inter * H + H * inter) * 2
+    t = timeit(layer, L, reps=3)
+    print(json.dumps({"Qwen3-32B TP8 rank shard, 6 launches per layer": {
+        "us": t * 1e6, "MB": byt / 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}}, indent=1))
+
+
+def gemms_32b_shard():
+    """Each projection of a Qwen3-32B TP 8 rank (and of the unsharded 32B layer) alone, bs 32: packed / split-K /
+    complete-row variants, 4 rotating weight copies."""
+    B, L = 32, 4
+    res = {}
+    shapes = {"qkv tp8 1280x5120": (1280, 5120, False), "o tp8 5120x1024": (5120, 1024, False),
+              "gate_up tp8 6400x5120": (6400, 5120, True), "down tp8 5120x3200": (5120, 3200, False),
+              "qkv tp1 10240x5120": (10240, 5120, False), "o tp1 5120x8192": (5120, 8192, False),
+              "gate_up tp1 51200x5120": (51200, 5120, True), "down tp1 5120x25600": (5120, 25600, False)}
+    for name, (N, K, silu) in shapes.items():
+        ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(L)]
+        wp = [ops.pack_weight(w) for w in ws]
+        x = torch.randn(B, K, device=DEV).bfloat16()
+        byt = N * K * 2
+        r = {}
+        t = timeit(lambda l: ops.gemm_packed(x, wp[l], silu_mul=silu), L, reps=4)
+        r["packed_us"] = t * 1e6
+        r["packed_frac"] = byt / t / PEAK
+        if not silu:
+            for ks in (2, 4, 8):
+                if K % (ks * 256) == 0:
+                    t = timeit(lambda l: ops.gemm_packed_splitk(x, wp[l], ks), L, reps=4)
+                    r[f"splitk{ks}_us"] = t * 1e6
+            w4 = [ops.pack_weight_rows4(w) for w in ws]
+            t = timeit(lambda l: ops.gemm_rows4(x, w4[l]), L, reps=4)
+            r["rows4_us"] = t * 1e6
+        res[name] = r
+        del ws, wp
+    print(json.dumps(res, indent=1))
+
+
 def main():
+    if os.environ.get("KBENCH_ONLY") == "32b_gemms":
+        return gemms_32b_shard()
+    if os.environ.get("KBENCH_ONLY") == "moe":
+        return moe_block()
+    if os.environ.get("KBENCH_ONLY") == "32b":
+        return chain_32b_shard()
     if os.environ.get("KBENCH_ONLY") == "prefill":
         return prefill_attention()
     if os.environ.get("KBENCH_ONLY") == "head":
