@@ -660,3 +660,28 @@ def test_lookahead_falls_back_when_a_preemption_is_needed():
         outs.append((_drain(eng), eng.model_runner.steps))
     assert outs[0][0] == outs[1][0] and all(len(v) == 7 for v in outs[0][0].values())
     assert outs[0][1] == outs[1][1]  # preemption and re-prefill happen at the same steps
+
+
+def test_lookahead_abort_drops_the_row_of_the_queued_step():
+    """abort_request between two step() calls while the aborted sequence still has a row in the queued decode
+    step: the row's token is discarded when the step is collected, the other streams are untouched."""
+    outs = []
+    for abort in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(True, eos=-1, num_kvcache_blocks=30, max_num_batched_tokens=64)
+        for i, p in enumerate(([1, 2, 3], [4, 5, 6, 7], [8, 9])):
+            eng.add_request(p, SamplingParams(max_tokens=10, ignore_eos=True, temperature=1.0), request_id=f"r{i}")
+        done = {}
+        for step in range(40):
+            if eng.is_finished():
+                break
+            if abort and step == 4:
+                assert eng._inflight is not None  # a decode step is queued right now
+                eng.abort_request("r1")
+            for seq_id, toks, _, _ in eng.step()[0]:
+                done[seq_id] = list(toks)
+        outs.append(done)
+        assert not eng.scheduler.block_manager.used_block_ids and eng._inflight is None
+    full, aborted = outs
+    assert sorted(full) == [0, 1, 2] and sorted(aborted) == [0, 2]
+    assert aborted[0] == full[0] and aborted[2] == full[2]
