@@ -311,7 +311,7 @@ int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatur
  * followed by sampler.py:9-17).  y = x @ W^T as mi_gemm_bf16_packed, and every
  * workgroup also reports the best sampling key of its columns per row - the key
  * mi_argmax / mi_sample would form from the ROUNDED logit, bit for bit - into
- * candidates [mi_gemm_pick_groups(M, N)][M] x 8 bytes.  mi_pick_final reduces
+ * candidates [M][mi_gemm_pick_groups(M, N)] x 8 bytes.  mi_pick_final reduces
  * them to out[rows] (ties -> lowest column): the same tokens as mi_sample over y
  * with the same (seed, step), without reading y again.  rng points to
  * {seed, step} in DEVICE memory so that a captured graph picks up the step the

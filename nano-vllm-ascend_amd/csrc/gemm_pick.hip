@@ -4,19 +4,30 @@
 
 namespace mi {
 
-// token of every row from the candidates of EPI_PICK: one workgroup per row
-__global__ __launch_bounds__(256) void pick_final_kernel(const uint2* __restrict__ cand, int n_groups, int M,
-                                                         int64_t* __restrict__ out) {
+// token of every row from the candidates of EPI_PICK: one 1024-thread workgroup per row.  The candidates were
+// written by other CUs a moment ago (every load is a trip to memory), so a thread issues eight loads before it
+// compares anything: one exposed latency per 8192 candidates instead of one per candidate.
+__global__ __launch_bounds__(1024) void pick_final_kernel(const uint2* __restrict__ cand, int n_groups, int M,
+                                                          int64_t* __restrict__ out) {
   const int row = blockIdx.x;
+  const uint2* p = cand + (int64_t)row * n_groups;
   float best = -INFINITY;
   int best_c = 0x7fffffff;
-  for (int gidx = threadIdx.x; gidx < n_groups; gidx += 256) {
-    const uint2 c = cand[(int64_t)gidx * M + row];
-    const float k2 = __uint_as_float(c.x);
-    const int c2 = (int)c.y;
-    if (k2 > best || (k2 == best && c2 < best_c)) {
-      best = k2;
-      best_c = c2;
+  for (int base = 0; base < n_groups; base += 8 * 1024) {
+    uint2 c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gidx = base + i * 1024 + (int)threadIdx.x;
+      c[i] = p[min(gidx, n_groups - 1)];  // past the end: the last candidate again (harmless under max)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float k2 = __uint_as_float(c[i].x);
+      const int c2 = (int)c[i].y;
+      if (k2 > best || (k2 == best && c2 < best_c)) {
+        best = k2;
+        best_c = c2;
+      }
     }
   }
 #pragma unroll
@@ -28,15 +39,15 @@ __global__ __launch_bounds__(256) void pick_final_kernel(const uint2* __restrict
       best_c = oc;
     }
   }
-  __shared__ float sb[4];
-  __shared__ int sc[4];
+  __shared__ float sb[16];
+  __shared__ int sc[16];
   if ((threadIdx.x & 63) == 0) {
     sb[threadIdx.x >> 6] = best;
     sc[threadIdx.x >> 6] = best_c;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (sb[w] > best || (sb[w] == best && sc[w] < best_c)) {
         best = sb[w];
         best_c = sc[w];
@@ -84,7 +95,7 @@ extern "C" int mi_gemm_fp8w_packed_pick(const mi_bf16* x, const uint8_t* w_packe
 extern "C" int mi_pick_final(const void* candidates, int n_groups, int rows, int64_t* out, mi_stream stream) {
   if (!candidates || !out || n_groups <= 0 || rows < 0) return MI_EINVAL;
   if (rows == 0) return MI_OK;
-  hipLaunchKernelGGL(pick_final_kernel, dim3(rows), dim3(256), 0, S(stream), static_cast<const uint2*>(candidates),
+  hipLaunchKernelGGL(pick_final_kernel, dim3(rows), dim3(1024), 0, S(stream), static_cast<const uint2*>(candidates),
                      n_groups, rows, out);
   return check_launch();
 }

@@ -17,7 +17,7 @@ enum { EPI_NONE = 0, EPI_SILU = 1, EPI_PARTIAL = 2, EPI_PICK = 3 };
 struct PickArgs {
   const float* temperatures;  // [M]; nullptr or <= 0: greedy
   const uint64_t* rng;        // {seed, step} in device memory (a captured graph reads the current step)
-  uint2* cand;                // [gridDim.x][M] {key bits, column}
+  uint2* cand;                // [M][gridDim.x] {key bits, column}: a row's candidates are contiguous
 };
 
 // B fragments (the activations x^T) of one wave for STEPS k-steps starting at xk = x + k0:
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
           best_c = c2;
         }
       }
-      pk.cand[(int64_t)blockIdx.x * M + row] = uint2{__float_as_uint(best), (uint32_t)best_c};
+      pk.cand[(int64_t)row * gridDim.x + blockIdx.x] = uint2{__float_as_uint(best), (uint32_t)best_c};
     }
   }
 }

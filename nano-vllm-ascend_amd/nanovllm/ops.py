@@ -487,7 +487,7 @@ def gemm_packed_pick(x, w_packed, temperatures, rng, out_tokens, logits=None, ca
     if logits is None:
         logits = torch.empty((M, N), dtype=_BF16, device=x.device)
     if candidates is None:
-        candidates = torch.empty((groups, M, 2), dtype=torch.int32, device=x.device)
+        candidates = torch.empty((M, groups, 2), dtype=torch.int32, device=x.device)
     assert candidates.numel() >= groups * M * 2
     if isinstance(w_packed, Fp8Weight):
         check(lib.mi_gemm_fp8w_packed_pick(ptr(x), ptr(w_packed.data), ptr(w_packed.scale), ptr(logits), M, N, K,
