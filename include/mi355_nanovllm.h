@@ -311,12 +311,12 @@ int mi_sample(const mi_bf16* logits, int64_t row_stride, const float* temperatur
  * followed by sampler.py:9-17).  y = x @ W^T as mi_gemm_bf16_packed, and every
  * workgroup also reports the best sampling key of its columns per row - the key
  * mi_argmax / mi_sample would form from the ROUNDED logit, bit for bit - into
- * candidates [M][mi_gemm_pick_groups(M, N)] x 8 bytes.  mi_pick_final reduces
+ * candidates [M][mi_gemm_pick_groups(M, N, K, fp8)] x 8 bytes.  mi_pick_final reduces
  * them to out[rows] (ties -> lowest column): the same tokens as mi_sample over y
  * with the same (seed, step), without reading y again.  rng points to
  * {seed, step} in DEVICE memory so that a captured graph picks up the step the
  * host wrote before replaying it.  temperatures may be NULL (all rows greedy). */
-int mi_gemm_pick_groups(int M, int N);
+int mi_gemm_pick_groups(int M, int N, int K, int fp8_weights);
 int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y,
                              int M, int N, int K, const float* temperatures,
                              const uint64_t* rng, void* candidates, mi_stream stream);

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(1024) void pick_final_kernel(const uint2* __restric
 using namespace mi;
 
 // head GEMM with the pick epilogue: the same workgroup geometry as mi_gemm_bf16_packed for this (M, N)
-extern "C" int mi_gemm_pick_groups(int M, int N) {
+extern "C" int mi_gemm_pick_groups(int M, int N, int K, int fp8_weights) {
   if (M <= 0 || N <= 0 || N % 16) return 0;
+  if (!fp8_weights && head_stream_fits(M, N, K)) return kHeadStreamGrid;
   return pick_two_tiles(M, N) ? N / 32 : N / 16;
 }
 
@@ -73,6 +74,11 @@ extern "C" int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packe
   if (rc != MI_OK) return rc;
   if (!rng || !candidates) return MI_EINVAL;
   if (M == 0) return MI_OK;
+  if (head_stream_fits(M, N, K)) {
+    launch_head_stream<true>(x, w_packed, y, M, N, K, PickArgs{temperatures, rng, static_cast<uint2*>(candidates)},
+                             S(stream));
+    return check_launch();
+  }
   GemmArgs a{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)};
   a.pick = PickArgs{temperatures, rng, static_cast<uint2*>(candidates)};
   return pick_two_tiles(M, N) ? pick_mt<2, 1, EPI_PICK>(a) : pick_mt<1, 1, EPI_PICK>(a);

@@ -404,6 +404,153 @@ static __global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t*
   *reinterpret_cast<u32x4*>(dst + idx * 8) = v;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Head-sized GEMM (thousands of row tiles, K = WAVES * 32 * STEPS): persistent workgroups.
+//
+// gemm_skinny_kernel starts one short-lived workgroup per pair of row tiles; each re-fetches the whole x
+// (as many bytes as its weights) and pays its own ramp, LDS reduction and teardown - 4748 times for the
+// Qwen3 vocabulary.  Here a workgroup keeps its waves' x K-slices in REGISTERS (B fragments, loaded once) and
+// walks a contiguous share of the tile groups: per group every wave streams its K-slice of RT tiles (non-temporal,
+// 1 KiB per wave-load), multiplies, parks the partial sums in one of two LDS buffers (alternating: one barrier
+// per group), and the first RT * MT waves finish the group - sum over the waves in wave order, round, store, and with
+// PICK keep each row's best sampling key in registers - while the others already fetch the next group.
+// Summation order: one MFMA chain per wave over its slice, then the waves in order (deterministic).
+// ---------------------------------------------------------------------------------------------------
+template <int MT, int RT, int WAVES, int STEPS, bool PICK>
+__global__ __launch_bounds__(WAVES * 64) void head_stream_kernel(const uint16_t* __restrict__ x,
+                                                                 const uint16_t* __restrict__ w,
+                                                                 uint16_t* __restrict__ y, int M, int N, int K,
+                                                                 int n_groups, PickArgs pk) {
+  static_assert(RT * MT * 64 <= WAVES * 64, "one epilogue item per thread");
+  __shared__ __attribute__((aligned(16))) float red[2][WAVES][RT * MT][64][4];
+  __shared__ float pick_key[PICK ? MT * 16 : 1][RT * 4];
+  __shared__ int pick_col[PICK ? MT * 16 : 1][RT * 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int ktiles = K >> 5, kbeg = wave * 32 * STEPS;
+
+  // this wave's x slice as B fragments: lane (g, c) <- x[16 m + c][kbeg + 32 s + 8 g .. +8]; rows >= M are
+  // clamped to row M - 1 (MFMA output columns are independent, the duplicates are never stored)
+  u32x4 bfrag[MT][STEPS];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+      bfrag[m][s] = *reinterpret_cast<const u32x4*>(x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 32 * s + 8 * g);
+
+  // epilogue item of this thread (threads >= RT * MT * 64 have none): fixed (row tile t, m-tile, lane) -> fixed row
+  const int item = threadIdx.x;
+  const bool has_item = item < RT * MT * 64;
+  const int el = item & 63, em = (item >> 6) % MT, et = (item >> 6) / MT;
+  const int erow = 16 * em + (el & 15);
+  float best = -INFINITY;
+  int best_c = 0x7fffffff;
+  float inv_t = 1.0f;
+  bool noisy = false;
+  uint64_t rkey = 0;
+  if (PICK && has_item && erow < M) {
+    const float tmp = pk.temperatures ? pk.temperatures[erow] : 0.f;
+    noisy = tmp > 0.f;
+    inv_t = noisy ? 1.0f / tmp : 1.0f;
+    rkey = sample_row_key(pk.rng[0], pk.rng[1], erow);
+  }
+
+  const int first = (int)((int64_t)blockIdx.x * n_groups / gridDim.x);
+  const int last = (int)((int64_t)(blockIdx.x + 1) * n_groups / gridDim.x);
+  int par = 0;
+  for (int grp = first; grp < last; ++grp, par ^= 1) {
+    // (fetching the next group's fragments before this group's barrier measured slower: 62.3 vs 59.0 us)
+    u32x4 a[RT][STEPS];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+        a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(
+            w + ((int64_t)(grp * RT + t) * ktiles + (kbeg >> 5) + s) * 512 + lane * 8));
+    f32x4 acc[RT][MT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[t][s]), as_frag(bfrag[m][s]), acc[t][m], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(&red[par][wave][t * MT + m][lane][0]) = acc[t][m];
+    // everybody's sums of this group are in red[par]; the readers of red[par] from two groups ago passed the
+    // barrier of the previous group after finishing
+    __syncthreads();
+    if (has_item && erow < M) {
+      f32x4 sum = *reinterpret_cast<const f32x4*>(&red[par][0][et * MT + em][el][0]);
+#pragma unroll
+      for (int wv = 1; wv < WAVES; ++wv) sum += *reinterpret_cast<const f32x4*>(&red[par][wv][et * MT + em][el][0]);
+      const int col = (grp * RT + et) * 16 + 4 * (el >> 4);
+      u32x2 o;
+      o[0] = pack_bf(sum[0], sum[1]);
+      o[1] = pack_bf(sum[2], sum[3]);
+      *reinterpret_cast<u32x2*>(y + (int64_t)erow * N + col) = o;
+      if (PICK) {  // keys of the ROUNDED logits, as a sampler reading y would form them; ascending columns
+        const float v[4] = {lo_bf(o[0]), hi_bf(o[0]), lo_bf(o[1]), hi_bf(o[1])};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float key = noisy ? gumbel_key(v[i], inv_t, rkey, col + i) : v[i];
+          if (key > best || (key == best && col + i < best_c)) {
+            best = key;
+            best_c = col + i;
+          }
+        }
+      }
+    }
+  }
+  if (PICK) {
+    if (has_item) {
+      pick_key[erow][et * 4 + (el >> 4)] = erow < M ? best : -INFINITY;
+      pick_col[erow][et * 4 + (el >> 4)] = erow < M ? best_c : 0x7fffffff;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < M) {
+      const int row = threadIdx.x;
+      float b2 = pick_key[row][0];
+      int c2 = pick_col[row][0];
+#pragma unroll
+      for (int j = 1; j < RT * 4; ++j) {
+        const float k3 = pick_key[row][j];
+        const int c3 = pick_col[row][j];
+        if (k3 > b2 || (k3 == b2 && c3 < c2)) {
+          b2 = k3;
+          c2 = c3;
+        }
+      }
+      pk.cand[(int64_t)row * gridDim.x + blockIdx.x] = uint2{__float_as_uint(b2), (uint32_t)c2};
+    }
+  }
+}
+
+// shapes the persistent head kernel takes: bf16 weights, no bias, <= 32 rows, K = 1024, >= 2048 tile pairs
+static bool head_stream_fits(int M, int N, int K) { return M <= 32 && K == 1024 && N % 32 == 0 && N / 32 >= 2048; }
+// 1024 workgroups of 4-5 groups each (two resident per CU, two rounds: the dispatcher evens out the 4-vs-5 split);
+// measured 57.2 us against 60.2 (512), 61.4 (256), 63.0 (768), 60.4 (2374) at 151936 x 1024, 32 rows
+constexpr int kHeadStreamGrid = 1024;
+
+template <bool PICK>
+static void launch_head_stream(const uint16_t* x, const uint16_t* w, uint16_t* y, int M, int N, int K, PickArgs pk,
+                               hipStream_t st) {
+  const int grid = kHeadStreamGrid;
+  if (M <= 16)
+    hipLaunchKernelGGL((head_stream_kernel<1, 2, 8, 4, PICK>), dim3(grid), dim3(512), 0, st, x, w, y, M, N,
+                       K, N / 32, pk);
+  else
+    hipLaunchKernelGGL((head_stream_kernel<2, 2, 8, 4, PICK>), dim3(grid), dim3(512), 0, st, x, w, y, M, N,
+                       K, N / 32, pk);
+}
+
 struct GemmArgs {
   const uint16_t *x, *w, *bias;
   uint16_t* y;

@@ -94,7 +94,7 @@ _SIGNATURES = {
     "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),
     "mi_argmax": (c_int, [_p, c_int64, _p, c_int, c_int, _p]),
     "mi_sample": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_uint64, c_uint64, _p]),
-    "mi_gemm_pick_groups": (c_int, [c_int, c_int]),
+    "mi_gemm_pick_groups": (c_int, [c_int, c_int, c_int, c_int]),
     "mi_gemm_bf16_packed_pick": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p, _p, _p, _p]),
     "mi_gemm_fp8w_packed_pick": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p, _p, _p, _p]),
     "mi_pick_final": (c_int, [_p, c_int, c_int, _p, _p]),

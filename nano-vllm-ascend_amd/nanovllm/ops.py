@@ -482,7 +482,7 @@ def gemm_packed_pick(x, w_packed, temperatures, rng, out_tokens, logits=None, ca
     N = w_packed.shape[0]
     assert w_packed.shape[1] == K and out_tokens.numel() >= M
     assert temperatures is None or (temperatures.dtype == torch.float32 and temperatures.numel() >= M)
-    groups = lib.mi_gemm_pick_groups(M, N)
+    groups = lib.mi_gemm_pick_groups(M, N, K, int(isinstance(w_packed, Fp8Weight)))
     assert groups > 0
     if logits is None:
         logits = torch.empty((M, N), dtype=_BF16, device=x.device)
