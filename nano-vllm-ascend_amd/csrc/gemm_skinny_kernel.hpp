@@ -617,8 +617,10 @@ static int pick_waves(const GemmArgs& a) {
         case 2: return try_waves<MT, RT, 2, WF, EPI>(a);
         case 3: return try_waves<MT, RT, 3, WF, EPI>(a);
         case 4: return try_waves<MT, RT, 4, WF, EPI>(a);
+        case 5: return try_waves<MT, RT, 5, WF, EPI>(a);
         case 6: return try_waves<MT, RT, 6, WF, EPI>(a);
         case 8: return try_waves<MT, RT, 8, WF, EPI>(a);
+        case 10: return try_waves<MT, RT, 10, WF, EPI>(a);
         case 12: return try_waves<MT, RT, 12, WF, EPI>(a);
         case 16: return try_waves<MT, RT, 16, WF, EPI>(a);
         default: return false;
@@ -626,6 +628,9 @@ static int pick_waves(const GemmArgs& a) {
     };
     if (kper % 64 == 0 && kper / 64 <= 16) ok = by_waves(kper / 64);
     if (!ok && kper % 128 == 0) ok = by_waves(kper / 128 <= 16 ? kper / 128 : (kper / 128 == 24 ? 12 : 16));
+    // K = 5 * 2^n * 64 (3200 = a Qwen3-32B intermediate shard at TP 8, 640, 1280 ...): ten waves on 64-deep
+    // multiples; without them such a K fell through to four waves with ONE k-step in flight each
+    if (!ok && kper % 640 == 0) ok = by_waves(10);
   }
   if (!ok) ok = try_waves<MT, RT, 8, WF, EPI>(a) || try_waves<MT, RT, 4, WF, EPI>(a) ||
                 try_waves<MT, RT, 2, WF, EPI>(a) || try_waves<MT, RT, 1, WF, EPI>(a);

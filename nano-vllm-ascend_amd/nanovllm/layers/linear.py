@@ -154,8 +154,10 @@ class RowParallelLinear(LinearBase):
         # tensor parallelism, bf16 weights: a second decode layout whose GEMM returns this rank's partial
         # sums as complete bf16 rows from N/4 workgroups (mi_gemm_bf16_rows4)
         w = self.weight.data
+        # complete rows from four-feature workgroups pay off while N is too small to fill the CUs with
+        # 16-feature row tiles (N = 1024: 64 tiles); at N = 5120 the packed kernel is 1.6-2.2x faster
         if self.tp_size > 1 and w.is_cuda and not isinstance(self.weight_packed, ops.Fp8Weight) \
-                and w.shape[0] % 4 == 0 and w.shape[1] % 32 == 0:
+                and w.shape[0] % 4 == 0 and w.shape[1] % 32 == 0 and w.shape[0] // 16 < 256:
             self.weight_rows4 = ops.pack_weight_rows4(w, self.weight_rows4)
         else:
             self.weight_rows4 = None

@@ -236,7 +236,7 @@ class Qwen3Model(nn.Module):
 
         def row_parallel(x, lin):
             """-> (tensor, is_partials): bf16 rows, or fp32 split-K partials for add_rmsnorm_splitk"""
-            if rows4:
+            if rows4 and lin.weight_rows4 is not None:
                 y = ops.gemm_rows4(x, lin.weight_rows4)
             elif tp == 1:
                 return ops.gemm_packed_splitk(x, lin.weight_packed, self._ksplit(lin.weight)), True

@@ -114,10 +114,9 @@ def chain_32b_shard():
     H, hq, hkv, inter, B, L = 5120, 8, 1, 25600 // 8, 32, 4
     mk = lambda n, k: ops.pack_weight((torch.randn(n, k, device=DEV) * 0.02).bfloat16())  # noqa: E731
     qkv = [mk((hq + 2 * hkv) * 128, H) for _ in range(L)]
-    mk4 = lambda n, k: ops.pack_weight_rows4((torch.randn(n, k, device=DEV) * 0.02).bfloat16())  # noqa: E731
-    o = [mk4(H, hq * 128) for _ in range(L)]  # row-parallel projections: complete bf16 rows per rank (TP path)
-    gu = [mk(2 * inter, H) for _ in range(L)]
-    dn = [mk4(H, inter) for _ in range(L)]
+    o = [mk(H, hq * 128) for _ in range(L)]  # row-parallel projections: complete bf16 rows per rank (TP path);
+    gu = [mk(2 * inter, H) for _ in range(L)]  # N = 5120 has enough row tiles for the packed kernel (layers/linear.py)
+    dn = [mk(H, inter) for _ in range(L)]
     wn = torch.ones(H, device=DEV).bfloat16()
     x = torch.randn(B, H, device=DEV).bfloat16()
     attn_out = torch.randn(B, hq * 128, device=DEV).bfloat16()
@@ -126,10 +125,10 @@ def chain_32b_shard():
     def layer(l):
         xn, r = ops.add_rmsnorm(x, res_, wn, 1e-6)
         ops.gemm_packed(xn, qkv[l])
-        y = ops.gemm_rows4(attn_out, o[l])
+        y = ops.gemm_packed(attn_out, o[l])
         xn, r = ops.add_rmsnorm(y, r, wn, 1e-6)
         a = ops.gemm_packed(xn, gu[l], silu_mul=True)
-        ops.gemm_rows4(a, dn[l])
+        ops.gemm_packed(a, dn[l])
 
     byt = ((hq + 2 * hkv) * 128 * H + H * hq * 128 + 2 * inter * H + H * inter) * 2
     t = timeit(layer, L, reps=3)
