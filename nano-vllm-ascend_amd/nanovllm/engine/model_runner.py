@@ -76,11 +76,17 @@ class ModelRunner:
             kw = {"device_id": self.device} if backend == "nccl" else {}
             dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{config.hccl_port}",
                                     world_size=self.world_size, rank=rank, **kw)
+        from nanovllm.layers import parallel
+
+        # the TP group is what Config says, not whatever process group happens to exist: independent replicas
+        # (bench.py --mode replicas) share a default group only for their barrier
+        parallel.set_tp(rank if self.world_size > 1 else 0, self.world_size)
+        parallel.set_xgmi_comm(None)
         self.channel = StepChannel(config.hccl_port, self.world_size, rank) if self.world_size > 1 else None
         self.xgmi = None
         self._steps_run = 0
         if self.world_size > 1:
-            from nanovllm.layers import parallel, xgmi_comm
+            from nanovllm.layers import xgmi_comm
 
             rows = max(64, min(config.max_num_seqs, 512))  # decode-sized activations; prefill goes through RCCL
             self.xgmi = xgmi_comm.create_if_enabled(rank, self.world_size, rows * self.hf_config.hidden_size * 2,
@@ -152,6 +158,9 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ lifecycle / RPC
     def exit(self):
+        from nanovllm.layers import parallel
+
+        parallel.reset_tp()
         self.graphs.clear()
         self.graph_logits.clear()
         torch.cuda.synchronize()

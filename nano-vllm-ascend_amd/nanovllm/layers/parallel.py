@@ -9,11 +9,32 @@ from __future__ import annotations
 import torch.distributed as dist
 
 
+_tp: tuple[int, int] | None = None  # (rank, size) of the tensor-parallel group once the runner has declared it
+
+
+def set_tp(rank: int, size: int) -> None:
+    """Declared by ModelRunner from Config.tensor_parallel_size.  A process group may exist WITHOUT tensor
+    parallelism (bench.py --mode replicas: N independent engines that only meet in a barrier), so the size
+    of the default group says nothing about how the layers are sharded."""
+    global _tp
+    assert 0 <= rank < size
+    _tp = (rank, size)
+
+
+def reset_tp() -> None:
+    global _tp
+    _tp = None
+
+
 def tp_rank() -> int:
+    if _tp is not None:
+        return _tp[0]
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def tp_size() -> int:
+    if _tp is not None:
+        return _tp[1]
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 

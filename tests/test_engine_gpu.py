@@ -1,6 +1,8 @@
 """End-to-end GPU parity: the engine (scheduler -> runner -> HIP kernels, eager prefill and
 hipGraph decode) against (a) the golden greedy run recorded from the reference's own
 model/scheduler classes and (b) the CPU oracle model on identical weights and inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -476,3 +478,30 @@ def test_full_size_properties_paging_invariance_and_decode_equals_reprefill():
         assert worst <= 8e-2, worst
     finally:
         llm.exit()
+
+
+@pytest.mark.parametrize("mode", ["replicas", "tp"])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per "GPU" - here both on
+    cuda:0, gloo instead of RCCL): the default mode runs N independent engines whose layers are NOT sharded
+    although a process group exists; --mode tp shards one model.  One JSON line with the contract's fields."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_NO_WARMUP="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--mode", mode]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "tokens/s"
+    assert d["mode"] == mode and d["scaling"] == ("weak" if mode == "replicas" else "strong")
+    assert d["config"]["global_batch"] == (64 if mode == "replicas" else 32)

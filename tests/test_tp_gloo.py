@@ -242,3 +242,30 @@ def test_tp2_rpc_channel():
 
 def test_tp2_replicated_metadata():
     _run("_body_replicated_scheduling")
+
+
+def _body_replicas_are_not_tensor_parallel(rank, world, port):
+    """A default process group without tensor parallelism (bench.py --mode replicas): once the runner has declared
+    the TP group (size 1), the layers are whole and never call a collective - whatever the world size says."""
+    from nanovllm.layers import parallel
+    from nanovllm.layers.linear import QKVParallelLinear, RowParallelLinear
+    from nanovllm.layers.embed_head import VocabParallelEmbedding
+
+    assert parallel.tp_size() == world and parallel.tp_rank() == rank  # undeclared: the default group
+    parallel.set_tp(0, 1)
+    try:
+        assert parallel.tp_size() == 1 and parallel.tp_rank() == 0
+        qkv = QKVParallelLinear(64, 16, 4, 2)
+        assert qkv.weight.shape == ((4 + 2 * 2) * 16, 64)
+        assert RowParallelLinear(64, 32).weight.shape == (32, 64)
+        emb = VocabParallelEmbedding(128, 32)
+        assert emb.weight.shape == (128, 32) and (emb.vocab_start_idx, emb.vocab_end_idx) == (0, 128)
+        t = torch.ones(4)
+        assert parallel.all_reduce_sum(t) is t and float(t.sum()) == 4.0  # no collective
+    finally:
+        parallel.reset_tp()
+    assert parallel.tp_size() == world
+
+
+def test_replica_processes_share_a_group_but_not_their_layers():
+    _run("_body_replicas_are_not_tensor_parallel")
