@@ -113,6 +113,7 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
   const int64_t off = (int64_t)row * cols;
   constexpr int MAXV = 2;  // vectors per lane: cols <= WPR * 64 * 8 * MAXV
   float v[MAXV][8];
+  u32x4 wr[MAXV];  // the norm weight is fetched with everything else, not behind the barrier
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
         phi[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
       }
       const u32x4 rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
+      wr[i] = *reinterpret_cast<const u32x4*>(w + vec * 8);
       f32x4 lo = plo[0], hi = phi[0];
 #pragma unroll
       for (int sp = 1; sp < PART; ++sp) {
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
       }
       *reinterpret_cast<u32x4*>(residual_out + off + vec * 8) = ro;
     } else {
+      wr[i] = u32x4{0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
     }
@@ -161,17 +164,71 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
   for (int i = 0; i < MAXV; ++i) {
     const int vec = tid + i * WPR * 64;
     if (vec < nvec) {
-      const u32x4 wr = *reinterpret_cast<const u32x4*>(w + vec * 8);
       u32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = rbf(v[i][2 * j] * rs) * lo_bf(wr[j]);
-        const float b = rbf(v[i][2 * j + 1] * rs) * hi_bf(wr[j]);
+        const float a = rbf(v[i][2 * j] * rs) * lo_bf(wr[i][j]);
+        const float b = rbf(v[i][2 * j + 1] * rs) * hi_bf(wr[i][j]);
         o[j] = pack_bf(a, b);
       }
       *reinterpret_cast<u32x4*>(y + off + vec * 8) = o;
     }
   }
+}
+
+// The same for rows of at most WPR * 64 * 4 columns (hidden 1024 with four waves): FOUR columns per thread, so
+// that every thread of the workgroup has work - PART + 2 loads per lane, all issued before the first use.
+// Same arithmetic and summation order per element; the sum of squares adds the lanes' partial sums in a
+// different grouping than the 8-wide form (both are fp32 sums of the same squares).
+template <int PART, int WPR>
+__global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
+    const float* __restrict__ part, const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
+    uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows, int cols, float eps) {
+  __shared__ float wave_ss[WPR];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = cols >> 2;
+  const int64_t off = (int64_t)row * cols;
+  const bool on = tid < nvec;
+  const int vec = on ? tid : 0;
+  f32x4 p[PART];
+#pragma unroll
+  for (int sp = 0; sp < PART; ++sp)
+    p[sp] = *reinterpret_cast<const f32x4*>(part + ((int64_t)sp * rows + row) * cols + vec * 4);
+  const u32x2 rr = *reinterpret_cast<const u32x2*>(residual + off + vec * 4);
+  const u32x2 wr = *reinterpret_cast<const u32x2*>(w + vec * 4);
+  f32x4 s = p[0];
+#pragma unroll
+  for (int sp = 1; sp < PART; ++sp) s += p[sp];
+  const u32x2 raw = {pack_bf(s[0], s[1]), pack_bf(s[2], s[3])};
+  float v[4];
+  u32x2 ro;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float a = lo_bf(raw[j]) + lo_bf(rr[j]);
+    const float b = hi_bf(raw[j]) + hi_bf(rr[j]);
+    ro[j] = pack_bf(a, b);
+    v[2 * j] = a;
+    v[2 * j + 1] = b;
+    ss += a * a;
+    ss += b * b;
+  }
+  if (on) *reinterpret_cast<u32x2*>(residual_out + off + vec * 4) = ro;
+  ss = wave_sum(on ? ss : 0.f);
+  if (lane == 0) wave_ss[wave] = ss;
+  __syncthreads();
+  float tot = wave_ss[0];
+#pragma unroll
+  for (int wv = 1; wv < WPR; ++wv) tot += wave_ss[wv];
+  const float rs = 1.0f / sqrtf(tot / (float)cols + eps);
+  u32x2 o;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float a = rbf(v[2 * j] * rs) * lo_bf(wr[j]);
+    const float b = rbf(v[2 * j + 1] * rs) * hi_bf(wr[j]);
+    o[j] = pack_bf(a, b);
+  }
+  if (on) *reinterpret_cast<u32x2*>(y + off + vec * 4) = o;
 }
 
 template <bool ADD, int PART = 0>
@@ -633,8 +690,14 @@ extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi
     const char* e = getenv("MI355_NORM_WPR");
     return e ? atoi(e) : 4;
   }();
+  constexpr bool narrow = true;  // four columns per thread when the row fits (24.2 vs 24.5 us per layer chain)
 #define SPLITK_CASE(NS)                                                                                       \
   case NS:                                                                                                    \
+    if (rows <= 64 && wpr == 4 && narrow && cols <= 4 * 64 * 4 && cols % 4 == 0) {                            \
+      hipLaunchKernelGGL((add_rmsnorm_splitk_rows4_kernel<NS, 4>), dim3(rows), dim3(256), 0, S(stream),        \
+                         partials, residual, w, y, residual_out, rows, cols, eps);                            \
+      return check_launch();                                                                                  \
+    }                                                                                                         \
     if (rows <= 64 && wpr == 4 && cols <= 4 * 64 * 8 * 2) {                                                   \
       hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<NS, 4>), dim3(rows), dim3(256), 0, S(stream),         \
                          partials, residual, w, y, residual_out, rows, cols, eps);                            \
