@@ -173,6 +173,18 @@ int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride,
                           int n_q_heads, int n_kv_heads, int head_dim,
                           int block_size, float scale, mi_stream stream);
 
+/* The same with the query side of qwen3.py:79-88 folded into the Q-operand load: q points at the RAW packed qkv
+ * rows (linear.py:117-126); per-head RMSNorm with q_w (NULL: no norm) and NeoX RoPE at positions[token] are
+ * applied in registers, bit-identical to what mi_qknorm_rope_store writes to q_out.  K and V must already be in
+ * the cache: call mi_qknorm_rope_store with q_out = NULL (K / V only) first. */
+int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
+                                const int64_t* positions, const float* cos_sin,
+                                const mi_bf16* k_cache, const mi_bf16* v_cache,
+                                const int32_t* block_table, int table_stride,
+                                const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
+                                int head_dim, int block_size, float scale, mi_stream stream);
+
 /* ---- normalisation (reference: layers/layernorm.py) ----------------------- */
 /* RMSNorm.rms_forward (layernorm.py:16-25):
  *   y = bf16( bf16(x32 * rsqrt(mean(x32^2)+eps)) * w )   — two roundings.
@@ -209,7 +221,9 @@ int mi_rope(const int64_t* positions, const float* cos_sin,
  * the unfused sequence mi_rmsnorm -> mi_rope -> mi_reshape_and_cache /
  * mi_scatter_update_kv, so results are bit-identical to it.
  * q_w/k_w may be NULL (attention_bias=true models skip the norms, qwen3.py:70).
- * slots: flat [n_tokens] if slot_is_2d == 0, else [n_tokens][2]. */
+ * slots: flat [n_tokens] if slot_is_2d == 0, else [n_tokens][2].
+ * q_out may be NULL for prefill-sized calls (flat slots, n_tokens >= 64): only K and V are processed and
+ * mi_paged_attn_prefill_fused prepares the queries itself. */
 int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride,
                          const mi_bf16* q_w, const mi_bf16* k_w, float eps,
                          const int64_t* positions, const float* cos_sin,

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(128) void qkv_prefill_store_kernel(
       }
     }
   }
-  // ---- Q: the G heads of this kv head (output rows are contiguous: coalesced as they are)
+  // ---- Q: the G heads of this kv head (output rows are contiguous: coalesced as they are);
+  //         q_out == nullptr: the attention kernel prepares Q itself (mi_paged_attn_prefill_fused)
+  if (q_out == nullptr) return;
   for (int g = 0; g < G; ++g) {
     const int hq = h * G + g;
     load16(row + hq * 128 + 8 * j, a);
@@ -794,12 +796,12 @@ extern "C" int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride, 
                                     const float* cos_sin, mi_bf16* q_out, mi_bf16* k_cache, mi_bf16* v_cache,
                                     const int32_t* slots, int slot_is_2d, int n_tokens, int n_q_heads,
                                     int n_kv_heads, int head_dim, int block_size, mi_stream stream) {
-  if (!qkv || !positions || !cos_sin || !q_out || !k_cache || !v_cache || !slots || n_tokens < 0)
-    return MI_EINVAL;
+  if (!qkv || !positions || !cos_sin || !k_cache || !v_cache || !slots || n_tokens < 0) return MI_EINVAL;
+  if (!q_out && (slot_is_2d || n_tokens < 64)) return MI_EINVAL;  // K/V-only is the prefill tile kernel's mode
   if ((q_w == nullptr) != (k_w == nullptr)) return MI_EINVAL;
   if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16 || qkv_row_stride % 8)
     return MI_EUNSUPPORTED;
-  if (!aligned16(qkv) || !aligned16(q_out) || !aligned16(k_cache) || !aligned16(v_cache) ||
+  if (!aligned16(qkv) || (q_out && !aligned16(q_out)) || !aligned16(k_cache) || !aligned16(v_cache) ||
       !aligned16(cos_sin) || (q_w && (!aligned16(q_w) || !aligned16(k_w))))
     return MI_EINVAL;
   if (n_tokens == 0) return MI_OK;

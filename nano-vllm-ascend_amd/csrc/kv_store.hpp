@@ -116,6 +116,57 @@ __device__ __forceinline__ void head_rope_frag(float (&x)[4][8], const float* cs
   }
 }
 
+// ---- and on the 32x32-MFMA B-operand distribution of the prefill attention's Q --------------------
+// Two lanes hi = 0 / 1 (lane ids n and n + 32) hold one head: lane hi owns dims 16 kk + 8 hi + e (kk < 8, e < 8)
+// in x[kk][e], i.e. the 8-dim groups 2 kk + hi.  Group j < 8 is the 8-lane form's a of lane j, group 8 + j its b:
+// lane hi holds (a, b) = (x[m], x[m + 4]) of the 8-lane lanes j = 2 m + hi.  Sums are associated as head_rmsnorm's
+// (per lane a then b, then the xor-1 / 2 / 4 tree: the xor-1 partner sits in the other lane), so the bits agree.
+__device__ __forceinline__ void head_rmsnorm_rope_q32(float (&x)[8][8], const uint16_t* w, const float* cs, int hi,
+                                                      float eps) {
+#pragma clang fp contract(off)
+  if (w != nullptr) {
+    float t[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += x[m][i] * x[m][i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += x[m + 4][i] * x[m + 4][i];
+      t[m] = ss + __shfl_xor(ss, 32, 64);  // s_(2m) + s_(2m+1)
+    }
+    const float ss = (t[0] + t[1]) + (t[2] + t[3]);
+    const float rs = 1.0f / sqrtf(ss / 128.0f + eps);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float wa[8], wb[8];
+      load16(w + 8 * (2 * m + hi), wa);
+      load16(w + 64 + 8 * (2 * m + hi), wb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[m][i] = rbf(rbf(x[m][i] * rs) * wa[i]);
+        x[m + 4][i] = rbf(rbf(x[m + 4][i] * rs) * wb[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float* cp = cs + 8 * (2 * m + hi);
+    const float4 c0 = *reinterpret_cast<const float4*>(cp);
+    const float4 c1 = *reinterpret_cast<const float4*>(cp + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(cp + 64);
+    const float4 s1 = *reinterpret_cast<const float4*>(cp + 68);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x1 = x[m][i], x2 = x[m + 4][i];
+      x[m][i] = rbf(x1 * c[i] - x2 * sn[i]);
+      x[m + 4][i] = rbf(x2 * c[i] + x1 * sn[i]);
+    }
+  }
+}
+
 __device__ __forceinline__ bool resolve_slot(const int32_t* slots, int slot_is_2d, int token,
                                              int block_size, int64_t& blk, int& off) {
   if (slot_is_2d) {

@@ -614,12 +614,21 @@ __device__ __forceinline__ float xor32_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int G, bool SPLIT_P>
+// FUSE_Q: q points at the RAW q heads of the packed qkv rows; q-norm (if q_w) and RoPE are applied while the Q
+// operand is loaded (the separate mi_qknorm_rope_store then handles K and V only and never writes q)
+struct QPrep {
+  const uint16_t* q_w;
+  const int64_t* positions;
+  const float* cos_sin;
+  float eps;
+};
+
+template <int G, bool SPLIT_P, bool FUSE_Q>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ kv_lens, uint16_t* __restrict__ out,
-    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e, int n_qblocks, int n_pairs) {
+    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
   constexpr int TQ = 32 / G;        // query tokens per wave
   constexpr int TQ_WG = 4 * TQ;     // per workgroup
   constexpr int NBUF = 3;           // LDS ring: chunk c is computed while c+1 and c+2 are landing
@@ -656,12 +665,25 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   bf16x8 Q[8];  // B operand of S^T = K . Q^T: column n, dims 16 kk + 8 hi .. +7
   {
     const int row = valid ? my_qt : wg_qt0;  // invalid columns read a valid row and are zeroed
-    const uint16_t* qp = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * hi;
+    const uint16_t* qrow = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * hi;
+    if (FUSE_Q) {
+      float xq[8][8];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * kk);
-      if (!valid) v = u32x4{0, 0, 0, 0};
-      Q[kk] = as_frag(v);
+      for (int kk = 0; kk < 8; ++kk) load16(qrow + 16 * kk, xq[kk]);
+      head_rmsnorm_rope_q32(xq, qp.q_w, qp.cos_sin + qp.positions[q_start + row] * 128, hi, qp.eps);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        u32x4 v = pack16(xq[kk]);
+        if (!valid) v = u32x4{0, 0, 0, 0};
+        Q[kk] = as_frag(v);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(qrow + 16 * kk);
+        if (!valid) v = u32x4{0, 0, 0, 0};
+        Q[kk] = as_frag(v);
+      }
     }
   }
   float m = -INFINITY, l = 0.f;  // running max (log2 domain) and this lane's share of the running sum
@@ -919,11 +941,11 @@ extern "C" int mi_paged_attn_decode_ex(const mi_bf16* q, int64_t q_row_stride, c
                      KvStrides{stride_block, stride_head, stride_tile}, stream);
 }
 
-extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
-                                     const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
-                                     const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
-                                     int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
-                                     int head_dim, int block_size, float scale, mi_stream stream) {
+static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* prep, const mi_bf16* k_cache,
+                        const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                        const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs, int max_seqlen_q,
+                        mi_bf16* out, int n_q_heads, int n_kv_heads, int head_dim, int block_size, float scale,
+                        mi_stream stream) {
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -938,10 +960,18 @@ extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, con
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = S(stream);
   constexpr bool kSplitP = MI_PREFILL_SPLIT_P;
-#define LAUNCH_PRE(GG)                                                                                       \
-  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,      \
-                     v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads, n_kv_heads, \
-                     block_size / 16, sl2, n_qblocks, n_pairs)
+  const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
+#define LAUNCH_PRE(GG)                                                                                          \
+  do {                                                                                                          \
+    if (prep)                                                                                                   \
+      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true>), grid, dim3(256), 0, st, q, q_row_stride, \
+                         k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads,     \
+                         n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                             \
+    else                                                                                                        \
+      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, false>), grid, dim3(256), 0, st, q,             \
+                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
+                         n_q_heads, n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                  \
+  } while (0)
   switch (G) {
     case 1: LAUNCH_PRE(1); break;
     case 2: LAUNCH_PRE(2); break;
@@ -951,4 +981,25 @@ extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, con
   }
 #undef LAUNCH_PRE
   return check_launch();
+}
+
+extern "C" int mi_paged_attn_prefill(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                                     const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                     const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                     int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
+                                     int head_dim, int block_size, float scale, mi_stream stream) {
+  return prefill_impl(q, q_row_stride, nullptr, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
+                      n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream);
+}
+
+extern "C" int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
+                                           const int64_t* positions, const float* cos_sin, const mi_bf16* k_cache,
+                                           const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                           const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                           int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
+                                           int head_dim, int block_size, float scale, mi_stream stream) {
+  if (!positions || !cos_sin || !aligned16(cos_sin) || (q_w && !aligned16(q_w))) return MI_EINVAL;
+  const QPrep prep{q_w, positions, cos_sin, eps};
+  return prefill_impl(qkv, qkv_row_stride, &prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
+                      n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream);
 }

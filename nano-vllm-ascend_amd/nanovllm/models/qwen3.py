@@ -91,6 +91,19 @@ class Qwen3Attention(nn.Module):
             rope.cos_sin_cache = rope.cos_sin_cache.to(qkv.device)
         qw = self.q_norm.weight if self.qk_norm else None
         kw = self.k_norm.weight if self.qk_norm else None
+        if ctx.is_prefill and qkv.shape[0] >= 64 and os.environ.get("MI355_PREFILL_FUSED_Q", "1") != "0":
+            # prefill-sized: K / V go to the cache (whole tiles), the queries are normed and rotated inside the
+            # attention kernel's Q-operand load - q is never written to and read back from HBM
+            ops.qknorm_rope_store(qkv, qw, kw, self.rms_norm_eps, positions, rope.cos_sin_cache, attn.k_cache,
+                                  attn.v_cache, ctx.slot_mapping, self.num_heads, self.num_kv_heads,
+                                  ctx.block_size, store_q=False)
+            kv_lens = ctx.kv_lens
+            if kv_lens is None:
+                kv_lens = (ctx.cu_seqlens_k[1:] - ctx.cu_seqlens_k[:-1]).contiguous()
+            return ops.paged_attn_prefill_fused(qkv, qw, self.rms_norm_eps, positions, rope.cos_sin_cache,
+                                                attn.k_cache, attn.v_cache, ctx.block_tables, ctx.cu_seqlens_q,
+                                                kv_lens, ctx.max_seqlen_q, self.num_heads, self.num_kv_heads,
+                                                ctx.block_size, attn.scale)
         q = ops.qknorm_rope_store(qkv, qw, kw, self.rms_norm_eps, positions, rope.cos_sin_cache, attn.k_cache,
                                   attn.v_cache, ctx.slot_mapping, self.num_heads, self.num_kv_heads,
                                   ctx.block_size)

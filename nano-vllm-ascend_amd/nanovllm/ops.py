@@ -152,6 +152,31 @@ def paged_attn_prefill(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens,
     return out
 
 
+def paged_attn_prefill_fused(qkv, q_w, eps: float, positions, cos_sin, k_cache, v_cache, block_tables, cu_seqlens_q,
+                             kv_lens, max_seqlen_q: int, n_q_heads: int, n_kv_heads: int, block_size: int, scale: float,
+                             out=None) -> torch.Tensor:
+    """paged_attn_prefill over the RAW q heads of the packed qkv rows: q-norm (q_w may be None) + RoPE happen in
+    the kernel's Q-operand load.  K / V must already be cached (qknorm_rope_store(..., store_q=False))."""
+    require_gpu(qkv, positions, cos_sin, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
+    _bf16(qkv, k_cache, v_cache)
+    T = qkv.shape[0]
+    assert qkv.stride(1) == 1 and qkv.shape[1] == (n_q_heads + 2 * n_kv_heads) * HEAD_DIM
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == T
+    assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert cu_seqlens_q.dtype == torch.int32 and kv_lens.dtype == torch.int32
+    n_seqs = cu_seqlens_q.numel() - 1
+    if out is None:
+        out = torch.empty((T, n_q_heads * HEAD_DIM), dtype=_BF16, device=qkv.device)
+    check(
+        lib.mi_paged_attn_prefill_fused(ptr(qkv), qkv.stride(0), ptr(q_w), float(eps), ptr(positions), ptr(cos_sin),
+                                        ptr(k_cache), ptr(v_cache), ptr(block_tables), block_tables.stride(0),
+                                        ptr(cu_seqlens_q), ptr(kv_lens), n_seqs, int(max_seqlen_q), ptr(out),
+                                        n_q_heads, n_kv_heads, HEAD_DIM, block_size, float(scale), stream()),
+        "mi_paged_attn_prefill_fused",
+    )
+    return out
+
+
 # --------------------------------------------------------------------------- norms
 def rmsnorm(x, w, eps: float, out=None) -> torch.Tensor:
     """x: [rows, cols] (contiguous rows) or [T, H, cols] with arbitrary token stride."""
@@ -214,7 +239,9 @@ def rope(positions, q, k, cos_sin, n_q_heads: int, n_kv_heads: int):
 
 
 def qknorm_rope_store(qkv, q_w, k_w, eps: float, positions, cos_sin, k_cache, v_cache, slots,
-                      n_q_heads: int, n_kv_heads: int, block_size: int, q_out=None) -> torch.Tensor:
+                      n_q_heads: int, n_kv_heads: int, block_size: int, q_out=None, store_q: bool = True):
+    """store_q=False (prefill-sized calls only): K and V go to the cache, the queries are left to
+    paged_attn_prefill_fused; returns None."""
     require_gpu(qkv, positions, cos_sin, k_cache, v_cache, slots)
     _bf16(qkv, k_cache, v_cache)
     T = qkv.shape[0]
@@ -222,7 +249,9 @@ def qknorm_rope_store(qkv, q_w, k_w, eps: float, positions, cos_sin, k_cache, v_
     assert positions.dtype == torch.int64 and positions.is_contiguous()
     assert slots.dtype == torch.int32 and slots.is_contiguous()
     is2d = int(slots.dim() == 2)
-    if q_out is None:
+    if not store_q:
+        q_out = None
+    elif q_out is None:
         q_out = torch.empty((T, n_q_heads * HEAD_DIM), dtype=_BF16, device=qkv.device)
     check(
         lib.mi_qknorm_rope_store(ptr(qkv), qkv.stride(0), ptr(q_w), ptr(k_w), float(eps), ptr(positions),

@@ -598,6 +598,52 @@ def test_prefill_attention_random(ops, hq, hkv, block_size):
     assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
 
 
+@pytest.mark.parametrize("hq,hkv,with_norm", [(16, 8, True), (8, 1, True), (4, 4, False), (16, 1, True)])
+def test_prefill_attention_with_q_prepared_in_the_kernel(ops, hq, hkv, with_norm):
+    """mi_paged_attn_prefill_fused (q-norm + RoPE inside the Q-operand load, K / V-only store before it) against
+    the two-launch sequence mi_qknorm_rope_store -> mi_paged_attn_prefill on the same packed qkv rows: identical
+    bits (the in-kernel norm associates its sums like the 8-lane kernel), ragged lengths, one sequence with a
+    cached prefix (queries start behind it: positions != row index), caches compared too."""
+    gen = torch.Generator().manual_seed(hq * 3 + hkv)
+    bs = 16
+    q_lens = [64, 7, 129, 33, 260, 80]
+    prefix = [0, 0, 64, 0, 0, 16]  # tokens already in the cache (whole blocks), prefix-aware prefill
+    kv_lens = [a + b for a, b in zip(q_lens, prefix)]
+    T, n_seqs = sum(q_lens), len(q_lens)
+    nb = [-(-n // bs) for n in kv_lens]
+    perm = torch.randperm(sum(nb) + 3, generator=gen)[: sum(nb)].to(torch.int32)
+    bt = torch.full((n_seqs, max(nb)), -1, dtype=torch.int32)
+    o = 0
+    for i, n in enumerate(nb):
+        bt[i, :n] = perm[o:o + n]
+        o += n
+    pos = torch.cat([torch.arange(p, p + n) for p, n in zip(prefix, q_lens)]).to(torch.int64)
+    slots = torch.cat([bt[i, (torch.arange(p, p + n) // bs)].to(torch.int64) * bs + torch.arange(p, p + n) % bs
+                       for i, (p, n) in enumerate(zip(prefix, q_lens))]).to(torch.int32)
+    qkv = (torch.randn(T, (hq + 2 * hkv) * 128, generator=gen) * 1.5).bfloat16().to(DEV)
+    qw = (1 + 0.2 * torch.randn(128, generator=gen)).bfloat16().to(DEV) if with_norm else None
+    kw = (1 + 0.2 * torch.randn(128, generator=gen)).bfloat16().to(DEV) if with_norm else None
+    table = oracle.build_cos_sin_cache(128, 4096, 1e6).to(DEV)
+    shape = ops.kv_cache_shape(sum(nb) + 3, hkv, bs)
+    base_k = torch.randn(shape, generator=gen).bfloat16().to(DEV)  # the cached prefixes' (random) contents
+    base_v = torch.randn(shape, generator=gen).bfloat16().to(DEV)
+    cu = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32).to(DEV)
+    kvl = torch.tensor(kv_lens, dtype=torch.int32).to(DEV)
+    posd, slotsd, btd = pos.to(DEV), slots.to(DEV), bt.to(DEV)
+    scale = 1.0 / math.sqrt(128)
+    kc1, vc1 = base_k.clone(), base_v.clone()
+    q1 = ops.qknorm_rope_store(qkv, qw, kw, 1e-6, posd, table, kc1, vc1, slotsd, hq, hkv, bs)
+    want = ops.paged_attn_prefill(q1, kc1, vc1, btd, cu, kvl, max(q_lens), hq, hkv, bs, scale)
+    kc2, vc2 = base_k.clone(), base_v.clone()
+    assert ops.qknorm_rope_store(qkv, qw, kw, 1e-6, posd, table, kc2, vc2, slotsd, hq, hkv, bs, store_q=False) is None
+    got = ops.paged_attn_prefill_fused(qkv, qw, 1e-6, posd, table, kc2, vc2, btd, cu, kvl, max(q_lens), hq, hkv, bs,
+                                       scale)
+    assert torch.equal(kc1.view(torch.int16), kc2.view(torch.int16))
+    assert torch.equal(vc1.view(torch.int16), vc2.view(torch.int16))
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert float(got.float().abs().max()) > 0.1
+
+
 # --------------------------------------------------------------------------- gathers / sampling
 def test_embedding_and_last_token(ops):
     g = torch.Generator().manual_seed(2)
