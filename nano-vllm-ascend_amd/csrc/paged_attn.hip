@@ -662,30 +662,6 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const int wave_chunks = wave_on ? (shift + min(qt0 + TQ, q_len) - 1 + 32) >> 5 : 0;
   const int limit_all = wave_on && qt0 + TQ <= q_len ? shift + qt0 + 1 : 0;  // earliest column of a full block
 
-  // cooperative fetch by LDS-DMA (global_load_lds_dwordx4): piece = wave (K0, K1, V0, V1), four
-  // 1 KiB rows of the 4 KiB cache tile per wave, each lane's 16 bytes landing at row + 16 * lane -
-  // the cache tile is copied as it is stored, no registers and no ds_write involved
-  const int32_t* table_row = block_table + (int64_t)seq * table_stride;
-  const KvStrides st = default_strides(n_kv_heads, tpb);
-  const int piece = wave;
-  auto issue = [&](int c) {
-    c = min(c, wg_chunks - 1);  // past the end: re-load the last chunk into a buffer nobody reads (keeps vmcnt uniform)
-    const int tile0 = 2 * c;
-    const int tile = (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
-    const int blk = table_row[tile / tpb];
-    const uint16_t* src = ((piece & 2) ? vc : kc) + (int64_t)blk * st.block + (int64_t)h * st.head +
-                          (int64_t)(tile % tpb) * st.tile + lane * 8;
-    uint16_t* dst = &stage[c % NBUF][piece][0];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
-                                       (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
-  };
-
-  // the first two chunks fly while the Q operand is fetched (and, FUSE_Q, normed and rotated)
-  issue(0);
-  issue(1);
-
   bf16x8 Q[8];  // B operand of S^T = K . Q^T: column n, dims 16 kk + 8 hi .. +7
   {
     const int row = valid ? my_qt : wg_qt0;  // invalid columns read a valid row and are zeroed
@@ -717,12 +693,34 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
+  // cooperative fetch by LDS-DMA (global_load_lds_dwordx4): piece = wave (K0, K1, V0, V1), four
+  // 1 KiB rows of the 4 KiB cache tile per wave, each lane's 16 bytes landing at row + 16 * lane -
+  // the cache tile is copied as it is stored, no registers and no ds_write involved
+  const int32_t* table_row = block_table + (int64_t)seq * table_stride;
+  const KvStrides st = default_strides(n_kv_heads, tpb);
+  const int piece = wave;
+  auto issue = [&](int c) {
+    c = min(c, wg_chunks - 1);  // past the end: re-load the last chunk into a buffer nobody reads (keeps vmcnt uniform)
+    const int tile0 = 2 * c;
+    const int tile = (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
+    const int blk = table_row[tile / tpb];
+    const uint16_t* src = ((piece & 2) ? vc : kc) + (int64_t)blk * st.block + (int64_t)h * st.head +
+                          (int64_t)(tile % tpb) * st.tile + lane * 8;
+    uint16_t* dst = &stage[c % NBUF][piece][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
+                                       (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
+  };
+
   // LDS element offsets of this lane's operand pieces inside a tile
   //   K (A of the first product): key n (tile n / 16, token n % 16), dims 16 kk + 8 hi .. +7
   const int k_off = (hi * 16 + (n & 15)) * 8;                  // + (kk / 2) * 512 + (kk % 2) * 256
   //   V (A of the second): dim 32 db + n, key slots {4 hi .. +3} and {8 + 4 hi .. +3} of tile s
   const int v_off = (hi * 16 + (n & 15)) * 8 + (n >> 4) * 4;   // + db * 512 (+ 256 for the second piece)
 
+  issue(0);
+  issue(1);
   for (int c = 0; c < wg_chunks; ++c) {
     // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
     // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
