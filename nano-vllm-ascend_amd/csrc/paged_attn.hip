@@ -719,6 +719,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   //   V (A of the second): dim 32 db + n, key slots {4 hi .. +3} and {8 + 4 hi .. +3} of tile s
   const int v_off = (hi * 16 + (n & 15)) * 8 + (n >> 4) * 4;   // + db * 512 (+ 256 for the second piece)
 
+  // (issuing these two ahead of the Q preparation was tried in round 2: no measurable gain, and the full-shape
+  // paging-invariance tests failed with that order - keep the chunk loads behind the Q operand)
   issue(0);
   issue(1);
   for (int c = 0; c < wg_chunks; ++c) {
