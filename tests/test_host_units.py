@@ -246,19 +246,22 @@ def test_c_abi_exports_every_declared_symbol_and_rejects_bad_arguments():
         ops.silu_mul(torch.zeros(2, 16, dtype=torch.bfloat16))  # CPU tensor: no fallback
 
 
-def test_decode_stager_equals_decode_meta_under_preemption_and_churn():
+@pytest.mark.parametrize("n_stagers", [1, 2])
+def test_decode_stager_equals_decode_meta_under_preemption_and_churn(n_stagers):
     """The incremental staging writer (what the runner uploads every step) must equal the plain
     decode_meta() at every step of a run with tight memory: preemptions rebuild block tables,
-    finished sequences hand their rows to others."""
+    finished sequences hand their rows to others.  n_stagers = 2: the runner's two alternating pinned buffers,
+    each writer sees every other step (its rows may be several appended blocks behind)."""
     import random
 
     rng = random.Random(3)
     max_seqs, bs, cols, nblk = 6, 4, 16, 19
     sc = sched(max_num_seqs=max_seqs, max_num_batched_tokens=64, num_kvcache_blocks=nblk, kvcache_block_size=bs,
                max_model_len=cols * bs - 1)
-    stage = dict(ids=np.zeros(max_seqs, np.int64), pos=np.zeros(max_seqs, np.int64), ctx=np.zeros(max_seqs, np.int32),
-                 slots=np.zeros((max_seqs, 2), np.int32), tables=np.zeros((max_seqs, cols), np.int32))
-    stager = batch_meta.DecodeStager(**stage)
+    stages = [dict(ids=np.zeros(max_seqs, np.int64), pos=np.zeros(max_seqs, np.int64),
+                   ctx=np.zeros(max_seqs, np.int32), slots=np.zeros((max_seqs, 2), np.int32),
+                   tables=np.zeros((max_seqs, cols), np.int32)) for _ in range(n_stagers)]
+    stagers = [batch_meta.DecodeStager(**st) for st in stages]
     pending = [seq([rng.randrange(1, 90) for _ in range(rng.randrange(2, 14))], block_size=bs,
                    max_tokens=rng.randrange(3, 25), ignore_eos=True) for _ in range(14)]
     decode_steps = preemptions = 0
@@ -278,6 +281,7 @@ def test_decode_stager_equals_decode_meta_under_preemption_and_churn():
         else:
             decode_steps += 1
             bucket = next(b for b in (1, 2, 4, max_seqs) if b >= len(seqs))
+            stage, stager = stages[decode_steps % n_stagers], stagers[decode_steps % n_stagers]
             stager.fill(seqs, bucket, nblk - 1)
             want = batch_meta.decode_meta(seqs, pad_to=bucket, dummy_block=nblk - 1, table_cols=cols)
             assert stage["ids"][:bucket].tolist() == want.input_ids.tolist()
@@ -685,3 +689,28 @@ def test_lookahead_abort_drops_the_row_of_the_queued_step():
     full, aborted = outs
     assert sorted(full) == [0, 1, 2] and sorted(aborted) == [0, 2]
     assert aborted[0] == full[0] and aborted[2] == full[2]
+
+
+def test_lookahead_seals_decode_blocks_for_later_prefix_hits():
+    """Blocks filled DURING decode are sealed (hashed, registered) one step late under lookahead - when the token
+    that completes them has reached the host.  A later request whose prompt is an earlier request's prompt + output
+    must find exactly the blocks the synchronous engine would have registered."""
+    results = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=-1, num_kvcache_blocks=40, max_num_batched_tokens=64)
+        a = eng.add_request([3, 1, 4, 1, 5, 9], SamplingParams(max_tokens=12, ignore_eos=True, temperature=1.0))
+        eng.add_request([2, 7, 1, 8], SamplingParams(max_tokens=40, ignore_eos=True, temperature=1.0))
+        done, step, c = {}, 0, None
+        while not eng.is_finished():
+            if step == 25:  # A has long finished, B is still decoding
+                assert a.is_finished
+                c = eng.add_request(a.prompt_token_ids + a.completion_token_ids[:10],
+                                    SamplingParams(max_tokens=5, ignore_eos=True, temperature=1.0))
+            for seq_id, toks, _, cached in eng.step()[0]:
+                done[seq_id] = (list(toks), cached)
+            step += 1
+        results.append((done, c.num_cached_tokens))
+    (d0, c0), (d1, c1) = results
+    assert c0 == c1 == 16  # four full blocks of A: one from its prompt, three sealed while it decoded
+    assert {k: v[0] for k, v in d0.items()} == {k: v[0] for k, v in d1.items()}
