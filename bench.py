@@ -16,16 +16,21 @@ N > 1 has two modes (the JSON line says which: `mode`, `scaling`, `config.parall
                       model every all-reduce is a 64 KiB latency-bound message, so it does not speed up.
 
 A "step" is one engine decode step over the batch of 32 sequences (scheduler -> metadata
--> graph replay -> sampling -> postprocess), i.e. 32 new tokens.  Inputs are synthetic
+-> graph replay incl. sampling -> postprocess), i.e. 32 new tokens.  On one GPU the engine keeps one step queued
+behind the running one (decode_lookahead): the timed region starts - after synchronize - with one
+step finished and not yet consumed, and ends - after synchronize - with one finished and not consumed, so exactly
+`--steps` steps of device work and of host work lie inside it.  Inputs are synthetic
 (random-init Qwen3-0.6B-shaped weights N(0,0.02^2), random prompt ids in [0,10000],
 random.seed(0)); the 32 x 1024-token prompts are prefilled through the
 engine first (that is where p50 TTFT comes from), so the KV cache is resident in HBM
 when the timed region starts.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the dominant kernel (paged_attn_decode) timed live with HIP events on its
-                launch stream over the engine's real KV cache: algorithmic KV bytes per
-                launch / average duration vs the 8 TB/s HBM peak;
+  roofline      the dominant kernel (paged_attn_decode, the fused step form the engine runs) timed live
+                with HIP events on its launch stream over the engine's real KV cache: algorithmic KV
+                bytes per launch / average duration vs the 8 TB/s HBM peak; `traffic` = those bytes x
+                the PMC ratio of the newest profiles/r*_attn_traffic.json;
+  chain_roofline the six non-attention launches of a layer over all layers' weights;
   step_roofline the whole decode step against BASELINE.md's bytes(B, ctx) model;
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's arithmetic) timed on
                 this host on a bounded sample of the same workload.
