@@ -714,3 +714,32 @@ def test_lookahead_seals_decode_blocks_for_later_prefix_hits():
     (d0, c0), (d1, c1) = results
     assert c0 == c1 == 16  # four full blocks of A: one from its prompt, three sealed while it decoded
     assert {k: v[0] for k, v in d0.items()} == {k: v[0] for k, v in d1.items()}
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_lookahead_fuzz_against_the_synchronous_engine(seed):
+    """Seeded random request streams (lengths straddling block boundaries, tight memory so that preemptions and
+    lookahead refusals occur, EOS on in half of the seeds): token streams equal the synchronous engine's; without
+    EOS endings and late arrivals the decode steps and the final allocator state are equal too."""
+    import random
+
+    rng = random.Random(seed)
+    eos = 5 if seed % 2 else -1
+    n_req = rng.randrange(3, 9)
+    reqs = [([rng.randrange(0, 23) for _ in range(rng.randrange(1, 14))], rng.randrange(1, 30)) for _ in range(n_req)]
+    nblk = rng.choice((9, 12, 40))  # 9 / 12: some requests wait or get preempted; 40: ample
+    outs = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=eos, num_kvcache_blocks=nblk, max_num_batched_tokens=32, max_num_seqs=4)
+        for p, n in reqs:
+            if len(p) + n < 8 * 4 - 1:  # must fit the allocator even alone
+                eng.add_request(p, SamplingParams(max_tokens=n, ignore_eos=False, temperature=1.0))
+        done = _drain(eng)
+        bm = eng.scheduler.block_manager
+        assert not bm.used_block_ids and eng._inflight is None
+        outs.append((done, eng.model_runner.steps, list(bm.free_block_ids), dict(bm.hash_to_block_id)))
+    (d0, s0, f0, h0), (d1, s1, f1, h1) = outs
+    assert d0 == d1
+    if eos < 0:
+        assert s0 == s1 and f0 == f1 and h0 == h1
