@@ -130,3 +130,101 @@ def test_sequence_wire_roundtrip():
         assert r.num_blocks == 3 and r.last_block_num_tokens == 8  # works on the receiver
         if is_prefill:
             assert r.token_ids == s.token_ids
+
+
+class _TraceRunner:
+    """ModelRunner stand-in that checks every launched step against the REFERENCE's recorded trace and samples
+    with the recording's stand-in sampler.  Under lookahead a step is launched before the previous step's tokens
+    are on the host: like the device, it takes them from the previous launch's token buffer (src rows)."""
+
+    def __init__(self, sc, index):
+        self.sc, self.c, self.index = sc, sc["config"], index
+        self.golden = {r["step"]: r for r in sc["steps"]}
+        self.step = 0
+        self.device_tokens: list[int] = []
+        self.max_launch_rows = self.c["max_num_seqs"]
+        self.lookahead_launches = 0
+
+    def can_launch_decode(self, n):
+        return 0 < n <= self.max_launch_rows
+
+    def _check_and_sample(self, seqs, is_prefill, src):
+        c, g, bs = self.c, self.golden[self.step], self.c["block_size"]
+        idx = self.index
+        assert is_prefill == g["is_prefill"], self.step
+        assert [idx[s.seq_id] for s in seqs] == g["seqs"], self.step
+        assert [list(s.block_table) for s in seqs] == g["block_tables"], self.step
+        assert [len(s) for s in seqs] == g["lens"], self.step
+        views = []  # each sequence's tokens as the DEVICE knows them at this launch
+        for s, r in zip(seqs, src):
+            toks = list(s.token_ids)
+            if r >= 0:
+                assert s.token_pending
+                toks[-1] = self.device_tokens[r]
+            views.append(toks)
+        ctx = g["context"]
+        if is_prefill:
+            m = batch_meta.prefill_meta(seqs, bs)
+            assert m.input_ids.tolist() == g["input_ids"] and m.positions.tolist() == g["positions"]
+            assert m.slot_mapping.tolist() == ctx["slot_mapping"] and m.block_tables.tolist() == ctx["block_tables"]
+        else:
+            if c["padded"]:
+                m = batch_meta.decode_meta(seqs, pad_to=c["max_num_seqs"], dummy_block=c["num_kvcache_blocks"] - 1,
+                                           table_cols=c["max_model_len"] // bs)
+            else:
+                m = batch_meta.decode_meta(seqs)
+            ids = m.input_ids.tolist()
+            ids[:len(seqs)] = [v[-1] for v in views]  # what the embedding kernel reads (mi_embedding_from_prev)
+            assert ids == g["input_ids"] and m.positions.tolist() == g["positions"], self.step
+            assert m.context_lens.tolist() == ctx["context_lens"] and m.slot_mapping.tolist() == ctx["slot_mapping"]
+            assert m.block_tables.tolist() == ctx["block_tables"]
+        toks = [(sum(v[-4:]) * 31 + 7 * self.step + len(v)) % 1000 + 1 for v in views]
+        assert toks == g["sampled"], self.step
+        self.step += 1
+        self.device_tokens = toks
+        return list(toks)
+
+    def launch_decode(self, seqs, src_rows=None):
+        self.lookahead_launches += src_rows is not None
+        return self._check_and_sample(seqs, False, src_rows if src_rows is not None else [-1] * len(seqs))
+
+    def collect(self, handle):
+        return handle
+
+    def call(self, name, seqs, is_prefill):
+        assert name == "run"
+        return self._check_and_sample(seqs, is_prefill, [-1] * len(seqs)) if seqs else []
+
+
+@pytest.mark.parametrize("sc", [s for s in SCENARIOS + FUZZ if {a[0] for a in s["arrivals"]} == {0}
+                                and all(a[3] for a in s["arrivals"])], ids=lambda s: s["name"])
+def test_lookahead_engine_reproduces_the_reference_trace(sc):
+    """The reference's recorded index streams (every request present from step 0, no EOS endings: preemption
+    under tight memory, block-boundary crossings eager and graph-padded) replayed through LLMEngine with
+    decode_lookahead: every step it launches - scheduled one step ahead, from lengths alone - carries exactly the
+    sequences, block tables, positions, slots and (device-side) input ids of the reference's step."""
+    from nanovllm.engine.llm_engine import LLMEngine
+
+    c = sc["config"]
+    cfg = SimpleNamespace(max_num_seqs=c["max_num_seqs"], max_num_batched_tokens=c["max_num_batched_tokens"],
+                          eos=c["eos"], num_kvcache_blocks=c["num_kvcache_blocks"],
+                          kvcache_block_size=c["block_size"], max_model_len=c["max_model_len"])
+    eng = object.__new__(LLMEngine)
+    eng.scheduler = Scheduler(cfg)
+    eng.block_size, eng.tokenizer, eng.ttft, eng.lookahead, eng._inflight = c["block_size"], None, {}, True, None
+    order, index = [], {}
+    eng.model_runner = _TraceRunner(sc, index)
+    for _, toks, max_tokens, ignore_eos in sorted(sc["arrivals"], key=lambda a: a[0]):
+        s = eng.add_request(toks, SamplingParams(temperature=1.0, max_tokens=max_tokens, ignore_eos=ignore_eos))
+        index[s.seq_id] = len(order)
+        order.append(s)
+    guard = 0
+    while not eng.is_finished():
+        eng.step()
+        guard += 1
+        assert guard < 2000
+    assert eng.model_runner.step == len(sc["steps"])  # every recorded step was launched, none extra
+    assert eng.model_runner.lookahead_launches > 0    # and some of them one step ahead
+    assert [list(s.token_ids) for s in order] == sc["final_tokens"]
+    assert [s.num_cached_tokens for s in order] == sc["final_cached"]
+    assert len(eng.scheduler.block_manager.free_block_ids) == c["num_kvcache_blocks"] - 1
