@@ -251,6 +251,21 @@ int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_bf16* bias,
  * (after TP sharding); N % 16 == 0, K % 32 == 0. */
 int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream stream);
 
+/* The same product for ANY number of rows (reference: F.linear at linear.py:51,73,150 with prefill-sized
+ * activations, every decode batch above 64 sequences): 256 x 256 x 64 MFMA tiles, both operands staged by
+ * LDS-DMA (csrc/gemm_tile.hip).  x [M][K] with row stride ldx, w [N][K] row-major (the checkpoint layout,
+ * no packed copy needed), y [M][N] with row stride ldy (strides in elements).
+ * epilogue 0: y = x @ w^T (+ bias[N]);  epilogue 1: rows j and j + N/2 of w are the gate and up rows of
+ * MergedColumnParallelLinear (linear.py:76-93) and y[M][N/2] = SiluAndMul (activation.py:10-12) of the product,
+ * with the reference's three bf16 roundings.  K % 64 == 0, N % 4 == 0 (epilogue 1: N/2 % 128 == 0, no bias),
+ * ldx % 8 == 0, ldy % 4 == 0. */
+int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y, int64_t ldy,
+                 int M, int N, int K, int epilogue, mi_stream stream);
+/* Tuning form of mi_gemm_bf16 (tools/gemm_bench.py): variant = 16 * prefetch depth + schedule flags, see
+ * csrc/gemm_tile.hip; MI_EUNSUPPORTED for variants that are not compiled. */
+int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, mi_bf16* y, int64_t ldy, int M, int N, int K,
+                    int variant, mi_stream stream);
+
 /* As mi_gemm_bf16_skinny on packed weights.  epilogue 0: y[M][N] (+bias).
  * epilogue 1 (SiluAndMul fused, activation.py:10-12 on top of MergedColumnParallelLinear,
  * linear.py:76-93): w is gate|up stacked, y[M][N/2] = bf16(bf16(silu(bf16 g)) * bf16 u)

@@ -1,0 +1,72 @@
+// Index arithmetic of the 256 x 256 x 64 MFMA tile GEMM (gemm_tile.hip), kept apart from the kernel so that a
+// host program can replay it (tests/test_gemm_tile_index.py compiles this header with g++ and checks that every
+// fragment read finds the element the LDS-DMA of some wave put there, and that no ds_read_b128 lane group hits a
+// bank twice).  No HIP types in here.
+//
+// Geometry.  The MFMA A operand carries weight rows ("features", output columns), the B operand activation rows
+// ("tokens"): C^T[feature][token], so that a lane ends up with runs of four consecutive features of one token.
+//   workgroup tile   256 features x 256 tokens, K step 64
+//   8 waves          fh = wave >> 2 (feature half, 128 each; also the ping-pong group), tq = wave & 3 (token quarter, 64 each)
+//   wave tile        128 features x 64 tokens = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16
+//   phases           a K step is consumed in four quadrants: (A half 0, B half 0), (A0, B1), (A1, B1), (A1, B0),
+//                    A half = 64 features (two 32-row fragments), B half = 32 tokens (one fragment)
+//
+// LDS.  One K step of the tile (2 x 256 rows x 128 bytes = 64 KiB) is stored as FOUR 16 KiB half-tiles, each holding
+// exactly the rows one phase reads, so that a half-tile can be consumed as soon as it has landed:
+//   h = 0: A half 0 of both feature halves     (read in phase 0)
+//   h = 1: B half 0 of the four token quarters (read in phase 0, kept for phase 3)
+//   h = 2: B half 1                            (read in phase 1)
+//   h = 3: A half 1                            (read in phase 2)
+// A half-tile is 128 "local rows" of 128 bytes (64 bf16 along K), in blocks of 8 rows = 1 KiB = one
+// global_load_lds_dwordx4 wave instruction (lane l lands at byte 16 l of the block): 8 lanes fetch one whole
+// 128-byte line of a row.  The 16-byte chunks of a row are XOR-swizzled by (row >> 1) & 7, applied to the SOURCE
+// address (the DMA destination is lane-linear) and to the fragment reads alike.
+#pragma once
+
+#ifndef MI_HD
+#ifdef __HIPCC__
+#define MI_HD __host__ __device__
+#else
+#define MI_HD
+#endif
+#endif
+
+namespace mi {
+namespace gt {
+
+constexpr int TILE_F = 256, TILE_T = 256, BK = 64;
+constexpr int HALF_BYTES = 16384, SLOTS = 8;         // two K steps x four half-tiles
+constexpr int LDS_BYTES = SLOTS * HALF_BYTES + 1024;  // + one block that absorbs the past-the-end loads
+
+// row of the workgroup tile (feature row for h = 0 / 3, token row for h = 1 / 2) held by local row lr of half-tile h
+MI_HD constexpr int tile_row(int h, int lr) {
+  return (h == 0 || h == 3) ? (lr >> 6) * 128 + (h == 3 ? 64 : 0) + (lr & 63)
+                            : (lr >> 5) * 64 + (h == 2 ? 32 : 0) + (lr & 31);
+}
+MI_HD constexpr bool is_weight_half(int h) { return h == 0 || h == 3; }
+MI_HD constexpr int swizzle(int lr) { return (lr >> 1) & 7; }
+// byte offset of 16-byte K chunk c (0..7) of local row lr inside a half-tile
+MI_HD constexpr int half_off(int lr, int c) { return (lr >> 3) * 1024 + (lr & 7) * 128 + ((c ^ swizzle(lr)) << 4); }
+
+// ---- LDS-DMA side: wave `wave`, instruction i (0, 1) of a half-tile, lane `lane` ----
+MI_HD constexpr int dma_block(int wave, int i) { return wave * 2 + i; }                  // 1 KiB block of the half-tile
+MI_HD constexpr int dma_local_row(int wave, int i, int lane) { return dma_block(wave, i) * 8 + (lane >> 3); }
+// the K chunk this lane must fetch so that its 16 bytes, landing at 16 * lane, are where half_off() expects them
+MI_HD constexpr int dma_chunk(int wave, int i, int lane) { return (lane & 7) ^ swizzle(dma_local_row(wave, i, lane)); }
+
+// ---- fragment side: wave (fh, tq), lane = 32 hi + l31 ----
+// A fragment `a` (0, 1) of A half `ah`, k step kk (0..3 of 16): row l31 of the fragment, K chunk 2 kk + hi
+MI_HD constexpr int a_half(int ah) { return ah ? 3 : 0; }
+MI_HD constexpr int a_local_row(int fh, int a, int l31) { return fh * 64 + a * 32 + l31; }
+MI_HD constexpr int b_half(int bh) { return bh ? 2 : 1; }
+MI_HD constexpr int b_local_row(int tq, int l31) { return tq * 32 + l31; }
+MI_HD constexpr int frag_chunk(int kk, int hi) { return 2 * kk + hi; }
+
+// ---- accumulator side: acc[ah * 2 + a][bh], register r (0..15) of lane (hi, l31) ----
+MI_HD constexpr int acc_feature(int fh, int ah, int a, int r, int hi) {
+  return fh * 128 + ah * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+}
+MI_HD constexpr int acc_token(int tq, int bh, int l31) { return tq * 64 + bh * 32 + l31; }
+
+}  // namespace gt
+}  // namespace mi

@@ -293,6 +293,32 @@ def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
     return out
 
 
+def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | None = None) -> torch.Tensor:
+    """y = x @ w.T (+ bias) for any number of rows on the 256 x 256 MFMA tile kernel (mi_gemm_bf16); silu_mul:
+    w stacks gate | up rows and y = SiluAndMul(x @ w.T).  x may be a row-strided 2-D view."""
+    require_gpu(x, w, bias)
+    _bf16(x, w, bias)
+    assert w.dim() == 2 and w.is_contiguous() and x.stride(-1) == 1
+    K = x.shape[-1]
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if x.dim() != 2 or x.stride(0) % 8:
+        x = x.reshape(-1, K).contiguous()
+    M = x.shape[0]
+    n_out = N // 2 if silu_mul else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=_BF16, device=x.device)
+    assert out.dim() == 2 and out.shape == (M, n_out) and out.stride(1) == 1
+    if variant is not None:
+        assert bias is None and not silu_mul
+        check(lib.mi_gemm_bf16_ex(ptr(x), x.stride(0), ptr(w), ptr(out), out.stride(0), M, N, K, variant, stream()),
+              "mi_gemm_bf16_ex")
+        return out
+    check(lib.mi_gemm_bf16(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(out), out.stride(0), M, N, K, int(silu_mul),
+                           stream()), "mi_gemm_bf16")
+    return out
+
+
 def pack_weight(w, out=None) -> torch.Tensor:
     """Fragment-native copy of a [N, K] weight for the decode GEMMs (same shape/bytes).
     Pass the previous copy as `out` to refresh it in place (captured graphs keep its address)."""

@@ -1,0 +1,168 @@
+// Host replay of the index arithmetic of csrc/gemm_tile.hip (gemm_tile_index.hpp): built and run by
+// tests/test_gemm_tile_index.py with g++ - no GPU involved.
+//   1. every 16-byte cell of a half-tile is written by exactly one (wave, instruction, lane) of the LDS-DMA
+//   2. every fragment read finds the (tile row, K chunk) the MFMA operand layout wants
+//   3. no ds_read_b128 lane group touches a 16-byte bank slot twice
+//   4. a whole 256 x 256 tile computed the way the kernel does it (DMA image -> fragments -> 32x32x16 MFMA
+//      semantics -> accumulator layout -> output columns, plain and SwiGLU row pairing) equals x @ w^T
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gemm_tile_index.hpp"
+
+using namespace mi::gt;
+
+struct Cell { int row = -1, chunk = -1, writers = 0; };
+
+static int fails = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { if (fails++ < 10) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } } while (0)
+
+int main() {
+  // ---- 1: the DMA image of each half-tile ----
+  std::vector<std::vector<Cell>> img(4, std::vector<Cell>(HALF_BYTES / 16));
+  for (int h = 0; h < 4; ++h)
+    for (int wave = 0; wave < 8; ++wave)
+      for (int i = 0; i < 2; ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int byte = dma_block(wave, i) * 1024 + lane * 16;  // lane-linear destination
+          const int lr = dma_local_row(wave, i, lane), c = dma_chunk(wave, i, lane);
+          CHECK(c >= 0 && c < 8, "chunk %d", c);
+          CHECK(byte == half_off(lr, c), "h %d wave %d i %d lane %d: lands at %d, layout says %d", h, wave, i, lane, byte, half_off(lr, c));
+          Cell& cell = img[h][byte / 16];
+          cell.row = tile_row(h, lr);
+          cell.chunk = c;
+          cell.writers++;
+        }
+  for (int h = 0; h < 4; ++h) {
+    std::vector<int> seen(256 * 8, 0);
+    for (const Cell& c : img[h]) {
+      CHECK(c.writers == 1, "half %d: a cell has %d writers", h, c.writers);
+      seen[c.row * 8 + c.chunk]++;
+    }
+    // a weight half holds rows {fh*128 + half*64 + j}, a token half rows {tq*64 + half*32 + j}: 128 rows x 8 chunks each once
+    int rows = 0;
+    for (int r = 0; r < 256; ++r) {
+      int n = 0;
+      for (int c = 0; c < 8; ++c) n += seen[r * 8 + c];
+      CHECK(n == 0 || n == 8, "half %d row %d: %d chunks", h, r, n);
+      rows += n == 8;
+    }
+    CHECK(rows == 128, "half %d holds %d rows", h, rows);
+  }
+
+  // ---- 2 + 3: fragment reads ----
+  static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  auto check_read = [&](int h, const int (&addr)[64], const int (&want_row)[64], int kk, const char* what) {
+    for (int lane = 0; lane < 64; ++lane) {
+      const Cell& c = img[h][addr[lane] / 16];
+      CHECK(addr[lane] % 16 == 0 && c.row == want_row[lane] && c.chunk == frag_chunk(kk, lane >> 5),
+            "%s lane %d: found row %d chunk %d, want row %d chunk %d", what, lane, c.row, c.chunk, want_row[lane], frag_chunk(kk, lane >> 5));
+    }
+    for (const auto& g : groups) {
+      int used[16] = {0};
+      for (int l : g) used[(addr[l] / 16) % 16]++;
+      for (int s = 0; s < 16; ++s) CHECK(used[s] <= 1, "%s: bank slot %d used %d times in one lane group", what, s, used[s]);
+    }
+  };
+  for (int wave = 0; wave < 8; ++wave) {
+    const int fh = wave >> 2, tq = wave & 3;
+    for (int kk = 0; kk < 4; ++kk) {
+      for (int ah = 0; ah < 2; ++ah)
+        for (int a = 0; a < 2; ++a) {
+          int addr[64], want[64];
+          for (int lane = 0; lane < 64; ++lane) {
+            const int hi = lane >> 5, l31 = lane & 31;
+            // the kernel's form: fh * 8192 + a * 4096 + rowoff + ((chunk ^ swizzle(l31)) << 4)
+            addr[lane] = fh * 8192 + a * 4096 + (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
+            CHECK(addr[lane] == half_off(a_local_row(fh, a, l31), frag_chunk(kk, hi)), "A address form");
+            want[lane] = acc_feature(fh, ah, a, 0, 0) + l31;  // MFMA A operand: row l31 of the fragment
+          }
+          check_read(a_half(ah), addr, want, kk, "A fragment");
+        }
+      for (int bh = 0; bh < 2; ++bh) {
+        int addr[64], want[64];
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hi = lane >> 5, l31 = lane & 31;
+          addr[lane] = tq * 4096 + (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
+          CHECK(addr[lane] == half_off(b_local_row(tq, l31), frag_chunk(kk, hi)), "B address form");
+          want[lane] = acc_token(tq, bh, l31);
+        }
+        check_read(b_half(bh), addr, want, kk, "B fragment");
+      }
+    }
+  }
+
+  // ---- 4: one tile end to end, K = 128 (two K steps), plain and SwiGLU ----
+  for (int silu = 0; silu < 2; ++silu) {
+    const int K = 128, N = silu ? 512 : 256, M = 256, n0 = 0, m0 = 0;
+    std::vector<float> x(M * K), w(N * K);
+    unsigned s = 12345u + silu;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((int)(s >> 24) - 128) / 64.0f; };
+    for (auto& v : x) v = rnd();
+    for (auto& v : w) v = rnd();
+    const int n_out = silu ? N / 2 : N;
+    std::vector<double> got(M * n_out, 0.0), gate(M * n_out, 0.0), up(M * n_out, 0.0);
+    for (int wave = 0; wave < 8; ++wave) {
+      const int fh = wave >> 2, tq = wave & 3;
+      for (int ah = 0; ah < 2; ++ah)
+        for (int a = 0; a < 2; ++a)
+          for (int bh = 0; bh < 2; ++bh) {
+            // accumulator acc[ah * 2 + a][bh] of every lane
+            for (int lane = 0; lane < 64; ++lane)
+              for (int r = 0; r < 16; ++r) {
+                // MFMA 32x32x16 semantics: D[row][col], row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31;
+                // A[row][k] comes from the lane with l31 = row, B[k][col] from the lane with l31 = col
+                const int frow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+                double sum = 0.0;
+                for (int kt = 0; kt < K / BK; ++kt)
+                  for (int kk = 0; kk < 4; ++kk)
+                    for (int hi = 0; hi < 2; ++hi) {
+                      const Cell& ca = img[a_half(ah)][half_off(a_local_row(fh, a, frow), frag_chunk(kk, hi)) / 16];
+                      const Cell& cb = img[b_half(bh)][half_off(b_local_row(tq, col), frag_chunk(kk, hi)) / 16];
+                      // source rows as the kernel computes them for the DMA
+                      const int tr = ca.row;
+                      const int wrow = silu ? ((tr >> 6) & 1) * (N >> 1) + (n0 >> 1) + (tr >> 7) * 64 + (tr & 63) : n0 + tr;
+                      const int xrow = m0 + cb.row;
+                      for (int e = 0; e < 8; ++e) {
+                        const int k = kt * BK + ca.chunk * 8 + e;
+                        CHECK(ca.chunk == cb.chunk, "operand chunks differ");
+                        sum += (double)w[wrow * K + k] * (double)x[xrow * K + k];
+                      }
+                    }
+                const int tok = m0 + acc_token(tq, bh, lane & 31);
+                if (silu) {
+                  const int j = a, rq = r >> 2, e = r & 3, hi = lane >> 5;
+                  const int colo = (n0 >> 1) + fh * 64 + j * 32 + 8 * rq + 4 * hi + e;
+                  (ah ? up : gate)[tok * n_out + colo] = sum;
+                } else {
+                  const int j = ah * 2 + a, rq = r >> 2, e = r & 3, hi = lane >> 5;
+                  const int colo = n0 + acc_feature(fh, j >> 1, j & 1, 4 * rq, hi) + e;
+                  got[tok * n_out + colo] = sum;
+                }
+              }
+          }
+    }
+    for (int t = 0; t < M; ++t)
+      for (int c = 0; c < (silu ? 128 : n_out); ++c) {  // one tile: 128 gate + 128 up rows -> 128 output columns
+        if (silu) {
+          double g = 0, u = 0;
+          for (int k = 0; k < K; ++k) {
+            g += (double)x[t * K + k] * w[c * K + k];
+            u += (double)x[t * K + k] * w[(N / 2 + c) * K + k];
+          }
+          CHECK(gate[t * n_out + c] == g && up[t * n_out + c] == u, "silu pairing at (%d, %d)", t, c);
+        } else {
+          double ref = 0;
+          for (int k = 0; k < K; ++k) ref += (double)x[t * K + k] * w[c * K + k];
+          CHECK(got[t * n_out + c] == ref, "output (%d, %d): %f vs %f", t, c, got[t * n_out + c], ref);
+        }
+      }
+  }
+  if (fails) { std::printf("%d check(s) failed\n", fails); return 1; }
+  std::printf("gemm_tile index replay: ok\n");
+  return 0;
+}

@@ -1,0 +1,128 @@
+"""GPU parity of the MFMA tile GEMM (mi_gemm_bf16, csrc/gemm_tile.hip) - the F.linear of every prefill-sized
+activation (linear.py:51,73,150) - against the CPU oracle.  fp32 accumulation in a different order than the
+oracle's: <= 1 bf16 ulp on a small fraction of the outputs, absolute floor K * 2^-22 where a dot product cancels."""
+import pytest
+import torch
+
+import oracle
+from test_kernels_gpu import assert_bf16_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nanovllm import ops as _ops
+
+    return _ops
+
+
+def _case(M, N, K, seed=0, wscale=0.05):
+    g = torch.Generator().manual_seed(seed + M * 7 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * wscale).bfloat16()
+    return g, x, w
+
+
+# prefill shapes of Qwen3-0.6B (qkv, o_proj, gate_up, down), ragged token counts, N not a multiple of the tile,
+# one and three K steps, the MoE router (N = 8 / 128)
+@pytest.mark.parametrize("M", [65, 256, 300, 1000])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (512, 128), (100, 64),
+                                 (8, 128), (128, 192), (1280, 5120)])
+def test_gemm_tile_vs_oracle(ops, M, N, K):
+    g, x, w = _case(M, N, K)
+    b = torch.randn(N, generator=g).bfloat16()
+    atol = K * 2.0 ** -22
+    y = ops.gemm_tile(x.to(DEV), w.to(DEV))
+    assert_bf16_close(y, oracle.linear(x, w), max_ulp=1, max_frac=2e-2, atol=atol)
+    yb = ops.gemm_tile(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert_bf16_close(yb, oracle.linear(x, w, b), max_ulp=1, max_frac=2e-2, atol=atol)
+    # transpose / fragment-layout detector: asymmetric weights, one-hot activations
+    xe = torch.zeros(M, K).bfloat16()
+    xe[M - 3, 5] = 1.0
+    xe[1, K - 1] = 1.0
+    ye = ops.gemm_tile(xe.to(DEV), w.to(DEV)).cpu()
+    assert torch.equal(ye[M - 3].view(torch.int16), w[:, 5].contiguous().view(torch.int16))
+    assert torch.equal(ye[1].view(torch.int16), w[:, K - 1].contiguous().view(torch.int16))
+    assert float(ye.float().abs().sum() - ye[M - 3].float().abs().sum() - ye[1].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M", [65, 256, 777])
+@pytest.mark.parametrize("N,K", [(6144, 1024), (512, 128), (6400, 5120), (1536, 2048)])
+def test_gemm_tile_swiglu_epilogue(ops, M, N, K):
+    """fused SiluAndMul == gate_up GEMM followed by the activation (activation.py:10-12, three bf16 roundings);
+    bit-identical to the tile GEMM's own plain output run through mi_silu_mul"""
+    g, x, w = _case(M, N, K, seed=3)
+    got = ops.gemm_tile(x.to(DEV), w.to(DEV), silu_mul=True)
+    two_pass = ops.silu_mul(ops.gemm_tile(x.to(DEV), w.to(DEV)))
+    assert torch.equal(got.view(torch.int16), two_pass.view(torch.int16))
+    atol = K * 2.0 ** -22
+    # a 1-ulp flip of the gate (summation order) times |up| <= ~6: widen the near-zero floor
+    assert_bf16_close(got, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=2, max_frac=3e-2, atol=32 * atol)
+
+
+def test_gemm_tile_strided_rows(ops):
+    """x and y as row-strided views (the q heads of a packed qkv row, a slice of a wider output)"""
+    g, xw, w = _case(300, 1024, 2048 + 1024 + 1024, seed=5)
+    x = xw[:, :2048]
+    w = w[:, :2048].contiguous()
+    out = torch.zeros(300, 1536, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_tile(xw.to(DEV)[:, :2048], w.to(DEV), out=out[:, 256:1280])
+    assert_bf16_close(out[:, 256:1280].cpu(), oracle.linear(x, w), max_frac=2e-2, atol=2048 * 2.0 ** -22)
+    assert float(out[:, :256].float().abs().sum()) == 0.0 and float(out[:, 1280:].float().abs().sum()) == 0.0
+
+
+def test_gemm_tile_full_prefill_shape_and_variants(ops):
+    """The bench's prefill step: 16384 tokens.  All schedule variants run the same MFMA chains: bit-identical
+    outputs; repeated launches under a competing HBM stream stay bit-identical (race screen of the DMA pipeline)."""
+    M, N, K = 16384, 4096, 1024
+    g, x, w = _case(M, N, K, seed=9)
+    xd, wd = x.to(DEV), w.to(DEV)
+    y = ops.gemm_tile(xd, wd)
+    want = oracle.linear(x[:2048], w)  # the oracle on the first 2048 rows and on the last tile's rows
+    assert_bf16_close(y[:2048], want, max_frac=2e-2, atol=K * 2.0 ** -22)
+    assert_bf16_close(y[-300:], oracle.linear(x[-300:], w), max_frac=2e-2, atol=K * 2.0 ** -22)
+    for variant in (5 * 16 + 1, 5 * 16 + 2, 5 * 16 + 4, 6 * 16 + 0, 6 * 16 + 1):
+        yv = ops.gemm_tile(xd, wd, variant=variant)
+        assert torch.equal(yv.view(torch.int16), y.view(torch.int16)), variant
+    side = torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    for it in range(40):
+        with torch.cuda.stream(side):
+            junk.add_(1)  # uneven HBM pressure next to the DMA pipeline
+        v = (5 * 16, 6 * 16)[it & 1]
+        yv = ops.gemm_tile(xd, wd, variant=v)
+        assert torch.equal(yv.view(torch.int16), y.view(torch.int16)), it
+    torch.cuda.synchronize()
+    # linearity in the rows: permuting the activation rows permutes the output rows, bit for bit
+    perm = torch.randperm(M, generator=g)
+    yp = ops.gemm_tile(xd[perm.to(DEV)].contiguous(), wd)
+    assert torch.equal(yp.view(torch.int16), y[perm.to(DEV)].view(torch.int16))
+
+
+def test_gemm_tile_rejects_what_it_cannot_do(ops):
+    from nanovllm._C import MiError
+
+    x = torch.zeros(128, 96, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(64, 96, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(MiError):  # K % 64
+        ops.gemm_tile(x, w)
+    with pytest.raises(MiError):
+        ops.gemm_tile(torch.zeros(128, 64).bfloat16(), torch.zeros(64, 64).bfloat16())  # CPU tensors
+
+
+def test_gemm_tile_captures_into_hipgraph(ops):
+    g, x, w = _case(512, 1024, 1024, seed=11)
+    xd, wd = x.to(DEV), w.to(DEV)
+    out = torch.empty(512, 1024, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_tile(xd, wd, out=out)
+    want = out.clone()
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.gemm_tile(xd, wd, out=out)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
