@@ -258,9 +258,13 @@ int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream 
  * epilogue 0: y = x @ w^T (+ bias[N]);  epilogue 1: rows j and j + N/2 of w are the gate and up rows of
  * MergedColumnParallelLinear (linear.py:76-93) and y[M][N/2] = SiluAndMul (activation.py:10-12) of the product,
  * with the reference's three bf16 roundings.  K % 64 == 0, N % 4 == 0 (epilogue 1: N/2 % 128 == 0, no bias),
- * ldx % 8 == 0, ldy % 4 == 0. */
+ * ldx % 8 == 0, ldy % 4 == 0.
+ * Shapes whose tiles cannot fill the chip (few token rows x a narrow projection, e.g. 1024 x 1024 x 3072) are
+ * computed as K slices into `workspace` (fp32, mi_gemm_bf16_workspace bytes; 0 = not needed for this shape) and
+ * summed in slice order by a second launch - deterministic, one rounding. */
+size_t mi_gemm_bf16_workspace(int M, int N, int K, int epilogue);
 int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y, int64_t ldy,
-                 int M, int N, int K, int epilogue, mi_stream stream);
+                 int M, int N, int K, int epilogue, void* workspace, size_t ws_bytes, mi_stream stream);
 /* Tuning form of mi_gemm_bf16 (tools/gemm_bench.py): variant = 16 * prefetch depth + schedule flags, see
  * csrc/gemm_tile.hip; MI_EUNSUPPORTED for variants that are not compiled. */
 int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, mi_bf16* y, int64_t ldy, int M, int N, int K,

@@ -78,10 +78,10 @@ extern "C" int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed, int N, 
 extern "C" int mi_gemm_bf16_rows4(const mi_bf16* x, const mi_bf16* w_packed4, mi_bf16* y, int M, int N, int K,
                                   mi_stream stream) {
   if (!x || !w_packed4 || !y || M < 0 || N <= 0 || K <= 0) return MI_EINVAL;
-  if (M > 64 || K % 32 || N % 4) return MI_EUNSUPPORTED;
+  if (M > kSkinnyMaxRows || K % 32 || N % 4) return MI_EUNSUPPORTED;
   if (!aligned16(x) || !aligned16(w_packed4) || !aligned16(y)) return MI_EINVAL;
   if (M == 0) return MI_OK;
-  switch ((M + 15) / 16) {
+  switch ((min(M, kSkinnyRows) + 15) / 16) {
     case 1: return rows4_waves<1>(x, w_packed4, y, M, N, K, S(stream));
     case 2: return rows4_waves<2>(x, w_packed4, y, M, N, K, S(stream));
     case 3: return rows4_waves<3>(x, w_packed4, y, M, N, K, S(stream));

@@ -29,6 +29,9 @@ struct PickArgs {
 // whole 128-byte lines (8 lanes per row, 8 rows per instruction), parks it in its private LDS slab
 // (16-byte units XOR-swizzled by row) and reads the fragments back with ds_read_b128.  LDS operations of
 // one wave execute in order, so the slab needs no barrier and is reused for every pair.
+constexpr int kSkinnyRows = 64;       // activation rows one workgroup holds (MT <= 4 column tiles of 16)
+constexpr int kSkinnyMaxRows = 512;   // rows a launch accepts (8 row chunks); beyond that the tile GEMM is the kernel
+
 template <int MT, int STEPS>
 __device__ __forceinline__ void issue_x_lines(const uint16_t* __restrict__ x, int M, int K, int k0, int lane,
                                               u32x4 (&stage)[(STEPS + 1) / 2][MT * 2]) {
@@ -67,8 +70,14 @@ constexpr int x_slab_bytes(int MT) { return MT * 16 * 64 * 2; }
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M, int N, int K,
+    uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M_all, int N, int K,
     PickArgs pk) {
+  // more than 64 activation rows: blockIdx.z walks them in chunks of 64 (the weight stream of the second and
+  // later chunks of a row tile is served by L2 / the Infinity Cache: the chunks of a tile are dispatched together)
+  const int m0 = (int)blockIdx.z * kSkinnyRows;
+  const int M = min(M_all - m0, kSkinnyRows);
+  x += (int64_t)m0 * K;
+  if (y) y += (int64_t)m0 * (EPI == EPI_SILU ? N >> 1 : N);
   // [WAVES][RT*MT][256] fp32 K-slice sums; before that, each wave's slot doubles as its x slab
   extern __shared__ __attribute__((aligned(16))) float red[];
   constexpr int SLOT = RT * MT * 1024 > x_slab_bytes(MT) ? RT * MT * 1024 : x_slab_bytes(MT);  // bytes per wave
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
   uint64_t pk_seed = 0, pk_step = 0;
   if (EPI == EPI_PICK) {
     const int row0 = 16 * (((int)threadIdx.x >> 6) % MT) + (lane & 15);  // the row of this thread's first item
-    if (pk.temperatures && row0 < M) pk_temp = pk.temperatures[row0];
+    if (pk.temperatures && row0 < M) pk_temp = pk.temperatures[m0 + row0];
     pk_seed = pk.rng[0];
     pk_step = pk.rng[1];
   }
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
       f32x4 s = total(t);
       const int col = tile[0] * 16 + t * 16 + 4 * (l >> 4);
       if (EPI == EPI_PARTIAL) {
-        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.y * M + row) * N + col) = s;
+        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.y * M_all + m0 + row) * N + col) = s;
       } else {
         if (BIAS) {
           const u32x2 bw = *reinterpret_cast<const u32x2*>(bias + col);
@@ -234,10 +243,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
         o[1] = pack_bf(s[2], s[3]);
         *reinterpret_cast<u32x2*>(y + (int64_t)row * N + col) = o;
         if (EPI == EPI_PICK) {  // keys of the ROUNDED logits, as a sampler reading y would form them
-          const float tmp = item == (int)threadIdx.x ? pk_temp : (pk.temperatures ? pk.temperatures[row] : 0.f);
+          const float tmp = item == (int)threadIdx.x ? pk_temp : (pk.temperatures ? pk.temperatures[m0 + row] : 0.f);
           const bool noisy = tmp > 0.f;
           const float inv_t = noisy ? 1.0f / tmp : 1.0f;
-          const uint64_t rkey = sample_row_key(pk_seed, pk_step, row);
+          const uint64_t rkey = sample_row_key(pk_seed, pk_step, m0 + row);
           const float v[4] = {lo_bf(o[0]), hi_bf(o[0]), lo_bf(o[1]), hi_bf(o[1])};
           float best = -INFINITY;
           int best_c = 0x7fffffff;
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
           best_c = c2;
         }
       }
-      pk.cand[(int64_t)row * gridDim.x + blockIdx.x] = uint2{__float_as_uint(best), (uint32_t)best_c};
+      pk.cand[(int64_t)(m0 + row) * gridDim.x + blockIdx.x] = uint2{__float_as_uint(best), (uint32_t)best_c};
     }
   }
 }
@@ -292,7 +301,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 template <int MT, int WAVES, int STEPS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_rows4_kernel(const uint16_t* __restrict__ x,
                                                                 const uint16_t* __restrict__ w4,
-                                                                uint16_t* __restrict__ y, int M, int N, int K) {
+                                                                uint16_t* __restrict__ y, int M_all, int N, int K) {
+  const int m0 = (int)blockIdx.y * kSkinnyRows;  // row chunks of 64, as gemm_skinny_kernel
+  const int M = min(M_all - m0, kSkinnyRows);
+  x += (int64_t)m0 * K;
+  y += (int64_t)m0 * N;
   __shared__ __attribute__((aligned(16))) float red[WAVES][MT][16][4];
   __shared__ __attribute__((aligned(16))) uint16_t slabs[WAVES][STEPS % 2 == 0 ? MT * 16 * 64 : 8];  // x in whole lines
   const int lane = threadIdx.x & 63;
@@ -364,8 +377,8 @@ static bool rows4_steps(const uint16_t* x, const uint16_t* w4, uint16_t* y, int 
   const int kslice = K / WAVES;
 #define ROWS4_GO(ST)                                                                                      \
   do {                                                                                                    \
-    hipLaunchKernelGGL((gemm_rows4_kernel<MT, WAVES, ST>), dim3(N / 4), dim3(WAVES * 64), 0, st, x, w4, y, \
-                       M, N, K);                                                                          \
+    hipLaunchKernelGGL((gemm_rows4_kernel<MT, WAVES, ST>), dim3(N / 4, (M + kSkinnyRows - 1) / kSkinnyRows),  \
+                       dim3(WAVES * 64), 0, st, x, w4, y, M, N, K);                                       \
     return true;                                                                                          \
   } while (0)
   // the whole K-slice in flight when the registers allow (MT + 1 fragments per k-step)
@@ -566,7 +579,7 @@ static void launch(const GemmArgs& a) {
   const size_t slot = (size_t)RT * MT * 1024 > (size_t)x_slab_bytes(MT) ? (size_t)RT * MT * 1024 : (size_t)x_slab_bytes(MT);
   const size_t lds = (size_t)WAVES * slot;
   const int tiles = a.N / 16;
-  const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit);
+  const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit, (a.M + kSkinnyRows - 1) / kSkinnyRows);
   if (a.bias && EPI == EPI_NONE)
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
                        a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
@@ -640,7 +653,7 @@ static int pick_waves(const GemmArgs& a) {
 
 template <int RT, int WF, int EPI>
 static int pick_mt(const GemmArgs& a) {
-  switch ((a.M + 15) / 16) {
+  switch ((min(a.M, kSkinnyRows) + 15) / 16) {
     case 1: return pick_waves<1, RT, WF, EPI>(a);
     case 2: return pick_waves<2, RT, WF, EPI>(a);
     case 3: return pick_waves<3, RT, WF, EPI>(a);
@@ -650,7 +663,7 @@ static int pick_mt(const GemmArgs& a) {
 
 static int check_gemm(const void* x, const void* w, const void* y, int M, int N, int K) {
   if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return MI_EINVAL;
-  if (M > 64 || K % 32 || N % 16) return MI_EUNSUPPORTED;
+  if (M > kSkinnyMaxRows || K % 32 || N % 16) return MI_EUNSUPPORTED;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return MI_EINVAL;
   return MI_OK;
 }

@@ -1,5 +1,5 @@
 // bf16 MFMA tile GEMM for the compute-bound regime (M > 64 rows of activations: every prefill projection,
-// decode batches above 64 sequences).
+// large decode batches).
 //
 //   y[M][N] = x[M][K] @ w[N][K]^T (+ bias)        (reference: F.linear, linear.py:51,73,150)
 //   epilogue 1: y[M][N/2] = SiluAndMul(x @ w^T)    (activation.py:10-12 on MergedColumnParallelLinear, linear.py:73)
@@ -7,23 +7,31 @@
 // Both operands are K-contiguous, so both are staged the same way: whole 128-byte lines by LDS-DMA
 // (global_load_lds_dwordx4) into XOR-swizzled 16 KiB half-tiles (layout and index arithmetic: gemm_tile_index.hpp).
 //
-// Schedule (one workgroup = 8 waves = one 256 x 256 output tile, 129 KiB of LDS, one workgroup per CU):
-//   * the K loop is a stream of half-tiles q = 4 * kstep + h; phase p = 4 * kstep + ph consumes the half-tiles
-//     q <= p + 1 and issues half-tile p + 5 (two DMA instructions per wave), so five half-tiles are always
-//     requested ahead and no wait in the loop is vmcnt(0): after issuing p + 5 a wave waits vmcnt(6), i.e. for its
-//     own pieces of every half-tile <= p + 2, and the workgroup barrier behind that wait publishes them to the
-//     readers of phase p + 1;
-//   * the two waves that share a SIMD (wave w and w + 4) run one barrier apart: while one issues its eight
-//     v_mfma_f32_32x32x16_bf16 of a phase, the other one reads the next phase's fragments (ds_read_b128,
-//     conflict-free through the swizzle) and issues its DMA - the matrix pipe of a SIMD always has one wave
-//     feeding it;
-//   * past-the-end half-tiles are fetched into a spare 1 KiB block, so the wait counts are the same in every phase.
-// Workgroups are dealt to the XCDs so that one XCD's L2 holds a contiguous run of tiles (feature-fastest: the
-// tiles that run together share their activation rows).
+// Schedule (one workgroup = 8 waves, 129 KiB of LDS, one workgroup per CU, PERSISTENT: workgroup b computes the
+// 256 x 256 tiles b, b + grid, ...; the DMA stream runs on across tile seams, so only a workgroup's first tile
+// pays the fill latency and a tile's stores overlap the next tile's loads):
+//   * a K step t is two phases of sixteen v_mfma_f32_32x32x16_bf16 per wave (512 cycles of matrix pipe each), each
+//     phase a read segment R and a matrix segment M between workgroup barriers:
+//       R_P0(t): reads A half 0, B half 0, B half 1 of step t (16 ds_read_b128);
+//                DMA of B half 1, A half 1 of step t + 1 (4 pieces)
+//       M_P0(t): (A0 x B0, A0 x B1), sixteen MFMAs back to back
+//       R_P1(t): reads A half 1 of step t (8 ds_read_b128); DMA of A half 0, B half 0 of step t + 2 (4 pieces)
+//       M_P1(t): (A1 x B1, A1 x B0)
+//     A DMA instruction blocks its wave for ~75 cycles: issued between MFMAs that is 75 cycles of idle matrix pipe
+//     (measured: 20-26 % of the kernel), issued by the READING wave it hides under the partner's MFMA cluster.
+//     Every piece has at least two segments to land.  No wait in the loop is vmcnt(0): a wave waits vmcnt(8) at the
+//     end of R_P0 (A1 of this step landed) and vmcnt(6) at the end of R_P1 (A0, B0, B1 of the next step landed),
+//     for its OWN pieces, and for its fragment reads (lgkmcnt(0): a slot just read may be re-filled by the partner
+//     group one barrier later); the workgroup barrier behind the wait publishes the pieces to the next readers;
+//   * the two waves that share a SIMD (wave w and w + 4) run one barrier apart: while one issues its MFMA cluster,
+//     the other reads the next phase's fragments - the matrix pipe of a SIMD always has one wave feeding it;
+//   * past-the-end pieces (no further tile) are fetched into a spare 1 KiB block: the wait counts never change.
+//     The first R_P0 of every tile waits vmcnt(0): the previous tile's stores sit on the same counter.
+// Tile order: plain (see tile_of_block).
 //
 // Summation order: one fp32 MFMA chain over K per output element (k ascending), rounded to bf16 once -
 // the same rounding points as F.linear; the SwiGLU epilogue keeps the reference's three roundings
-// (bf16 gate_up output, bf16 silu, bf16 product) exactly as the decode GEMM's epilogue does.
+// (bf16 gate_up output, bf16 silu, bf16 product).
 #include <type_traits>
 
 #include "mi_common.hpp"
@@ -34,7 +42,7 @@ using namespace gt;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-enum { TEPI_NONE = 0, TEPI_SILU = 1 };
+enum { TEPI_NONE = 0, TEPI_SILU = 1, TEPI_PARTIAL = 2 };
 
 struct TileArgs {
   const uint16_t* x;
@@ -44,213 +52,402 @@ struct TileArgs {
   int64_t ldx, ldy;
   int M, N, K;
   int tiles_f, tiles_t;
+  float* part;  // split-K (gridDim.y > 1): fp32 partial sums [gridDim.y][M][N] instead of y
 };
 
-// Tuning variants (mi_gemm_bf16_ex; the product entry point uses kDefaultVariant):
-//   PF       half-tiles requested ahead of the issuing phase (5 or 6); a wave's wait leaves PF - 2 of them in flight.
-//            6 is the most the eight LDS slots allow with every overwrite two barriers behind the last read.
-//   V & 1    no s_setprio around the MFMA clusters
+// Tuning variants (mi_gemm_bf16_ex; the product entry point uses kDefaultV):
 //   V & 2    both waves of a SIMD in lockstep (no one-barrier stagger)
-//   V & 4    workgroup b takes tile b (no XCD-aware order)
-constexpr int kDefaultPF = 5, kDefaultV = 0;
+//   V & 4    XCD-rectangle tile order instead of the plain one (tile_of_block; measured equal or slower)
+//   V & 8    8-byte stores in the epilogue (no v_permlane32_swap widening)
+//   V & 16   one tile per workgroup (grid = tiles, not persistent)
+//   V & 32 / 64 / 128   ABLATIONS for timing only (wrong results): no DMA in the K loop / no fragment reads in the K
+//            loop / no workgroup barriers in the K loop
+constexpr int kDefaultV = 0;
+constexpr int kPersistentGrid = 256;  // one workgroup per CU
 
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier() {
-  static_assert(N == 6 || N == 8, "vmcnt immediates used by the K loop");
-  if (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-}
 #define MI_GT_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int EPI, bool BIAS, int PF, int V>
+// tile of "block" b.  Plain order (the default): tile b, feature tiles fastest.  The dispatcher places workgroup b
+// on XCD b % 8 (a speed assumption only) and a persistent workgroup keeps b % 8 - and, the feature-tile count dividing
+// 256 for every shape of the path, its feature tile - over its tiles: its 256 x K weight panel stays in the XCD's L2
+// while the activation panels stream through.  The alternative (rect): the 32 workgroups an XCD runs together are
+// given a GT x GF rectangle of tiles, GT activation + GF weight panels per K step; measured equal or slower
+// (tools/gemm_bench.py), kept as a tuning variant.
+__device__ __forceinline__ int tile_of_block(int b, int tiles_t, int tiles_f, bool rect) {
+  const int ntiles = tiles_t * tiles_f;
+  if (!rect) return b;
+  const int gf = tiles_f % 8 == 0 ? 8 : (tiles_f % 4 == 0 ? 4 : (tiles_f % 2 == 0 ? 2 : 1)), gt = 32 / gf;
+  const int xcd = b & 7, idx = b >> 3;
+  if (ntiles % 256 == 0 && tiles_t % gt == 0) {
+    const int r = (idx >> 5) * 8 + xcd, local = idx & 31, rc = tiles_f / gf;
+    return ((r / rc) * gt + local / gf) * tiles_f + (r % rc) * gf + local % gf;
+  }
+  // any other grid: XCD x takes the x-th contiguous run of tiles (bijective for every ntiles)
+  const int qn = ntiles >> 3, rn = ntiles & 7;
+  return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+}
+
+template <int EPI, bool BIAS, int V>
 __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
-  static_assert(PF == 5 || PF == 6, "prefetch distance");
-  constexpr int VM = 2 * (PF - 2);  // DMA instructions that may stay in flight behind a phase's wait
   // ONE LDS object (a second one makes hipcc drain the DMA queue before every fragment read)
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fh = wave >> 2, tq = wave & 3, hi = lane >> 5, l31 = lane & 31;
+  // split-K: blockIdx.y takes the K steps [kbeg, kbeg + KT) of every tile it is given
+  const int KT_all = a.K / BK;
+  const int KT = EPI == TEPI_PARTIAL ? KT_all / (int)gridDim.y : KT_all;
+  const int64_t kbeg_bytes = EPI == TEPI_PARTIAL ? (int64_t)blockIdx.y * KT * (BK * 2) : 0;
+  const int ntiles = a.tiles_f * a.tiles_t, stride = (int)gridDim.x;
 
-  // XCD-aware tile order: workgroup b runs on XCD b % 8; XCD x takes the x-th contiguous run of tiles
-  const int ntiles = a.tiles_f * a.tiles_t;
-  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-  const int qn = ntiles >> 3, rn = ntiles & 7;
-  const int tid = (V & 4) ? (int)blockIdx.x : (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  const int m0 = (tid / a.tiles_f) * TILE_T, n0 = (tid % a.tiles_f) * TILE_F;
-  const int KT = a.K / BK;
-
-  // ---- LDS-DMA sources: byte offset of this lane's 16 bytes for (half-tile h, instruction i), K step 0 ----
+  // ---- LDS-DMA sources: byte offset (K step 0) of this lane's 16 bytes of piece (half-tile h, instruction i) of
+  // the tile at (m0, n0) ----
+  auto src_offset = [&](int h, int i, int m0, int n0) __attribute__((always_inline)) -> uint32_t {
+    const int lr = dma_local_row(wave, i, lane), c = dma_chunk(wave, i, lane), r = tile_row(h, lr);
+    if (is_weight_half(h)) {
+      // SwiGLU: the tile's feature rows are 128 gate rows (A half 0 of both feature halves) and the 128 up rows
+      // that pair with them (A half 1)
+      const int row = EPI == TEPI_SILU ? ((r >> 6) & 1) * (a.N >> 1) + (n0 >> 1) + (r >> 7) * 64 + (r & 63) : n0 + r;
+      return (uint32_t)(((int64_t)min(row, a.N - 1) * a.K + c * 8) * 2);
+    }
+    return (uint32_t)(((int64_t)min(m0 + r, a.M - 1) * a.ldx + c * 8) * 2);
+  };
+  int blk = (int)blockIdx.x;  // "block id" of the current tile
+  auto coords = [&](int b, int& m0_, int& n0_) __attribute__((always_inline)) {
+    const int tid = tile_of_block(b, a.tiles_t, a.tiles_f, (V & 4) != 0);
+    m0_ = (tid / a.tiles_f) * TILE_T;
+    n0_ = (tid % a.tiles_f) * TILE_F;
+  };
+  int m0, n0, m0_next = 0, n0_next = 0;
+  coords(blk, m0, n0);
+  bool has_next = blk + stride < ntiles;
+  if (has_next) coords(blk + stride, m0_next, n0_next);
+  // src_off[h][i] belongs to the tile that half-tile h is CURRENTLY being fetched for: the stream runs two K steps
+  // ahead, so near the end of a tile the offsets of the A0 / B halves, then of A1, switch to the next tile
   uint32_t src_off[4][2];
 #pragma unroll
   for (int h = 0; h < 4; ++h)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int lr = dma_local_row(wave, i, lane), c = dma_chunk(wave, i, lane), r = tile_row(h, lr);
-      if (is_weight_half(h)) {
-        // SwiGLU: the tile's feature rows are 128 gate rows (A half 0 of both feature halves) and the 128 up rows
-        // that pair with them (A half 1)
-        const int row = EPI == TEPI_SILU ? ((r >> 6) & 1) * (a.N >> 1) + (n0 >> 1) + (r >> 7) * 64 + (r & 63) : n0 + r;
-        src_off[h][i] = (uint32_t)(((int64_t)min(row, a.N - 1) * a.K + c * 8) * 2);
-      } else {
-        src_off[h][i] = (uint32_t)(((int64_t)min(m0 + r, a.M - 1) * a.ldx + c * 8) * 2);
-      }
-    }
+    for (int i = 0; i < 2; ++i) src_off[h][i] = src_offset(h, i, m0, n0);
+
+  // The K steps of a workgroup form ONE stream over all its tiles; `par` is the parity of the stream position of
+  // the step being computed (it selects the four LDS slots of that step) and simply keeps toggling across tiles.
+  int par = 0;
+  // issue piece i of half-tile h of step kt_target (< KT) of the current tile into the slots of parity p
+  auto issue_cur = [&](int h, int i, int kt_target, int p) __attribute__((always_inline)) {
+    if ((V & 32) && kt_target > 1) return;
+    const char* src = reinterpret_cast<const char*>(is_weight_half(h) ? a.w : a.x) + kbeg_bytes + (int64_t)kt_target * (BK * 2) + src_off[h][i];
+    char* dst = lds + (p * 4 + h) * HALF_BYTES + dma_block(wave, i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  // the same for step ke (0 or 1) of the workgroup's NEXT tile (src_off[h] already points at it); without a next
+  // tile the piece goes to the spare block, from an address that is valid in any case
   char* const dummy = lds + SLOTS * HALF_BYTES;
-  // issue half-tile h of K step kt (kt >= KT: into the spare block)
-  auto issue = [&](int h, int kt) __attribute__((always_inline)) {
-    const bool live = kt < KT;
-    const char* base = reinterpret_cast<const char*>(is_weight_half(h) ? a.w : a.x) + (live ? (int64_t)kt * (BK * 2) : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      char* dst = live ? lds + ((kt & 1) * 4 + h) * HALF_BYTES + dma_block(wave, i) * 1024 : dummy;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + src_off[h][i]),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
+  auto issue_next = [&](int h, int i, int ke, int p) __attribute__((always_inline)) {
+    if (V & 32) return;
+    const char* src = reinterpret_cast<const char*>(is_weight_half(h) ? a.w : a.x) + kbeg_bytes + (has_next ? (int64_t)ke * (BK * 2) : 0) + src_off[h][i];
+    char* dst = has_next ? lds + (p * 4 + h) * HALF_BYTES + dma_block(wave, i) * 1024 : dummy;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
 
-  // ---- fragment reads: per-lane byte offsets inside a half-tile ----
-  int kx[4];
+  // ---- fragment reads: per-lane byte offsets inside a half-tile, plus the parity's 64 KiB ----
+  int kxa[4], kxb[4];
   {
     const int rowoff = (l31 >> 3) * 1024 + (l31 & 7) * 128, sw = swizzle(l31);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) kx[kk] = rowoff + ((frag_chunk(kk, hi) ^ sw) << 4);
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kx = rowoff + ((frag_chunk(kk, hi) ^ sw) << 4);
+      kxa[kk] = kx + fh * 8192;  // + h * HALF_BYTES + f * 4096 as immediates
+      kxb[kk] = kx + tq * 4096;  // + h * HALF_BYTES
+    }
   }
-  const char* const ldsA = lds + fh * 8192;  // + slot * HALF_BYTES + a * 4096 + kx[kk]
-  const char* const ldsB = lds + tq * 4096;  // + slot * HALF_BYTES + kx[kk]
+  auto flip_parity = [&]() __attribute__((always_inline)) {
+    par ^= 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kxa[kk] ^= 4 * HALF_BYTES;
+      kxb[kk] ^= 4 * HALF_BYTES;
+    }
+  };
 
   u32x4 Af[2][4], B0[4], B1[4];
   f32x16 acc[4][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+  };
+  zero_acc();
 
-  auto read_a = [&](int slot) __attribute__((always_inline)) {
+  bool ablate_reads = false;  // V & 64: only the first K step reads its fragments
+  auto read_a = [&](int h) __attribute__((always_inline)) {
+    if ((V & 64) && ablate_reads) return;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
-        Af[f][kk] = *reinterpret_cast<const u32x4*>(ldsA + slot * HALF_BYTES + f * 4096 + kx[kk]);
+        Af[f][kk] = *reinterpret_cast<const u32x4*>(lds + h * HALF_BYTES + f * 4096 + kxa[kk]);
   };
-  auto read_b = [&](int slot, u32x4 (&B)[4]) __attribute__((always_inline)) {
+  auto read_b = [&](int h, u32x4 (&B)[4]) __attribute__((always_inline)) {
+    if ((V & 64) && ablate_reads) return;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) B[kk] = *reinterpret_cast<const u32x4*>(ldsB + slot * HALF_BYTES + kx[kk]);
+    for (int kk = 0; kk < 4; ++kk) B[kk] = *reinterpret_cast<const u32x4*>(lds + h * HALF_BYTES + kxb[kk]);
   };
-  auto mma = [&](int ah, int bh, const u32x4 (&B)[4]) __attribute__((always_inline)) {
-    if (!(V & 1)) __builtin_amdgcn_s_setprio(1);
+  // the four MFMAs of k group kk of a phase: A half ah x (B half bx, B half by) - four independent accumulators
+  auto mma_k = [&](int ah, int kk, const u32x4 (&Bx)[4], int bx, const u32x4 (&By)[4], int by) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-        acc[ah * 2 + f][bh] =
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(Af[f][kk]), as_frag(B[kk]), acc[ah * 2 + f][bh], 0, 0, 0);
-    if (!(V & 1)) __builtin_amdgcn_s_setprio(0);
-  };
-
-  // one K step = four phases; st = kt & 1 as a compile-time constant (the LDS addresses fold into immediates)
-  auto kstep = [&](int kt, auto stc) __attribute__((always_inline)) {
-    constexpr int st = decltype(stc)::value;
-    // phase 0: (A half 0, B half 0)
-    read_a(st * 4 + 0);
-    read_b(st * 4 + 1, B0);
-    issue((0 + PF) & 3, kt + ((0 + PF) >> 2));
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vm_barrier<VM>();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, 0, B0);
-    __builtin_amdgcn_sched_barrier(0);
-    MI_GT_BARRIER();
-    // phase 1: (A half 0, B half 1)
-    read_b(st * 4 + 2, B1);
-    issue((1 + PF) & 3, kt + ((1 + PF) >> 2));
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vm_barrier<VM>();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, 1, B1);
-    __builtin_amdgcn_sched_barrier(0);
-    MI_GT_BARRIER();
-    // phase 2: (A half 1, B half 1)
-    read_a(st * 4 + 3);
-    issue((2 + PF) & 3, kt + ((2 + PF) >> 2));
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vm_barrier<VM>();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1, 1, B1);
-    __builtin_amdgcn_sched_barrier(0);
-    MI_GT_BARRIER();
-    // phase 3: (A half 1, B half 0)
-    issue((3 + PF) & 3, kt + ((3 + PF) >> 2));
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vm_barrier<VM>();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1, 0, B0);
-    __builtin_amdgcn_sched_barrier(0);
-    MI_GT_BARRIER();
+    for (int f = 0; f < 2; ++f) {
+      acc[ah * 2 + f][bx] =
+          __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(Af[f][kk]), as_frag(Bx[kk]), acc[ah * 2 + f][bx], 0, 0, 0);
+      acc[ah * 2 + f][by] =
+          __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(Af[f][kk]), as_frag(By[kk]), acc[ah * 2 + f][by], 0, 0, 0);
+    }
   };
 
-  // prologue: half-tiles 0 .. PF - 1 requested, 0 and 1 landed and published
+  // One K step.  MODE 0: steps 0 .. KT - 3 (everything it requests belongs to this tile); MODE 1: step KT - 2 (A0, B0
+  // of step kt + 2 are the next tile's step 0); MODE 2: step KT - 1 (B1, A1 of the next tile's step 0, A0, B0 of its
+  // step 1).  ALL DMA is issued from the read segments, between the ds_reads: a DMA instruction blocks its wave for
+  // ~75 cycles, which inside an MFMA cluster is 75 cycles of idle matrix pipe (measured: 20-26 % of the kernel),
+  // while a reading wave's partner is computing.
+  auto kstep = [&](int kt, auto modec) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(modec)::value;
+    auto issue_1 = [&](int h, int i) __attribute__((always_inline)) {  // B half 1 / A half 1, one step ahead
+      if (MODE == 2) issue_next(h, i, 0, par ^ 1);
+      else issue_cur(h, i, kt + 1, par ^ 1);
+    };
+    auto issue_2 = [&](int h, int i) __attribute__((always_inline)) {  // A half 0 / B half 0, two steps ahead
+      if (MODE == 0) issue_cur(h, i, kt + 2, par);
+      else issue_next(h, i, MODE - 1, par);
+    };
+    // R_P0: A half 0, B half 0, B half 1 of this step; DMA of B half 1 and A half 1 of the next step
+    if (MODE == 2 && has_next) {  // from here on B half 1 and A half 1 are fetched for the next tile
 #pragma unroll
-  for (int q = 0; q < PF; ++q) issue(q & 3, q >> 2);
+      for (int h = 2; h < 4; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) src_off[h][i] = src_offset(h, i, m0_next, n0_next);
+    }
+    read_a(0);
+    issue_1(2, 0);
+    issue_1(2, 1);
+    read_b(1, B0);
+    issue_1(3, 0);
+    read_b(2, B1);
+    issue_1(3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // a tile's first wait: the previous tile's stores share the counter with the loads, drain it once
+    if (V & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (V & 256) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ablation: DMA never waited for
+    else if (kt == 0 || (V & 32)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // M_P0
+    mma_k(0, 0, B0, 0, B1, 1);
+    mma_k(0, 1, B0, 0, B1, 1);
+    mma_k(0, 2, B0, 0, B1, 1);
+    mma_k(0, 3, B0, 0, B1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(V & 128)) MI_GT_BARRIER();
+    // R_P1: A half 1 of this step; DMA of A half 0 and B half 0 two steps ahead
+    if ((MODE == 1 || (MODE == 2 && KT == 1)) && has_next) {  // from here on A half 0 and B half 0 are the next tile's
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) src_off[h][i] = src_offset(h, i, m0_next, n0_next);
+    }
+    read_a(3);
+    issue_2(0, 0);
+    issue_2(0, 1);
+    issue_2(1, 0);
+    issue_2(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (V & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (V & 256) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (V & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // M_P1
+    mma_k(1, 0, B1, 1, B0, 0);
+    mma_k(1, 1, B1, 1, B0, 0);
+    mma_k(1, 2, B1, 1, B0, 0);
+    mma_k(1, 3, B1, 1, B0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(V & 128)) MI_GT_BARRIER();
+    flip_parity();
+    ablate_reads = true;
+  };
+
+  // ---- epilogue of the tile at (m0, n0): lane (hi, l31) holds token acc_token(...), features 8 rq + 4 hi + {0..3} of
+  // each 32-row fragment.  Two register quads (rq, rq + 1) are exchanged between the half-waves
+  // (v_permlane32_swap) so that every lane stores 8 consecutive features = 16 bytes: half the store instructions
+  // for the same bytes.
+  const int n_out = EPI == TEPI_SILU ? a.N >> 1 : a.N;
+  const bool wide = !(V & 8) && n_out % 8 == 0 && a.ldy % 8 == 0;
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    if (EPI == TEPI_PARTIAL) {  // fp32 sums of this K slice: [slice][token][feature], 16 bytes per lane and register quad
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh) {
+        const int tok = m0 + acc_token(tq, bh, l31);
+        float* prow = a.part + ((int64_t)blockIdx.y * a.M + min(tok, a.M - 1)) * a.N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int col = n0 + acc_feature(fh, j >> 1, j & 1, 4 * rq, hi);
+            if (tok < a.M && col < a.N)
+              *reinterpret_cast<f32x4*>(prow + col) =
+                  f32x4{acc[j][bh][4 * rq], acc[j][bh][4 * rq + 1], acc[j][bh][4 * rq + 2], acc[j][bh][4 * rq + 3]};
+          }
+      }
+      return;
+    }
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh) {
+      const int tok = m0 + acc_token(tq, bh, l31);
+      const bool tok_ok = tok < a.M;
+      uint16_t* yrow = a.y + (int64_t)min(tok, a.M - 1) * a.ldy;
+#pragma unroll
+      for (int j = 0; j < (EPI == TEPI_SILU ? 2 : 4); ++j) {
+        // first column of this fragment for hi = 0, rq = 0 (tile feature row fh * 128 + (j >> 1) * 64 + (j & 1) * 32)
+        const int col0 = EPI == TEPI_SILU ? (n0 >> 1) + fh * 64 + j * 32 : n0 + acc_feature(fh, j >> 1, j & 1, 0, 0);
+        u32x2 pk[4];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int col = col0 + 8 * rq + 4 * hi;
+          float o[4];
+          if (EPI == TEPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // the gate_up GEMM output rounded to bf16 as the unfused path, then silu in fp32 on the hardware
+              // exp2 / reciprocal (v_exp_f32, v_rcp_f32: a few fp32 ulps, i.e. below the bf16 rounding that follows
+              // except at ties; the libm expf + IEEE division of mi_silu_mul cost the 256 x 256 tile's epilogue - which
+              // nothing overlaps - 15 % of the kernel)
+              const float gb = rbf(acc[j][bh][4 * rq + e]);
+              const float sb = rbf(gb * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb * -1.4426950408889634f)));
+              o[e] = sb * rbf(acc[2 + j][bh][4 * rq + e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[j][bh][4 * rq + e];
+            if (BIAS && col < n_out) {
+              const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+              o[0] += lo_bf(bw[0]);
+              o[1] += hi_bf(bw[0]);
+              o[2] += lo_bf(bw[1]);
+              o[3] += hi_bf(bw[1]);
+            }
+          }
+          pk[rq] = u32x2{pack_bf(o[0], o[1]), pack_bf(o[2], o[3])};
+        }
+        if (wide) {
+#pragma unroll
+          for (int rq = 0; rq < 4; rq += 2) {
+            // lanes 32..63 of quad rq <-> lanes 0..31 of quad rq + 1: lanes < 32 then hold features 8 rq .. 8 rq + 7,
+            // lanes >= 32 features 8 (rq + 1) .. 8 (rq + 1) + 7
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[rq][0], pk[rq + 1][0], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[rq][1], pk[rq + 1][1], false, false);
+            const int col = col0 + 8 * (rq + hi);
+            if (tok_ok && col < n_out) *reinterpret_cast<u32x4*>(yrow + col) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+          }
+        } else {
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int col = col0 + 8 * rq + 4 * hi;
+            if (tok_ok && col < n_out) *reinterpret_cast<u32x2*>(yrow + col) = pk[rq];
+          }
+        }
+      }
+    }
+  };
+
+  // prologue, in the stream's order (R_P1 issues A0, B0 two steps ahead; R_P0 issues B1, A1 one step ahead):
+  // A0, B0 of step 0 | B1, A1 of step 0 | A0, B0 of step 1; everything but the six newest pieces - that is A0, B0,
+  // B1 of step 0 - landed and published.  (K = 64: "step 1" is the next tile's step 0.)
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_cur(h, i, 0, 0);
+  if (KT > 1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) issue_cur(h, i, 1, 1);
+  } else {
+    if (has_next) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) src_off[h][i] = src_offset(h, i, m0_next, n0_next);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) issue_next(h, i, 0, 1);
+  }
   __builtin_amdgcn_sched_barrier(0);
-  wait_vm_barrier<VM>();
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
   if (!(V & 2) && fh == 1) MI_GT_BARRIER();  // the second wave of every SIMD runs one barrier behind the first
   __builtin_amdgcn_sched_barrier(0);
 
-  int kt = 0;
-  for (; kt + 1 < KT; kt += 2) {
-    kstep(kt, std::integral_constant<int, 0>{});
-    kstep(kt + 1, std::integral_constant<int, 1>{});
+  for (;;) {
+    for (int kt = 0; kt < KT - 2; ++kt) kstep(kt, std::integral_constant<int, 0>{});
+    if (KT > 1) kstep(KT - 2, std::integral_constant<int, 1>{});
+    kstep(KT - 1, std::integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    epilogue();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!has_next) break;
+    zero_acc();
+    blk += stride;
+    m0 = m0_next;
+    n0 = n0_next;
+    has_next = blk + stride < ntiles;
+    if (has_next) coords(blk + stride, m0_next, n0_next);
   }
-  if (kt < KT) kstep(kt, std::integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the past-the-end loads must not outlive the workgroup's LDS
   if (!(V & 2) && fh == 0) MI_GT_BARRIER();         // barrier counts match again
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- epilogue: lane (hi, l31) holds token acc_token(...), features 8 rq + 4 hi + {0..3} of each 32-row fragment ----
-  const int n_out = EPI == TEPI_SILU ? a.N >> 1 : a.N;
-#pragma unroll
-  for (int bh = 0; bh < 2; ++bh) {
-    const int tok = m0 + acc_token(tq, bh, l31);
-    if (tok >= a.M) continue;
-    uint16_t* yrow = a.y + (int64_t)tok * a.ldy;
-#pragma unroll
-    for (int j = 0; j < (EPI == TEPI_SILU ? 2 : 4); ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        // tile feature row of register 4 rq: fh * 128 + (j >> 1) * 64 + (j & 1) * 32 + 8 rq + 4 hi
-        float o[4];
-        int col;
-        if (EPI == TEPI_SILU) {
-          col = (n0 >> 1) + fh * 64 + j * 32 + 8 * rq + 4 * hi;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float gb = rbf(acc[j][bh][4 * rq + e]);  // the gate_up GEMM output, rounded to bf16 as the unfused path
-            const float sb = rbf(gb / (1.0f + expf(-gb)));
-            o[e] = sb * rbf(acc[2 + j][bh][4 * rq + e]);
-          }
-        } else {
-          col = n0 + acc_feature(fh, j >> 1, j & 1, 4 * rq, hi);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[j][bh][4 * rq + e];
-          if (BIAS && col < n_out) {
-            const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
-            o[0] += lo_bf(bw[0]);
-            o[1] += hi_bf(bw[0]);
-            o[2] += lo_bf(bw[1]);
-            o[3] += hi_bf(bw[1]);
-          }
-        }
-        if (col < n_out) *reinterpret_cast<u32x2*>(yrow + col) = u32x2{pack_bf(o[0], o[1]), pack_bf(o[2], o[3])};
-      }
-  }
 }
 
-template <int EPI, bool BIAS, int PF = kDefaultPF, int V = kDefaultV>
-static int launch_tile(const TileArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, PF, V>), dim3(a.tiles_f * a.tiles_t), dim3(512), 0, st, a);
+// sum of the split-K slices in slice order, (+ bias), one rounding to bf16: four features per thread
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit,
+                                                                   const uint16_t* __restrict__ bias,
+                                                                   uint16_t* __restrict__ y, int64_t ldy, int M, int N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = N >> 2;
+  if (idx >= (int64_t)M * nq) return;
+  const int row = (int)(idx / nq), col = (int)(idx % nq) * 4;
+  f32x4 s = *reinterpret_cast<const f32x4*>(part + (int64_t)row * N + col);
+  for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(part + ((int64_t)k * M + row) * N + col);
+  if (bias) {
+    const u32x2 bw = *reinterpret_cast<const u32x2*>(bias + col);
+    s[0] += lo_bf(bw[0]);
+    s[1] += hi_bf(bw[0]);
+    s[2] += lo_bf(bw[1]);
+    s[3] += hi_bf(bw[1]);
+  }
+  *reinterpret_cast<u32x2*>(y + (int64_t)row * ldy + col) = u32x2{pack_bf(s[0], s[1]), pack_bf(s[2], s[3])};
+}
+
+// K slices for a shape whose tiles cannot fill the chip (few token rows x a narrow projection): the smallest
+// power of two that brings tiles x slices to ~one workgroup per CU, every slice at least four K steps deep
+static int tile_ksplit(int M, int N, int K) {
+  const int ntiles = ((M + TILE_T - 1) / TILE_T) * ((N + TILE_F - 1) / TILE_F), kt = K / BK;
+  int ks = 1;
+  while (ntiles * ks * 2 <= kPersistentGrid && kt % (ks * 2) == 0 && kt / (ks * 2) >= 4 && ks < 16) ks *= 2;
+  return ks;
+}
+
+template <int EPI, bool BIAS, int V = kDefaultV>
+static int launch_tile(const TileArgs& a, hipStream_t st, int ksplit = 1) {
+  // persistent workgroups: one per CU; the grid is a multiple of 8, so a workgroup stays in one XCD class
+  const int ntiles = a.tiles_f * a.tiles_t;
+  const bool persistent = !(V & 16) && ntiles > kPersistentGrid;
+  hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, V>), dim3(persistent ? kPersistentGrid : ntiles, ksplit), dim3(512), 0,
+                     st, a);
   return check_launch();
 }
 
@@ -271,30 +468,52 @@ static int check_tile_gemm(const void* x, int64_t ldx, const void* w, const void
 
 using namespace mi;
 
+extern "C" size_t mi_gemm_bf16_workspace(int M, int N, int K, int epilogue) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % BK || epilogue != 0) return 0;
+  const int ks = tile_ksplit(M, N, K);
+  return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+}
+
 extern "C" int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y,
-                            int64_t ldy, int M, int N, int K, int epilogue, mi_stream stream) {
+                            int64_t ldy, int M, int N, int K, int epilogue, void* workspace, size_t ws_bytes,
+                            mi_stream stream) {
   const int rc = check_tile_gemm(x, ldx, w, bias, y, ldy, M, N, K, epilogue);
   if (rc != MI_OK || M == 0) return rc;
-  const TileArgs a{x, w, bias, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T};
+  TileArgs a{x, w, bias, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T, nullptr};
   hipStream_t st = S(stream);
   if (epilogue == 1) return launch_tile<TEPI_SILU, false>(a, st);
+  const int ks = tile_ksplit(M, N, K);
+  if (ks > 1) {  // two launches: K slices as fp32 partial sums, then their sum (+ bias) rounded once
+    if (!workspace || !aligned16(workspace) || ws_bytes < mi_gemm_bf16_workspace(M, N, K, 0)) return MI_EWORKSPACE;
+    a.part = static_cast<float*>(workspace);
+    const int rc2 = launch_tile<TEPI_PARTIAL, false>(a, st, ks);
+    if (rc2 != MI_OK) return rc2;
+    const int64_t quads = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.part, ks, bias, y,
+                       ldy, M, N);
+    return check_launch();
+  }
   return bias ? launch_tile<TEPI_NONE, true>(a, st) : launch_tile<TEPI_NONE, false>(a, st);
 }
 
-// tuning entry point (tools/gemm_bench.py): variant = PF * 16 + V, no bias, plain epilogue
+// tuning entry point (tools/gemm_bench.py): variant = schedule flags V, no bias, plain epilogue
 extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, mi_bf16* y, int64_t ldy, int M, int N,
                                int K, int variant, mi_stream stream) {
   const int rc = check_tile_gemm(x, ldx, w, nullptr, y, ldy, M, N, K, 0);
   if (rc != MI_OK || M == 0) return rc;
-  const TileArgs a{x, w, nullptr, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T};
+  const TileArgs a{x, w, nullptr, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T, nullptr};
   hipStream_t st = S(stream);
   switch (variant) {
-    case 5 * 16 + 0: return launch_tile<TEPI_NONE, false, 5, 0>(a, st);
-    case 5 * 16 + 1: return launch_tile<TEPI_NONE, false, 5, 1>(a, st);
-    case 5 * 16 + 2: return launch_tile<TEPI_NONE, false, 5, 2>(a, st);
-    case 5 * 16 + 4: return launch_tile<TEPI_NONE, false, 5, 4>(a, st);
-    case 6 * 16 + 0: return launch_tile<TEPI_NONE, false, 6, 0>(a, st);
-    case 6 * 16 + 1: return launch_tile<TEPI_NONE, false, 6, 1>(a, st);
+    case 0: return launch_tile<TEPI_NONE, false, 0>(a, st);
+    case 2: return launch_tile<TEPI_NONE, false, 2>(a, st);
+    case 4: return launch_tile<TEPI_NONE, false, 4>(a, st);
+    case 8: return launch_tile<TEPI_NONE, false, 8>(a, st);
+    case 16: return launch_tile<TEPI_NONE, false, 16>(a, st);
+    case 32: return launch_tile<TEPI_NONE, false, 32>(a, st);
+    case 64: return launch_tile<TEPI_NONE, false, 64>(a, st);
+    case 96: return launch_tile<TEPI_NONE, false, 96>(a, st);
+    case 224: return launch_tile<TEPI_NONE, false, 224>(a, st);
+    case 256: return launch_tile<TEPI_NONE, false, 256>(a, st);
     default: return MI_EUNSUPPORTED;
   }
 }

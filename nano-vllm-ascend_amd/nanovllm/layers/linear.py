@@ -1,14 +1,14 @@
 """Tensor-parallel linear layers (reference: nanovllm/layers/linear.py) — same class
 names, constructor arguments and per-parameter `weight_loader` sharding rules.
 
-forward(): activations with at most 64 rows (every decode step) go through the
-hand-written weight-streaming MFMA kernel mi_gemm_bf16_skinny; larger prefill batches
-are plain compute-bound GEMMs and use the library GEMM behind F.linear (hipBLASLt).
+forward(): decode-sized activations (at most ops.SKINNY_MAX_M rows) go through the hand-written
+weight-streaming MFMA kernels (mi_gemm_bf16_packed / _skinny, the rows in chunks of 64); everything
+larger - every prefill projection - through the 256 x 256 MFMA tile kernel mi_gemm_bf16
+(csrc/gemm_tile.hip).  No library GEMM anywhere on the path.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from nanovllm import ops
@@ -25,8 +25,9 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
         if packed is not None:
             return ops.gemm_packed(x, packed, bias)
         return ops.gemm_skinny(x, weight, bias)
-    ops.require_gpu(x, weight)
-    return F.linear(x, weight, bias)
+    shape = x.shape
+    y = ops.gemm_tile(x.reshape(-1, shape[-1]), weight, bias)
+    return y.view(*shape[:-1], weight.shape[0])
 
 
 def can_pack(weight: torch.Tensor) -> bool:

@@ -127,7 +127,16 @@ class Qwen3MLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        gu = self.gate_up_proj
+        rows = x.numel() // x.shape[-1]
+        if (rows > ops.SKINNY_MAX_M and gu.bias is None and x.is_cuda and gu.weight.shape[1] % 64 == 0
+                and (gu.weight.shape[0] // 2) % 128 == 0):
+            # prefill-sized: SiluAndMul is the tile GEMM's epilogue (the reference's three roundings; the
+            # 2 x intermediate wide gate_up output never exists in memory)
+            shape = x.shape
+            act = ops.gemm_tile(x.reshape(-1, shape[-1]), gu.weight, silu_mul=True)
+            return self.down_proj(act.view(*shape[:-1], -1))
+        return self.down_proj(self.act_fn(gu(x)))
 
 
 class Qwen3DecoderLayer(nn.Module):

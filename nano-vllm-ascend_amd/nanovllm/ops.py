@@ -275,11 +275,13 @@ def silu_mul(x, out=None) -> torch.Tensor:
     return out
 
 
-SKINNY_MAX_M = 64
+# rows the weight-streaming decode kernels take in one launch (chunks of 64 rows, csrc kSkinnyMaxRows); the decode
+# fast path of the models, the in-graph sampler and the engine's lookahead all go up to this many sequences
+SKINNY_MAX_M = 512
 
 
 def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
-    """y = x @ w.T (+ bias) for M <= 64 rows (decode)."""
+    """y = x @ w.T (+ bias) for M <= SKINNY_MAX_M rows (decode)."""
     require_gpu(x, w, bias)
     _bf16(x, w, bias)
     assert x.is_contiguous() and w.is_contiguous()
@@ -314,9 +316,24 @@ def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | 
         check(lib.mi_gemm_bf16_ex(ptr(x), x.stride(0), ptr(w), ptr(out), out.stride(0), M, N, K, variant, stream()),
               "mi_gemm_bf16_ex")
         return out
+    need = lib.mi_gemm_bf16_workspace(M, N, K, int(silu_mul))
+    ws = _gemm_workspace(x.device, need) if need else None
     check(lib.mi_gemm_bf16(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(out), out.stride(0), M, N, K, int(silu_mul),
-                           stream()), "mi_gemm_bf16")
+                           ptr(ws), need, stream()), "mi_gemm_bf16")
     return out
+
+
+_GEMM_WS: dict[torch.device, torch.Tensor] = {}
+
+
+def _gemm_workspace(device, nbytes: int) -> torch.Tensor:
+    """split-K partial sums of the tile GEMM (one buffer per device, grown on demand; launches on one stream are
+    ordered, so consecutive GEMMs may share it)"""
+    ws = _GEMM_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _GEMM_WS[device] = ws
+    return ws
 
 
 def pack_weight(w, out=None) -> torch.Tensor:

@@ -45,7 +45,25 @@ def test_gemm_tile_vs_oracle(ops, M, N, K):
     ye = ops.gemm_tile(xe.to(DEV), w.to(DEV)).cpu()
     assert torch.equal(ye[M - 3].view(torch.int16), w[:, 5].contiguous().view(torch.int16))
     assert torch.equal(ye[1].view(torch.int16), w[:, K - 1].contiguous().view(torch.int16))
-    assert float(ye.float().abs().sum() - ye[M - 3].float().abs().sum() - ye[1].float().abs().sum()) == 0.0
+    ye[M - 3] = 0
+    ye[1] = 0
+    assert int((ye.view(torch.int16) & 0x7FFF).count_nonzero()) == 0  # every other row is exactly (+-) zero
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 1024])
+def test_gemm_tile_persistent_ragged(ops, K):
+    """more tiles than workgroups (18 x 16 = 288 tiles on 256 persistent workgroups: the DMA stream crosses tile
+    seams) with ragged last tiles in both dimensions, one / two / three K steps (both slot parities at the seam)"""
+    M, N = 4400, 4000
+    g, x, w = _case(M, N, K, seed=21)
+    b = torch.randn(N, generator=g).bfloat16()
+    y = ops.gemm_tile(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert_bf16_close(y, oracle.linear(x, w, b), max_ulp=1, max_frac=2e-2, atol=K * 2.0 ** -22)
+    one_tile_each = ops.gemm_tile(x.to(DEV), w.to(DEV), variant=16)  # grid = tiles
+    assert torch.equal(ops.gemm_tile(x.to(DEV), w.to(DEV)).view(torch.int16), one_tile_each.view(torch.int16))
+    gu = ops.gemm_tile(x.to(DEV), w[:3840].contiguous().to(DEV), silu_mul=True)  # 15 x 18 = 270 tiles
+    assert torch.equal(gu.view(torch.int16),
+                       ops.silu_mul(ops.gemm_tile(x.to(DEV), w[:3840].contiguous().to(DEV))).view(torch.int16))
 
 
 @pytest.mark.parametrize("M", [65, 256, 777])
@@ -59,7 +77,7 @@ def test_gemm_tile_swiglu_epilogue(ops, M, N, K):
     assert torch.equal(got.view(torch.int16), two_pass.view(torch.int16))
     atol = K * 2.0 ** -22
     # a 1-ulp flip of the gate (summation order) times |up| <= ~6: widen the near-zero floor
-    assert_bf16_close(got, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=2, max_frac=3e-2, atol=32 * atol)
+    assert_bf16_close(got, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=4, max_frac=3e-2, atol=32 * atol)
 
 
 def test_gemm_tile_strided_rows(ops):
@@ -83,7 +101,7 @@ def test_gemm_tile_full_prefill_shape_and_variants(ops):
     want = oracle.linear(x[:2048], w)  # the oracle on the first 2048 rows and on the last tile's rows
     assert_bf16_close(y[:2048], want, max_frac=2e-2, atol=K * 2.0 ** -22)
     assert_bf16_close(y[-300:], oracle.linear(x[-300:], w), max_frac=2e-2, atol=K * 2.0 ** -22)
-    for variant in (5 * 16 + 1, 5 * 16 + 2, 5 * 16 + 4, 6 * 16 + 0, 6 * 16 + 1):
+    for variant in (2, 4, 8, 16):
         yv = ops.gemm_tile(xd, wd, variant=variant)
         assert torch.equal(yv.view(torch.int16), y.view(torch.int16)), variant
     side = torch.cuda.Stream()
@@ -91,8 +109,7 @@ def test_gemm_tile_full_prefill_shape_and_variants(ops):
     for it in range(40):
         with torch.cuda.stream(side):
             junk.add_(1)  # uneven HBM pressure next to the DMA pipeline
-        v = (5 * 16, 6 * 16)[it & 1]
-        yv = ops.gemm_tile(xd, wd, variant=v)
+        yv = ops.gemm_tile(xd, wd, variant=(0, 2)[it & 1])
         assert torch.equal(yv.view(torch.int16), y.view(torch.int16)), it
     torch.cuda.synchronize()
     # linearity in the rows: permuting the activation rows permutes the output rows, bit for bit

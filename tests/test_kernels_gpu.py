@@ -327,6 +327,36 @@ def test_gemm_packed(ops, M, N, K):
         assert_bf16_close(y, yo, max_ulp=2, max_frac=3e-2, atol=4e-2)
 
 
+@pytest.mark.parametrize("M", [65, 128, 200, 512])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (256, 128)])
+def test_gemm_packed_more_than_64_rows(ops, M, N, K):
+    """decode batches above 64 sequences: the weight-streaming kernels walk the rows in chunks of 64 (grid.z) -
+    plain, SwiGLU, split-K partials + add_rmsnorm, complete rows (rows4), all against the oracle"""
+    g = torch.Generator().manual_seed(M * 5 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    wp = ops.pack_weight(w.to(DEV))
+    atol = K * 2.0 ** -22
+    assert_bf16_close(ops.gemm_skinny(x.to(DEV), w.to(DEV), b.to(DEV)), oracle.linear(x, w, b), max_frac=2e-2, atol=atol)
+    assert_bf16_close(ops.gemm_packed(x.to(DEV), wp), oracle.linear(x, w), max_frac=2e-2, atol=atol)
+    assert_bf16_close(ops.gemm_packed(x.to(DEV), wp, silu_mul=True), oracle.silu_and_mul(oracle.linear(x, w)),
+                      max_ulp=2, max_frac=3e-2, atol=32 * atol)
+    assert_bf16_close(ops.gemm_rows4(x.to(DEV), ops.pack_weight_rows4(w.to(DEV))), oracle.linear(x, w),
+                      max_frac=2e-2, atol=atol)
+    r = torch.randn(M, N, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).bfloat16()
+    yo, ro = oracle.add_rms_norm(oracle.linear(x, w), r, nw, 1e-6)
+    parts = ops.gemm_packed_splitk(x.to(DEV), wp, 2 if K % 64 == 0 else 1)
+    y, r2 = ops.add_rmsnorm_splitk(parts, r.to(DEV), nw.to(DEV), 1e-6)
+    assert_bf16_close(r2, ro, max_frac=2e-2, atol=4e-2)
+    assert_bf16_close(y, yo, max_ulp=2, max_frac=3e-2, atol=4e-2)
+    # each 64-row chunk is computed exactly as a 64-row call on its own
+    lo = ops.gemm_packed(x[64:128].contiguous().to(DEV), wp) if M >= 128 else None
+    if lo is not None:
+        assert torch.equal(lo.view(torch.int16), ops.gemm_packed(x.to(DEV), wp)[64:128].view(torch.int16))
+
+
 @pytest.mark.parametrize("N,K", [(1280, 5120), (5120, 1024), (6400, 5120), (5120, 3200)])
 def test_gemm_packed_qwen3_32b_tp8_shapes(ops, N, K):
     """per-rank projection shapes of BASELINE.json configs[2] (Qwen3-32B, TP=8): hidden 5120,

@@ -42,8 +42,10 @@ def main():
         (16384, 1024, 3072, "down"), (4096, 4096, 1024, "qkv@4k"), (1024, 4096, 1024, "qkv@1k"),
         (1024, 1024, 3072, "down@1k"), (256, 4096, 1024, "qkv@256"), (8192, 8192, 8192, "8k^3"),
     ]
-    variants = {"pf5": 5 * 16, "pf5_noprio": 5 * 16 + 1, "pf5_lockstep": 5 * 16 + 2, "pf5_noxcd": 5 * 16 + 4,
-                "pf6": 6 * 16, "pf6_noprio": 6 * 16 + 1}
+    variants = {"tile": 0, "lockstep": 2, "plain_order": 4, "narrow_stores": 8, "one_tile_per_wg": 16}
+    if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
+        variants = {"tile": 0, "no_dma": 32, "no_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
+                    "dma_never_waited": 256}
     rows = []
     for M, N, K, label in shapes:
         g = torch.Generator().manual_seed(M + N + K)
@@ -60,7 +62,7 @@ def main():
             row[name + "_us"] = round(t, 2)
             row[name + "_tflops"] = round(flops / t / 1e6, 1)
         ref = F.linear(x, w)
-        ops.gemm_tile(x, w, out=y)
+        ops.gemm_tile(x, w, out=y, variant=0)
         row["max_abs_diff_vs_library"] = float((y.float() - ref.float()).abs().max())
         if N % 256 == 0 and label in ("gate_up",):
             ya = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
