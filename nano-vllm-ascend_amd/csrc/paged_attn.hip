@@ -163,6 +163,14 @@ __device__ __forceinline__ void load_tiles(const uint16_t* __restrict__ cache, c
   load_tile(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(t2 % tpb) * st.tile, lane, T1);
 }
 
+// The same from resolved tile offsets (elements from the cache base of this kv head): no table read, no stride
+// arithmetic between the end of one chunk and the 16 loads of the next
+__device__ __forceinline__ void load_tiles_at(const uint16_t* __restrict__ cache_h, int64_t off0, int64_t off1, int lane,
+                                              u32x4 (&T0)[4], u32x4 (&T1)[4]) {
+  load_tile(cache_h + off0, lane, T0);
+  load_tile(cache_h + off1, lane, T1);
+}
+
 // Operands of the fused step prologue (FUSE): the packed qkv row of QKVParallelLinear is consumed
 // directly - q_norm / k_norm / RoPE (qwen3.py:83-88) and the scatter of the new token's K / V row
 // (attention.py:32-35) happen inside the attention launch (bit-identical to mi_qknorm_rope_store,
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* kc,
     const uint16_t* vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ ctx_lens, float* __restrict__ part_o, float* __restrict__ part_ml,
-    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, float scale_log2e, FusedStep fs) {
+    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, int tpb_shift, float scale_log2e, FusedStep fs) {
   static_assert(!FUSE || PIPE, "the fused prologue needs the register room of the 8-wave form");
   __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
   __shared__ float sm_m[WAVES][16];
@@ -433,13 +441,41 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     u32x4 AK0[4], AK1[4], AV0[4], AV1[4], BK0[4], BK1[4], BV0[4], BV1[4];
     bf16x8 Q[4];
     int ta = t0, tb = t0 + 2;
+    // The wave's whole run of block ids is read ONCE, by one vector load issued ahead of everything else: lane i
+    // keeps the element offset of block (b_first + i).  A chunk's two tile addresses are then two pairs of
+    // v_readlane and two scalar adds - the round-1/2 form went to the scalar cache for the block ids (s_load +
+    // lgkmcnt(0)) and through ~20 s_mul of 64-bit stride arithmetic between finishing a chunk and issuing the next
+    // one's 16 loads, with only the other buffer's loads in flight.  Runs of more than 64 blocks (contexts beyond
+    // 64 x block_size x waves tokens) take the table path.
+    const uint16_t* const kc_h = kc + (int64_t)h * kvs.head;
+    const uint16_t* const vc_h = vc + (int64_t)h * kvs.head;
+    const int b_first = tpb_shift >= 0 ? t0 >> tpb_shift : t0 / tpb;
+    const int b_last = t1 > t0 ? (tpb_shift >= 0 ? (t1 - 1) >> tpb_shift : (t1 - 1) / tpb) : b_first;
+    const bool resolved = b_last - b_first < 64;  // wave-uniform
+    uint32_t run_lo = 0, run_hi = 0;
+    if (resolved) {
+      const int64_t o = (int64_t)table_row[min(b_first + lane, table_stride - 1)] * kvs.block;
+      run_lo = (uint32_t)o;
+      run_hi = (uint32_t)((uint64_t)o >> 32);
+    }
+    auto tile_off = [&](int t) __attribute__((always_inline)) -> int64_t {
+      const int bi = tpb_shift >= 0 ? t >> tpb_shift : t / tpb;
+      const int64_t in_block = tpb == 1 ? 0 : (int64_t)(tpb_shift >= 0 ? t & (tpb - 1) : t % tpb) * kvs.tile;
+      if (resolved) {
+        const uint32_t lo = __builtin_amdgcn_readlane(run_lo, bi - b_first), hi = __builtin_amdgcn_readlane(run_hi, bi - b_first);
+        return (int64_t)(((uint64_t)hi << 32) | lo) + in_block;
+      }
+      return (int64_t)table_row[bi] * kvs.block + in_block;
+    };
     auto load_a = [&]() __attribute__((always_inline)) {
-      load_tiles(kc, table_row, ta, second(ta), h, kvs, tpb, lane, AK0, AK1);
-      load_tiles(vc, table_row, ta, second(ta), h, kvs, tpb, lane, AV0, AV1);
+      const int64_t o0 = tile_off(ta), o1 = tile_off(second(ta));
+      load_tiles_at(kc_h, o0, o1, lane, AK0, AK1);
+      load_tiles_at(vc_h, o0, o1, lane, AV0, AV1);
     };
     auto load_b = [&]() __attribute__((always_inline)) {
-      load_tiles(kc, table_row, tb, second(tb), h, kvs, tpb, lane, BK0, BK1);
-      load_tiles(vc, table_row, tb, second(tb), h, kvs, tpb, lane, BV0, BV1);
+      const int64_t o0 = tile_off(tb), o1 = tile_off(second(tb));
+      load_tiles_at(kc_h, o0, o1, lane, BK0, BK1);
+      load_tiles_at(vc_h, o0, o1, lane, BV0, BV1);
     };
     auto attend_a = [&]() __attribute__((always_inline)) {
       if (FUSE && (ta == new_tile || ta + 1 == new_tile)) {  // wave-uniform, true once per (sequence, kv head)
@@ -877,13 +913,17 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   float* part_o = static_cast<float*>(workspace);
   float* part_ml = part_o + (size_t)batch * n_q_heads * 16 * 128;
   const float sl2 = scale * 1.4426950408889634f;
+  const int tpb_host = block_size / 16;
+  int tpb_shift = -1;  // log2 of the tiles per block, or -1 (division) for block sizes like 48
+  for (int sft = 0; sft < 12; ++sft)
+    if ((1 << sft) == tpb_host) tpb_shift = sft;
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
   const FusedStep fs = fused ? *fused : FusedStep{};
 #define LAUNCH_DEC_AS(GG, WW, FF, PP)                                                                          \
   hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW, FF, PP>), grid, dim3(WW * 64), 0, st, q, q_row_stride, \
                      k_cache, v_cache, block_table, table_stride, context_lens, part_o, part_ml, out,         \
-                     n_q_heads, kvs, block_size / 16, sl2, fs)
+                     n_q_heads, kvs, block_size / 16, tpb_shift, sl2, fs)
 #define LAUNCH_DEC(GG, WW)                       \
   if (fused) LAUNCH_DEC_AS(GG, 8, true, true);   \
   else if (pipe) LAUNCH_DEC_AS(GG, 8, false, true); \

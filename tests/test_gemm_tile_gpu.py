@@ -62,19 +62,21 @@ def test_gemm_tile_persistent_ragged(ops, K):
     one_tile_each = ops.gemm_tile(x.to(DEV), w.to(DEV), variant=16)  # grid = tiles
     assert torch.equal(ops.gemm_tile(x.to(DEV), w.to(DEV)).view(torch.int16), one_tile_each.view(torch.int16))
     gu = ops.gemm_tile(x.to(DEV), w[:3840].contiguous().to(DEV), silu_mul=True)  # 15 x 18 = 270 tiles
-    assert torch.equal(gu.view(torch.int16),
-                       ops.silu_mul(ops.gemm_tile(x.to(DEV), w[:3840].contiguous().to(DEV))).view(torch.int16))
+    assert_bf16_close(gu, ops.silu_mul(ops.gemm_tile(x.to(DEV), w[:3840].contiguous().to(DEV))).cpu(), max_ulp=1,
+                      max_frac=1e-3)
 
 
 @pytest.mark.parametrize("M", [65, 256, 777])
 @pytest.mark.parametrize("N,K", [(6144, 1024), (512, 128), (6400, 5120), (1536, 2048)])
 def test_gemm_tile_swiglu_epilogue(ops, M, N, K):
-    """fused SiluAndMul == gate_up GEMM followed by the activation (activation.py:10-12, three bf16 roundings);
-    bit-identical to the tile GEMM's own plain output run through mi_silu_mul"""
+    """fused SiluAndMul == gate_up GEMM followed by the activation (activation.py:10-12, three bf16 roundings).
+    Against the tile GEMM's own plain output run through mi_silu_mul (same gate / up bits in): the epilogue's
+    silu uses the hardware exp2 / reciprocal instead of libm expf + IEEE division - a few fp32 ulps before the bf16
+    rounding, i.e. one bf16 ulp at rounding ties only (< 0.1 % of the elements)."""
     g, x, w = _case(M, N, K, seed=3)
     got = ops.gemm_tile(x.to(DEV), w.to(DEV), silu_mul=True)
     two_pass = ops.silu_mul(ops.gemm_tile(x.to(DEV), w.to(DEV)))
-    assert torch.equal(got.view(torch.int16), two_pass.view(torch.int16))
+    assert_bf16_close(got, two_pass.cpu(), max_ulp=1, max_frac=1e-3)
     atol = K * 2.0 ** -22
     # a 1-ulp flip of the gate (summation order) times |up| <= ~6: widen the near-zero floor
     assert_bf16_close(got, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=4, max_frac=3e-2, atol=32 * atol)
