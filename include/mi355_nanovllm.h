@@ -184,6 +184,14 @@ int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_stride, cons
                                 const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
                                 int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
                                 int head_dim, int block_size, float scale, mi_stream stream);
+/* Tuning / stress-test form: variant 0 = mi_paged_attn_prefill_fused, variant 1 requests the first two K/V chunks
+ * ahead of the Q preparation.  Same results bit for bit (tests). */
+int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
+                                   const int64_t* positions, const float* cos_sin, const mi_bf16* k_cache,
+                                   const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                   const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                   int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads, int head_dim,
+                                   int block_size, float scale, int variant, mi_stream stream);
 
 /* ---- normalisation (reference: layers/layernorm.py) ----------------------- */
 /* RMSNorm.rms_forward (layernorm.py:16-25):

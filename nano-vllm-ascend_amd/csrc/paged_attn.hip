@@ -343,7 +343,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* kc,
     const uint16_t* vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ ctx_lens, float* __restrict__ part_o, float* __restrict__ part_ml,
-    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, int tpb_shift, float scale_log2e, FusedStep fs) {
+    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, int tpb_shift, int resolve_run, float scale_log2e, FusedStep fs) {
   static_assert(!FUSE || PIPE, "the fused prologue needs the register room of the 8-wave form");
   __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
   __shared__ float sm_m[WAVES][16];
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     const uint16_t* const vc_h = vc + (int64_t)h * kvs.head;
     const int b_first = tpb_shift >= 0 ? t0 >> tpb_shift : t0 / tpb;
     const int b_last = t1 > t0 ? (tpb_shift >= 0 ? (t1 - 1) >> tpb_shift : (t1 - 1) / tpb) : b_first;
-    const bool resolved = b_last - b_first < 64;  // wave-uniform
+    const bool resolved = resolve_run && b_last - b_first < 64;  // wave-uniform
     uint32_t run_lo = 0, run_hi = 0;
     if (resolved) {
       const int64_t o = (int64_t)table_row[min(b_first + lane, table_stride - 1)] * kvs.block;
@@ -659,7 +659,9 @@ struct QPrep {
   float eps;
 };
 
-template <int G, bool SPLIT_P, bool FUSE_Q>
+// EARLY (tuning / stress-test variant, mi_paged_attn_prefill_fused_ex): the first two chunks are requested ahead of
+// the Q preparation instead of behind it.
+template <int G, bool SPLIT_P, bool FUSE_Q, bool EARLY = false>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const int limit_all = wave_on && qt0 + TQ <= q_len ? shift + qt0 + 1 : 0;  // earliest column of a full block
 
   bf16x8 Q[8];  // B operand of S^T = K . Q^T: column n, dims 16 kk + 8 hi .. +7
-  {
+  auto prepare_q = [&]() __attribute__((always_inline)) {
     const int row = valid ? my_qt : wg_qt0;  // invalid columns read a valid row and are zeroed
     const uint16_t* qrow = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * hi;
     if (FUSE_Q) {
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         Q[kk] = as_frag(v);
       }
     }
-  }
+  };
   float m = -INFINITY, l = 0.f;  // running max (log2 domain) and this lane's share of the running sum
   f32x16 acc[4];
 #pragma unroll
@@ -755,10 +757,25 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   //   V (A of the second): dim 32 db + n, key slots {4 hi .. +3} and {8 + 4 hi .. +3} of tile s
   const int v_off = (hi * 16 + (n & 15)) * 8 + (n >> 4) * 4;   // + db * 512 (+ 256 for the second piece)
 
-  // (issuing these two ahead of the Q preparation was tried in round 2: no measurable gain, and the full-shape
-  // paging-invariance tests failed with that order - keep the chunk loads behind the Q operand)
-  issue(0);
-  issue(1);
+  // The loop's wait is a COUNT: vmcnt(4) = "all but the four newest vector-memory operations of this wave have
+  // completed".  That means "chunk c has landed" only if the chunk DMAs are the ONLY vector-memory operations in
+  // flight, in issue order.  Made true by construction: the Q operand (ordinary loads, placed by the compiler) is
+  // finished and the counter drained to zero before the first chunk request; inside the loop the wave issues no
+  // other vector-memory operation (block ids come through the scalar cache: lgkmcnt), and the output stores follow
+  // the final vmcnt(0).  EARLY: the two requests go out first and the drain behind the Q preparation waits for
+  // them as well - the same invariant at loop entry, one DMA latency more of overlap in exchange for nothing
+  // measurable (profiles/r03_prefill_attention_order.txt).
+  if (EARLY) {
+    issue(0);
+    issue(1);
+    prepare_q();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    prepare_q();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0);
+    issue(1);
+  }
   for (int c = 0; c < wg_chunks; ++c) {
     // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
     // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
@@ -917,13 +934,15 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   int tpb_shift = -1;  // log2 of the tiles per block, or -1 (division) for block sizes like 48
   for (int sft = 0; sft < 12; ++sft)
     if ((1 << sft) == tpb_host) tpb_shift = sft;
+  const char* table_env = getenv("MI355_ATTN_TABLE");  // A/B knob: 1 = block ids through the scalar cache per chunk (round 2)
+  const int resolve_run = !(table_env && atoi(table_env) != 0);
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
   const FusedStep fs = fused ? *fused : FusedStep{};
 #define LAUNCH_DEC_AS(GG, WW, FF, PP)                                                                          \
   hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW, FF, PP>), grid, dim3(WW * 64), 0, st, q, q_row_stride, \
                      k_cache, v_cache, block_table, table_stride, context_lens, part_o, part_ml, out,         \
-                     n_q_heads, kvs, block_size / 16, tpb_shift, sl2, fs)
+                     n_q_heads, kvs, block_size / 16, tpb_shift, resolve_run, sl2, fs)
 #define LAUNCH_DEC(GG, WW)                       \
   if (fused) LAUNCH_DEC_AS(GG, 8, true, true);   \
   else if (pipe) LAUNCH_DEC_AS(GG, 8, false, true); \
@@ -987,7 +1006,7 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
                         const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
                         const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs, int max_seqlen_q,
                         mi_bf16* out, int n_q_heads, int n_kv_heads, int head_dim, int block_size, float scale,
-                        mi_stream stream) {
+                        mi_stream stream, bool early = false) {
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -1005,7 +1024,11 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
 #define LAUNCH_PRE(GG)                                                                                          \
   do {                                                                                                          \
-    if (prep)                                                                                                   \
+    if (prep && early)                                                                                          \
+      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true, true>), grid, dim3(256), 0, st, q,        \
+                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
+                         n_q_heads, n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                  \
+    else if (prep)                                                                                              \
       hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true>), grid, dim3(256), 0, st, q, q_row_stride, \
                          k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads,     \
                          n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                             \
@@ -1044,4 +1067,19 @@ extern "C" int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_s
   const QPrep prep{q_w, positions, cos_sin, eps};
   return prefill_impl(qkv, qkv_row_stride, &prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
                       n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream);
+}
+
+// tuning / stress-test form of mi_paged_attn_prefill_fused: variant 1 requests the first two K/V chunks ahead of the
+// Q preparation (tests/test_kernels_gpu.py::test_prefill_attention_chunk_pipeline_stress)
+extern "C" int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
+                                              const int64_t* positions, const float* cos_sin, const mi_bf16* k_cache,
+                                              const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                              const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                              int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
+                                              int head_dim, int block_size, float scale, int variant, mi_stream stream) {
+  if (!positions || !cos_sin || !aligned16(cos_sin) || (q_w && !aligned16(q_w))) return MI_EINVAL;
+  if (variant != 0 && variant != 1) return MI_EUNSUPPORTED;
+  const QPrep prep{q_w, positions, cos_sin, eps};
+  return prefill_impl(qkv, qkv_row_stride, &prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
+                      n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream, variant == 1);
 }

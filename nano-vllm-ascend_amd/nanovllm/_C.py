@@ -79,6 +79,11 @@ _SIGNATURES = {
         [_p, c_int64, _p, c_float, _p, _p, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int, c_int, c_int,
          c_float, _p],
     ),
+    "mi_paged_attn_prefill_fused_ex": (
+        c_int,
+        [_p, c_int64, _p, c_float, _p, _p, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int, c_int, c_int,
+         c_float, c_int, _p],
+    ),
     "mi_rmsnorm": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_int, c_float, _p]),
     "mi_add_rmsnorm": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_rope": (c_int, [_p, _p, _p, c_int64, c_int, _p, c_int64, c_int, _p, _p, c_int, c_int, _p]),

@@ -154,7 +154,7 @@ def paged_attn_prefill(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens,
 
 def paged_attn_prefill_fused(qkv, q_w, eps: float, positions, cos_sin, k_cache, v_cache, block_tables, cu_seqlens_q,
                              kv_lens, max_seqlen_q: int, n_q_heads: int, n_kv_heads: int, block_size: int, scale: float,
-                             out=None) -> torch.Tensor:
+                             out=None, variant: int | None = None) -> torch.Tensor:
     """paged_attn_prefill over the RAW q heads of the packed qkv rows: q-norm (q_w may be None) + RoPE happen in
     the kernel's Q-operand load.  K / V must already be cached (qknorm_rope_store(..., store_q=False))."""
     require_gpu(qkv, positions, cos_sin, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
@@ -167,6 +167,16 @@ def paged_attn_prefill_fused(qkv, q_w, eps: float, positions, cos_sin, k_cache, 
     n_seqs = cu_seqlens_q.numel() - 1
     if out is None:
         out = torch.empty((T, n_q_heads * HEAD_DIM), dtype=_BF16, device=qkv.device)
+    if variant is not None:
+        check(
+            lib.mi_paged_attn_prefill_fused_ex(ptr(qkv), qkv.stride(0), ptr(q_w), float(eps), ptr(positions),
+                                               ptr(cos_sin), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                               block_tables.stride(0), ptr(cu_seqlens_q), ptr(kv_lens), n_seqs,
+                                               int(max_seqlen_q), ptr(out), n_q_heads, n_kv_heads, HEAD_DIM, block_size,
+                                               float(scale), int(variant), stream()),
+            "mi_paged_attn_prefill_fused_ex",
+        )
+        return out
     check(
         lib.mi_paged_attn_prefill_fused(ptr(qkv), qkv.stride(0), ptr(q_w), float(eps), ptr(positions), ptr(cos_sin),
                                         ptr(k_cache), ptr(v_cache), ptr(block_tables), block_tables.stride(0),

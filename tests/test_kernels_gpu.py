@@ -628,6 +628,61 @@ def test_prefill_attention_random(ops, hq, hkv, block_size):
     assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
 
 
+def test_prefill_attention_chunk_pipeline_stress(ops):
+    """Kernel-level guard of the prefill attention's LDS-DMA ring (the counted `s_waitcnt vmcnt(4)` of its chunk
+    loop): the bench's prefill step - 16 sequences x 1024 tokens, Qwen3-0.6B heads, block 16 - with SCRAMBLED block
+    tables, 100 launches of each request order (chunks behind / ahead of the Q preparation) next to a competing
+    HBM stream.  Every launch must reproduce the first one bit for bit, both orders must agree, and the result must
+    be the unscrambled layout's (paging invariance) and the fp32 oracle's on a sample of rows."""
+    gen = torch.Generator().manual_seed(77)
+    hq, hkv, bs, n_seqs, L = 16, 8, 16, 16, 1024
+    T = n_seqs * L
+    nblk = n_seqs * (L // bs)
+    qkv = (torch.randn(T, (hq + 2 * hkv) * 128, generator=gen) * 0.8).bfloat16().to(DEV)
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).bfloat16().to(DEV)
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).bfloat16().to(DEV)
+    table = oracle.build_cos_sin_cache(128, 2048, 1e6).to(DEV)
+    pos = torch.arange(L, dtype=torch.int64).repeat(n_seqs).to(DEV)
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32).to(DEV)
+    kvl = torch.full((n_seqs,), L, dtype=torch.int32, device=DEV)
+
+    def run(perm, variant, reps):
+        bt = perm.view(n_seqs, L // bs).to(torch.int32).to(DEV)
+        slots = (bt.long().repeat_interleave(bs, dim=1) * bs + torch.arange(bs, device=DEV).repeat(L // bs)).view(-1).to(torch.int32)
+        kc = torch.zeros(ops.kv_cache_shape(nblk + 7, hkv, bs), dtype=torch.bfloat16, device=DEV)
+        vc = torch.zeros_like(kc)
+        ops.qknorm_rope_store(qkv, qw, kw, 1e-6, pos, table, kc, vc, slots, hq, hkv, bs, store_q=False)
+        first = ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, table, kc, vc, bt, cu, kvl, L, hq, hkv, bs, 128 ** -0.5,
+                                             variant=variant)
+        side, junk = torch.cuda.Stream(), torch.empty(192 << 20, dtype=torch.uint8, device=DEV)
+        for it in range(reps):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1)  # uneven memory pressure next to the DMA ring
+            again = ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, table, kc, vc, bt, cu, kvl, L, hq, hkv, bs,
+                                                 128 ** -0.5, variant=variant)
+            assert torch.equal(again.view(torch.int16), first.view(torch.int16)), (variant, it)
+        torch.cuda.synchronize()
+        return first, (kc, vc, bt)
+
+    straight = torch.arange(nblk)
+    scrambled = torch.randperm(nblk + 7, generator=gen)[:nblk]
+    ref, _ = run(straight, 0, 3)
+    late, (kc, vc, bt) = run(scrambled, 0, 100)
+    early, _ = run(scrambled, 1, 100)
+    assert torch.equal(late.view(torch.int16), ref.view(torch.int16))    # paging invariance
+    assert torch.equal(early.view(torch.int16), late.view(torch.int16))  # request order does not matter
+    # the fp32 oracle on the last 40 query rows of two sequences (full causal context)
+    qo = oracle.apply_rope(pos.cpu(), oracle.rms_norm(qkv[:, : hq * 128].cpu().view(T, hq, 128), qw.cpu(), 1e-6), table.cpu())
+    kc_l, vc_l = to_logical(kc.cpu(), bs, False), to_logical(vc.cpu(), bs, True)
+    for s_i in (0, n_seqs - 1):
+        rows = slice(s_i * L + L - 40, s_i * L + L)
+        want = oracle.paged_attention_prefill(qo[rows], kc_l, vc_l, bt[s_i:s_i + 1].cpu(), torch.tensor([0, 40], dtype=torch.int32),
+                                              torch.tensor([L], dtype=torch.int32), keep_fp32=True)
+        err = (late[rows].cpu().float() - want).abs()
+        assert bool((err <= want.abs() * 2 ** -8 + 1e-4).all()), err.max().item()
+
+
 @pytest.mark.parametrize("hq,hkv,with_norm", [(16, 8, True), (8, 1, True), (4, 4, False), (16, 1, True)])
 def test_prefill_attention_with_q_prepared_in_the_kernel(ops, hq, hkv, with_norm):
     """mi_paged_attn_prefill_fused (q-norm + RoPE inside the Q-operand load, K / V-only store before it) against

@@ -227,6 +227,23 @@ def main():
                                                          hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
         res[f"attn fused step ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
 
+    # block ids of a wave's run resolved once (default) vs read through the scalar cache per chunk (round 2), interleaved
+    c2 = 1100
+    ctx2 = torch.full((B,), c2, dtype=torch.int32, device=DEV)
+    nb2 = (c2 + bs - 1) // bs
+    perm2 = torch.randperm(nblk, generator=g)[: B * nb2].to(torch.int32).view(B, nb2).to(DEV)
+    pos2 = torch.full((B,), c2 - 1, dtype=torch.int64, device=DEV)
+    sl2 = torch.stack([perm2[:, (c2 - 1) // bs], torch.full((B,), (c2 - 1) % bs, dtype=torch.int32, device=DEV)], 1).contiguous()
+    byt2 = B * 2 * c2 * hkv * 128 * 2
+    for rnd in range(3):
+        for mode in ("0", "1"):
+            os.environ["MI355_ATTN_TABLE"] = mode
+            t = timeit(lambda l: ops.paged_attn_decode_fused(qkv_, w128, w128, 1e-6, pos2, rope_t, sl2, kc[l], vc[l], perm2, ctx2,
+                                                             hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
+            res[f"fused step ctx=1100 {'table per chunk' if mode == '1' else 'run resolved   '} #{rnd}"] = {
+                "us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
+    os.environ["MI355_ATTN_TABLE"] = "0"
+
     if os.environ.get("KBENCH_ONLY") == "attn":
         for k, v in res.items():
             print(f"{k:32s} " + "  ".join(f"{a}={b:9.2f}" for a, b in v.items()))
