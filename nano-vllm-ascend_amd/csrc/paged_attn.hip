@@ -441,12 +441,11 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     u32x4 AK0[4], AK1[4], AV0[4], AV1[4], BK0[4], BK1[4], BV0[4], BV1[4];
     bf16x8 Q[4];
     int ta = t0, tb = t0 + 2;
-    // The wave's whole run of block ids is read ONCE, by one vector load issued ahead of everything else: lane i
-    // keeps the element offset of block (b_first + i).  A chunk's two tile addresses are then two pairs of
-    // v_readlane and two scalar adds - the round-1/2 form went to the scalar cache for the block ids (s_load +
-    // lgkmcnt(0)) and through ~20 s_mul of 64-bit stride arithmetic between finishing a chunk and issuing the next
-    // one's 16 loads, with only the other buffer's loads in flight.  Runs of more than 64 blocks (contexts beyond
-    // 64 x block_size x waves tokens) take the table path.
+    // resolve_run (MI355_ATTN_RESOLVE=1, off by default - measured slower, see decode_impl): the wave's whole run of
+    // block ids is read ONCE by one vector load issued ahead of everything else, lane i keeps the element offset of
+    // block (b_first + i), and a chunk's two tile addresses are two pairs of v_readlane and two scalar adds instead
+    // of two scalar-cache reads (s_load + lgkmcnt(0)) and 64-bit stride multiplies.  Runs of more than 64 blocks
+    // take the table path in any case.
     const uint16_t* const kc_h = kc + (int64_t)h * kvs.head;
     const uint16_t* const vc_h = vc + (int64_t)h * kvs.head;
     const int b_first = tpb_shift >= 0 ? t0 >> tpb_shift : t0 / tpb;
@@ -934,8 +933,12 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   int tpb_shift = -1;  // log2 of the tiles per block, or -1 (division) for block sizes like 48
   for (int sft = 0; sft < 12; ++sft)
     if ((1 << sft) == tpb_host) tpb_shift = sft;
-  const char* table_env = getenv("MI355_ATTN_TABLE");  // A/B knob: 1 = block ids through the scalar cache per chunk (round 2)
-  const int resolve_run = !(table_env && atoi(table_env) != 0);
+  // A/B knob, read per call: 1 = a wave resolves its whole run of block ids once (vector load + v_readlane).  Measured
+  // SLOWER than reading the ids through the scalar cache per chunk (26.07 vs 25.70 us for the fused step at ctx 1100,
+  // interleaved rounds, profiles/r03_kbench_attention.txt): the first tile loads then wait for a vector load instead
+  // of a scalar one.  Default off.
+  const char* resolve_env = getenv("MI355_ATTN_RESOLVE");
+  const int resolve_run = resolve_env && atoi(resolve_env) != 0;
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
   const FusedStep fs = fused ? *fused : FusedStep{};

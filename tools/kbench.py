@@ -227,7 +227,7 @@ def main():
                                                          hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
         res[f"attn fused step ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
 
-    # block ids of a wave's run resolved once (default) vs read through the scalar cache per chunk (round 2), interleaved
+    # block ids read through the scalar cache per chunk (default) vs a wave's run resolved once, interleaved rounds
     c2 = 1100
     ctx2 = torch.full((B,), c2, dtype=torch.int32, device=DEV)
     nb2 = (c2 + bs - 1) // bs
@@ -237,12 +237,12 @@ def main():
     byt2 = B * 2 * c2 * hkv * 128 * 2
     for rnd in range(3):
         for mode in ("0", "1"):
-            os.environ["MI355_ATTN_TABLE"] = mode
+            os.environ["MI355_ATTN_RESOLVE"] = mode
             t = timeit(lambda l: ops.paged_attn_decode_fused(qkv_, w128, w128, 1e-6, pos2, rope_t, sl2, kc[l], vc[l], perm2, ctx2,
                                                              hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
-            res[f"fused step ctx=1100 {'table per chunk' if mode == '1' else 'run resolved   '} #{rnd}"] = {
+            res[f"fused step ctx=1100 {'run resolved   ' if mode == '1' else 'table per chunk'} #{rnd}"] = {
                 "us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
-    os.environ["MI355_ATTN_TABLE"] = "0"
+    os.environ["MI355_ATTN_RESOLVE"] = "0"
 
     if os.environ.get("KBENCH_ONLY") == "attn":
         for k, v in res.items():
