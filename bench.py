@@ -6,14 +6,18 @@ bf16, paged decode under hipGraph — BASELINE.json configs[1] — on N MI355X.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W [--mode replicas|tp]
 
-N > 1 has two modes (the JSON line says which: `mode`, `scaling`, `config.parallelism`):
-  replicas (default)  the decode batch is a set of independent sequences, so the path shards with NO
-                      data-path collective: every rank runs the whole 0.6 B model on its own GPU over its own
-                      32 sequences (global batch 32 N, weak scaling); `value` is the sum over ranks of
+`python bench.py --gpus N` without torchrun around it starts the N ranks itself (same command line).
+N > 1 measures BOTH ways of using N GPUs, back to back, and reports them in ONE line (--mode picks one):
+  replicas            the headline `value`: the decode batch is a set of independent sequences, so the path shards
+                      with NO data-path collective: every rank runs the whole 0.6 B model on its own GPU over its
+                      own 32 sequences (global batch 32 N, weak scaling); `value` is the sum over ranks of
                       tokens / the slowest rank's time (barrier + synchronize on both sides, max over ranks).
-  tp                  Megatron tensor parallelism over RCCL/xGMI at the fixed batch of 32 (strong scaling):
+  tp   (`tp_run`)     Megatron tensor parallelism over RCCL/xGMI at the fixed batch of 32 (strong scaling):
                       what a model that does not fit one GPU needs (BASELINE configs[2]); for this 0.6 B
                       model every all-reduce is a 64 KiB latency-bound message, so it does not speed up.
+                      Carries its own value, ms_per_step, world_seen, backend, xgmi_selftest and the
+                      per-rank kernel rooflines; runs under a watchdog, so a failure there costs the
+                      `tp_run` object, never the line.
 
 A "step" is one engine decode step over the batch of 32 sequences (scheduler -> metadata
 -> graph replay incl. sampling -> postprocess), i.e. 32 new tokens.  On one GPU the engine keeps one step queued
@@ -26,6 +30,8 @@ engine first (that is where p50 TTFT comes from), so the KV cache is resident in
 when the timed region starts.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  prefill_roofline  MFMA flops of one prefill step (16 x 1024 tokens: projections, causal attention, head) / its wall
+                time vs the 2.5 PFLOP/s dense bf16 peak - the TTFT half of the metric;
   roofline      the dominant kernel (paged_attn_decode, the fused step form the engine runs) timed live
                 with HIP events on its launch stream over the engine's real KV cache: algorithmic KV
                 bytes per launch / average duration vs the 8 TB/s HBM peak; `traffic` = those bytes x
@@ -249,16 +255,47 @@ def chain_roofline(llm, batch: int, iters: int = 20):
                 "launches_per_layer": 6, "layers": n}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--mode", choices=("replicas", "tp"), default="replicas",
-                    help="N > 1: independent replicas (weak scaling, default) or tensor parallelism (strong scaling)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+PREFILL_MFMA_PEAK = 2.5e15  # dense bf16 MFMA flop/s (MI355X_MICROARCH.md)
 
+
+def prefill_flops(n_seqs: int, seq_len: int, cfg: dict) -> float:
+    """MFMA flops of one prefill step of n_seqs x seq_len tokens: the four projections of every layer, causal
+    attention (QK^T and PV over the lower triangle incl. the diagonal), the head GEMM on the last tokens."""
+    h, inter, layers = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    hq, hkv, d = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
+    per_token = 2 * (h * (hq + 2 * hkv) * d + hq * d * h + 3 * h * inter)
+    attn = 2 * 2 * hq * d * (seq_len * (seq_len + 1) // 2)  # per sequence and layer
+    return layers * (n_seqs * seq_len * per_token + n_seqs * attn) + 2 * n_seqs * h * cfg["vocab_size"]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: start the N ranks ourselves (the same command
+    line the driver uses).  On a box with fewer GPUs than ranks the ranks share devices over gloo - a functional dry
+    run of the N-rank flow, not a measurement (the JSON line says so)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        env.setdefault("BENCH_DIST_BACKEND", "gloo")
+        env.setdefault("MI355_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--mode", args.mode]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    return subprocess.call(cmd, env=env)
+
+
+def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str):
+    """One measurement: mode "single" (one GPU), "replicas" (every rank its own engine over its own 32 sequences) or
+    "tp" (one engine, rank 0, the model sharded over all ranks; the other ranks serve it).  Returns the result
+    object on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
 
@@ -266,30 +303,7 @@ def main():
     from nanovllm import LLM, SamplingParams
     from nanovllm.engine.llm_engine import run_worker
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    tp = world if args.mode == "tp" else 1
-    port = int(os.environ.get("MASTER_PORT", "29500"))
-    if world > 1:
-        local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
-        torch.cuda.set_device(local)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # BENCH_DIST_BACKEND=gloo: functional run of this N > 1 flow with the ranks sharing one GPU
-        # (eager decode, not a measurement); the driver's runs use RCCL ("nccl"), one GPU per rank
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    tmp = os.environ.get("TMPDIR", "/tmp")
-    model_dir = os.path.join(tmp, f"mi355_qwen3_0p6b_{port}")
-    if rank == 0:
-        os.makedirs(model_dir, exist_ok=True)
-        with open(os.path.join(model_dir, "config.json"), "w") as f:
-            json.dump(QWEN3_0_6B, f)
-    if world > 1:
-        dist.barrier()
+    tp = world if mode == "tp" else 1
     total_new = args.warmup + args.steps + 2
     blocks_needed = BATCH * ((PROMPT_LEN + total_new) // BLOCK + 2) + 64
     kw = dict(tensor_parallel_size=tp, kvcache_block_size=BLOCK, max_num_seqs=BATCH, max_model_len=4096,
@@ -300,21 +314,25 @@ def main():
               enforce_eager=os.environ.get("BENCH_EAGER") is not None)
     if tp > 1 and rank != 0:
         run_worker(model_dir, **kw)
-        return
+        return None
 
     llm = LLM(model_dir, **kw)
     random.seed(rank if tp == 1 else 0)  # replicas: every rank its own prompts
     prompts = [[random.randint(0, 10000) for _ in range(PROMPT_LEN)] for _ in range(BATCH)]
     sp = SamplingParams(temperature=1.0, max_tokens=total_new, ignore_eos=True, greedy=True)
     seqs = [llm.add_request(p, sp) for p in prompts]
-    prefill_steps = 0
+    prefill_ms = []
     while any(s.num_completion_tokens == 0 for s in seqs):  # prefill (2 steps of 16 x 1024 tokens)
+        torch.cuda.synchronize()
+        t_p = time.perf_counter()
         llm.step()
-        prefill_steps += 1
+        torch.cuda.synchronize()
+        prefill_ms.append((time.perf_counter() - t_p) * 1e3)
+    prefill_steps = len(prefill_ms)
     ttft = sorted(llm.ttft[s.seq_id] for s in seqs)
     for _ in range(args.warmup):
         llm.step()
-    replicas = world > 1 and tp == 1
+    replicas = mode == "replicas"
     if replicas:
         dist.barrier()
     torch.cuda.synchronize()
@@ -341,19 +359,25 @@ def main():
         n_rep = world
     algo = n_rep * sum(step_bytes(BATCH, c) for c in range(ctx0 + 1, ctx1 + 1))
     value = n_rep * BATCH * args.steps / elapsed
-    if world == 1:
+    n_dev = world if mode != "single" else 1
+    if mode == "single":
         par, agg = "tp1", "one GPU"
     elif replicas:
         par = f"dp{world} (independent replicas of bs {BATCH}; no data-path collective)"
-        agg = f"sum over {world} replicas, global batch {BATCH * world} (--mode tp: Megatron TP at fixed bs {BATCH})"
+        agg = f"sum over {world} replicas, global batch {BATCH * world}"
     else:
-        par, agg = f"tp{world}", f"one model sharded over {world} GPUs at fixed bs {BATCH} (--mode replicas: weak scaling)"
+        par, agg = f"tp{world}", f"one model sharded over {world} GPUs (Megatron TP, RCCL / xGMI) at fixed bs {BATCH}"
+    # MFMA roofline of the prefill: flops of the prefill steps / their wall time vs the dense bf16 peak of the GPUs
+    # that computed them (replicas: rank 0's own steps on its one GPU)
+    per_step = BATCH // max(1, prefill_steps)
+    pf = prefill_flops(per_step, PROMPT_LEN, QWEN3_0_6B)
+    pf_ms = statistics.median(prefill_ms)
     result = {
         "metric": "decode tokens/s, Qwen3-0.6B bs=32 seq=1024 (p50 TTFT in ttft_p50_ms)",
-        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "tokens/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if tp > 1 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "mode": "tp" if tp > 1 else ("replicas" if replicas else "single"), "aggregate": agg,
+        "mode": mode, "aggregate": agg,
         "config": {"workload": "Qwen3-0.6B bf16 paged decode under hipGraph, bs=32, 1024-token prompts, "
                                "block_size=16 (BASELINE.json configs[1])",
                    "batch": BATCH, "global_batch": BATCH * n_rep, "prompt_len": PROMPT_LEN, "ctx_first": ctx0 + 1,
@@ -361,15 +385,19 @@ def main():
                    **({"weights": os.environ["BENCH_QUANT"]} if os.environ.get("BENCH_QUANT") else {})},
         "ttft_p50_ms": statistics.median(ttft) * 1e3, "ttft_max_ms": ttft[-1] * 1e3,
         "prefill_steps": prefill_steps,
-        "step_roofline": {"bound": "hbm", "achieved": algo / elapsed / 1e9, "peak": HBM_PEAK / 1e9 * world,
-                          "unit": "GB/s", "frac": algo / elapsed / (HBM_PEAK * world),
+        "prefill_roofline": {"bound": "mfma", "achieved": pf / (pf_ms * 1e-3) / 1e12, "peak": PREFILL_MFMA_PEAK * tp / 1e12,
+                             "unit": "TFLOP/s", "frac": pf / (pf_ms * 1e-3) / (PREFILL_MFMA_PEAK * tp),
+                             "flops_per_step": pf, "ms_per_step": pf_ms, "tokens_per_step": per_step * PROMPT_LEN,
+                             "what": "one engine prefill step (projections + causal attention + head), wall time incl. host"},
+        "step_roofline": {"bound": "hbm", "achieved": algo / elapsed / 1e9, "peak": HBM_PEAK / 1e9 * n_dev,
+                          "unit": "GB/s", "frac": algo / elapsed / (HBM_PEAK * n_dev),
                           "bytes_per_step": algo / args.steps},
     }
     mr = llm.model_runner
     if tp > 1:  # what the ranks really ran on: visible to the driver
         result["tp"] = {"world_seen": dist.get_world_size(), "backend": dist.get_backend(),
                         "xgmi_exchange": mr.xgmi is not None, "xgmi_selftest": getattr(mr, "xgmi_selftest", None),
-                        "decode_graphs": sorted(mr.graphs)}
+                        "decode_graphs": sorted(mr.graphs), "lookahead": bool(getattr(llm, "lookahead", False))}
     # device time of the captured decode step alone (graph replays back to back, HIP events):
     # ms_per_step minus this is the host share of a step (scheduler, metadata, sampling, sync)
     bucket = mr._bucket_for(BATCH) if mr.graphs else None
@@ -384,13 +412,101 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         result["step_roofline"]["graph_replay_ms"] = e0.elapsed_time(e1) / 20
-    if tp == 1 and rank == 0:
-        result["roofline"] = attention_roofline(llm, seqs)
-        result["chain_roofline"] = chain_roofline(llm, BATCH)
-    else:
-        result["roofline"] = None
+    if rank == 0:
+        # per-GPU kernel rooflines (rank 0's shard of the heads / weights under TP): local launches, no collective
+        try:
+            result["roofline"] = attention_roofline(llm, seqs)
+            result["chain_roofline"] = chain_roofline(llm, BATCH)
+            if tp > 1:
+                result["roofline"]["per_rank"] = result["chain_roofline"]["per_rank"] = True
+        except Exception as e:  # never lose the line over a diagnostic
+            result["roofline"] = {"error": repr(e)}
     llm.exit()
-    if rank != 0:
+    return result if rank == 0 else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--mode", choices=("both", "replicas", "tp"), default="both",
+                    help="N > 1: independent replicas (weak scaling, the headline value) AND tensor parallelism at the "
+                         "fixed batch (reported under `tp_run` of the same line), or only one of the two")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
+    from model_configs import QWEN3_0_6B
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:  # launched with another rank count than --gpus says: the ranks that exist are what runs
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    shared_gpu = False
+    if world > 1:
+        local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
+        shared_gpu = torch.cuda.device_count() < world
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # BENCH_DIST_BACKEND=gloo: functional run of this N > 1 flow with the ranks sharing one GPU
+        # (not a measurement); the driver's runs use RCCL ("nccl"), one GPU per rank
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    model_dir = os.path.join(tmp, f"mi355_qwen3_0p6b_{port}")
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
+        with open(os.path.join(model_dir, "config.json"), "w") as f:
+            json.dump(QWEN3_0_6B, f)
+    if world > 1:
+        dist.barrier()
+
+    if world == 1:
+        result = run_phase(args, "single", rank, world, port, model_dir)
+    else:
+        # Both aggregates in ONE line.  Replicas first: the tensor-parallel engine tears the process group down
+        # when it exits.  The TP phase runs under a watchdog: whatever happens to it, the line is printed.
+        result = run_phase(args, "replicas", rank, world, port, model_dir) if args.mode in ("both", "replicas") else None
+        tp_run = None
+        if args.mode in ("both", "tp"):
+            import threading
+
+            def give_up():
+                if rank == 0 and result is not None:
+                    result["tp_run"] = {"error": "tensor-parallel phase did not finish within its time limit"}
+                    print(json.dumps(result), flush=True)
+                os._exit(0 if result is not None else 3)
+
+            dog = threading.Timer(float(os.environ.get("BENCH_TP_TIMEOUT", "420")), give_up)
+            dog.daemon = True
+            dog.start()
+            try:
+                tp_run = run_phase(args, "tp", rank, world, port + 7, model_dir)
+            except Exception as e:
+                tp_run = {"error": repr(e)} if rank == 0 else None
+            dog.cancel()
+        if rank == 0:
+            if result is None:
+                result = tp_run  # --mode tp: the TP line is the line
+            elif tp_run is not None:
+                result["tp_run"] = {k: tp_run[k] for k in ("value", "ms_per_step", "scaling", "mode", "aggregate",
+                                                            "ttft_p50_ms", "prefill_roofline", "step_roofline", "tp",
+                                                            "roofline", "chain_roofline", "error") if k in tp_run}
+                result["tp_run"].setdefault("n_gpus", world)
+        if rank == 0 and result is not None and shared_gpu:
+            result["dry_run"] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over "
+                                 f"{os.environ.get('BENCH_DIST_BACKEND', 'nccl')}: functional run of the multi-rank flow, "
+                                 "not a measurement")
+    if rank != 0 or result is None:
         return
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -500,28 +500,35 @@ def test_full_size_properties_paging_invariance_and_decode_equals_reprefill():
         llm.exit()
 
 
-@pytest.mark.parametrize("mode", ["replicas", "tp"])
-def test_bench_two_ranks_on_one_gpu(mode):
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per "GPU" - here both on
-    cuda:0, gloo instead of RCCL): the default mode runs N independent engines whose layers are NOT sharded
-    although a process group exists; --mode tp shards one model.  One JSON line with the contract's fields."""
+@pytest.mark.parametrize("mode,ranks", [("replicas", 2), ("tp", 2), ("both", 2), ("both", 4)])
+def test_bench_ranks_on_one_gpu(mode, ranks):
+    """bench.py for N > 1 on a 1-GPU box (all ranks on cuda:0, gloo instead of RCCL).  `python bench.py --gpus N`
+    starts its ranks itself - the command the driver uses for N = 1 must not die for N > 1 - and the default mode
+    reports BOTH aggregates in one JSON line: N independent engines (layers NOT sharded although a process group
+    exists) as the headline, the tensor-parallel run of one sharded model under `tp_run` with its own per-rank
+    rooflines."""
     import json
-    import socket
     import subprocess
     import sys
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_NO_WARMUP="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "1", "--mode", mode]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MI355_DIST_BACKEND="gloo", BENCH_NO_WARMUP="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
+           "--mode", mode]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "tokens/s"
-    assert d["mode"] == mode and d["scaling"] == ("weak" if mode == "replicas" else "strong")
-    assert d["config"]["global_batch"] == (64 if mode == "replicas" else 32)
+    assert d["n_gpus"] == ranks and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "tokens/s"
+    assert "dry_run" in d  # more ranks than GPUs: the line says it is not a measurement
+    head = "tp" if mode == "tp" else "replicas"
+    assert d["mode"] == head and d["scaling"] == ("weak" if head == "replicas" else "strong")
+    assert d["config"]["global_batch"] == (32 * ranks if head == "replicas" else 32)
+    assert d["prefill_roofline"]["bound"] == "mfma" and 0 < d["prefill_roofline"]["frac"] < 1
+    tp = d if mode == "tp" else d.get("tp_run")
+    if mode != "replicas":
+        assert tp is not None and "error" not in tp, tp
+        assert tp["value"] > 0 and tp["tp"]["world_seen"] == ranks and tp["tp"]["backend"] == "gloo"
+        assert tp["roofline"]["bound"] == "hbm" and tp["roofline"].get("per_rank") and tp["roofline"]["frac"] > 0
