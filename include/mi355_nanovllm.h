@@ -361,6 +361,14 @@ int mi_gemm_pick_groups(int M, int N, int K, int fp8_weights);
 int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y,
                              int M, int N, int K, const float* temperatures,
                              const uint64_t* rng, void* candidates, mi_stream stream);
+/* Tensor-parallel form: w_packed is this rank's vocabulary shard (rows col_offset .. col_offset + N of the whole
+ * head, embed_head.py:9-31); the sampler's noise is keyed by the GLOBAL column and the candidates carry global
+ * columns.  mi_pick_final_pairs reduces them to this rank's best {key bits u32, column u32} per row;
+ * mi_pick_exchange (below, with the exchange kernels) picks over the ranks. */
+int mi_gemm_bf16_packed_pick_shard(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K,
+                                   const float* temperatures, const uint64_t* rng, void* candidates,
+                                   int col_offset, mi_stream stream);
+int mi_pick_final_pairs(const void* candidates, int n_groups, int rows, void* pairs, mi_stream stream);
 int mi_gemm_fp8w_packed_pick(const mi_bf16* x, const uint8_t* w_packed, const float* scale,
                              mi_bf16* y, int M, int N, int K, const float* temperatures,
                              const uint64_t* rng, void* candidates, mi_stream stream);
@@ -454,6 +462,14 @@ int mi_allreduce_sum_bf16(mi_comm* comm, const mi_bf16* in, mi_bf16* out, int64_
 int mi_allreduce_add_rmsnorm(mi_comm* comm, const mi_bf16* x, const mi_bf16* residual,
                              const mi_bf16* weight, mi_bf16* out, mi_bf16* residual_out,
                              int rows, int cols, float eps, mi_stream stream);
+/* The sampler under tensor parallelism, without the logits gather of embed_head.py:62-65: every rank contributes its
+ * shard's best {key, token} per row (mi_pick_final_pairs), the pairs cross the exchange region (8 bytes per row and
+ * rank), and EVERY rank writes the same tokens[rows] - largest key, ties to the lowest token id, i.e. what
+ * sampler.py:9-17 on the gathered logits picks.  Capturable; rows <= 512 * 64. */
+int mi_pick_exchange(mi_comm* comm, const void* pairs, int64_t* tokens, int rows, mi_stream stream);
+/* mi_comm_status without a device synchronisation: the flag is copied to `timed_out_host` (pinned memory) behind the
+ * work already queued on `stream`. */
+int mi_comm_status_async(mi_comm* comm, int* timed_out_host, mi_stream stream);
 /* Polls (~1 us each) a workgroup waits for a peer before it gives up; default 2^26 (about a minute).
  * Init-time call (synchronises the device). */
 int mi_comm_set_spin_limit(mi_comm* comm, uint32_t polls);

@@ -17,7 +17,7 @@
 
 namespace mi {
 
-constexpr int MAX_SLICES = 64;   // flag slots per (parity, source): rows of the fused kernel
+constexpr int MAX_SLICES = 512;  // flag slots per (parity, source): rows of the fused kernel (= the largest decode batch)
 constexpr size_t CTRL_BYTES = 4096;
 constexpr uint32_t DEFAULT_SPIN_LIMIT = 1u << 26;  // polls of ~1 us each: about a minute
 
@@ -124,7 +124,42 @@ __global__ __launch_bounds__(64) void allreduce_kernel(CommGeom g, const uint16_
   if (lane == 0) comm_finish(g, e, n_slices);
 }
 
-// all-reduce + residual add + RMSNorm in one launch: one wave per token row (decode: <= 64 rows).
+// The sampler's last step under tensor parallelism: every rank holds, per batch row, the best (sampling key, token)
+// of ITS vocabulary shard (mi_pick_final_pairs); the ranks exchange these 8-byte pairs - instead of gathering
+// [rows][vocab / world] logits to rank 0 (embed_head.py:62-65) - and every rank reduces them the same way (largest
+// key, ties to the lowest token id: what the unsharded sampler picks), so every rank ends up with the step's tokens
+// on its own device, inside the captured graph.  One wave per 64 rows.
+__global__ __launch_bounds__(64) void pick_exchange_kernel(CommGeom g, const uint2* __restrict__ pairs,
+                                                           int64_t* __restrict__ tokens, int n) {
+  const int s = blockIdx.x, lane = threadIdx.x, row = s * 64 + lane;
+  const uint32_t e = comm_epoch(g);
+  const uint32_t par = e & 1u;
+  if (row < n) {
+    const uint2 p = pairs[row];
+    const uint64_t v = ((uint64_t)p.x << 32) | p.y;
+    for (int k = 1; k <= g.world; ++k)
+      reinterpret_cast<uint64_t*>(comm_slot(g, (g.rank + k) % g.world, par, g.rank))[row] = v;
+  }
+  comm_publish_and_wait(g, e, s, lane, false);
+  if (row < n) {
+    const uint8_t* slots = comm_slot(g, g.rank, par, 0);
+    float best = -INFINITY;
+    uint32_t best_c = 0x7fffffffu;
+    for (int r = 0; r < g.world; ++r) {
+      const uint64_t v = reinterpret_cast<const uint64_t*>(slots + (size_t)r * g.slot_stride)[row];
+      const float key = __uint_as_float((uint32_t)(v >> 32));
+      const uint32_t c = (uint32_t)v;
+      if (key > best || (key == best && c < best_c)) {
+        best = key;
+        best_c = c;
+      }
+    }
+    tokens[row] = best_c == 0x7fffffffu ? 0 : (int64_t)best_c;
+  }
+  if (lane == 0) comm_finish(g, e, gridDim.x);
+}
+
+// all-reduce + residual add + RMSNorm in one launch: one wave per token row (decode batches, <= MAX_SLICES rows).
 // The row's partial sums are pushed to every rank, summed in rank order in fp32 and rounded to bf16 -
 // exactly what allreduce_kernel leaves in memory - then the row goes through the arithmetic of
 // rmsnorm_kernel<64, VPL, ADD> (elementwise.hip; same operation order, this file is built with
@@ -336,6 +371,25 @@ extern "C" int mi_allreduce_add_rmsnorm(mi_comm* comm, const mi_bf16* x, const m
   else LAUNCH_ARN(16);
 #undef LAUNCH_ARN
   return check_launch();
+}
+
+extern "C" int mi_pick_exchange(mi_comm* comm, const void* pairs, int64_t* tokens, int rows, mi_stream stream) {
+  if (!comm || !pairs || !tokens || rows < 0) return MI_EINVAL;
+  if ((rows + 63) / 64 > MAX_SLICES || (size_t)rows * 8 > comm->max_bytes) return MI_EUNSUPPORTED;
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(pick_exchange_kernel, dim3((rows + 63) / 64), dim3(64), 0, S(stream), comm->geom(),
+                     static_cast<const uint2*>(pairs), tokens, rows);
+  return check_launch();
+}
+
+// the sticky timeout flag, copied to (pinned) host memory behind the work already queued on `stream` - the form a
+// caller uses that must not synchronise the device (the engine's lookahead loop)
+extern "C" int mi_comm_status_async(mi_comm* comm, int* timed_out_host, mi_stream stream) {
+  if (!comm || !timed_out_host) return MI_EINVAL;
+  if (hipMemcpyAsync(timed_out_host, comm->ptrs.region[comm->rank] + 2 * sizeof(uint32_t), sizeof(uint32_t),
+                     hipMemcpyDeviceToHost, S(stream)) != hipSuccess)
+    return MI_ERUNTIME;
+  return MI_OK;
 }
 
 extern "C" int mi_comm_set_spin_limit(mi_comm* comm, uint32_t polls) {

@@ -8,7 +8,7 @@ namespace mi {
 // written by other CUs a moment ago (every load is a trip to memory), so a thread issues eight loads before it
 // compares anything: one exposed latency per 8192 candidates instead of one per candidate.
 __global__ __launch_bounds__(1024) void pick_final_kernel(const uint2* __restrict__ cand, int n_groups, int M,
-                                                          int64_t* __restrict__ out) {
+                                                          int64_t* __restrict__ out, uint2* __restrict__ pairs) {
   const int row = blockIdx.x;
   const uint2* p = cand + (int64_t)row * n_groups;
   float best = -INFINITY;
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(1024) void pick_final_kernel(const uint2* __restric
         best = sb[w];
         best_c = sc[w];
       }
-    out[row] = best_c == 0x7fffffff ? 0 : best_c;
+    if (pairs) pairs[row] = uint2{__float_as_uint(best), (uint32_t)best_c};  // this rank's best (key, global column)
+    else out[row] = best_c == 0x7fffffff ? 0 : best_c;
   }
 }
 
@@ -67,21 +68,33 @@ extern "C" int mi_gemm_pick_groups(int M, int N, int K, int fp8_weights) {
   return pick_two_tiles(M, N) ? N / 32 : N / 16;
 }
 
-extern "C" int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K,
-                                        const float* temperatures, const uint64_t* rng, void* candidates,
-                                        mi_stream stream) {
+static int packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K,
+                       const float* temperatures, const uint64_t* rng, void* candidates, int col_offset,
+                       mi_stream stream) {
   int rc = check_gemm(x, w_packed, y, M, N, K);
   if (rc != MI_OK) return rc;
-  if (!rng || !candidates) return MI_EINVAL;
+  if (!rng || !candidates || col_offset < 0) return MI_EINVAL;
   if (M == 0) return MI_OK;
+  const PickArgs pk{temperatures, rng, static_cast<uint2*>(candidates), col_offset};
   if (head_stream_fits(M, N, K)) {
-    launch_head_stream<true>(x, w_packed, y, M, N, K, PickArgs{temperatures, rng, static_cast<uint2*>(candidates)},
-                             S(stream));
+    launch_head_stream<true>(x, w_packed, y, M, N, K, pk, S(stream));
     return check_launch();
   }
   GemmArgs a{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)};
-  a.pick = PickArgs{temperatures, rng, static_cast<uint2*>(candidates)};
+  a.pick = pk;
   return pick_two_tiles(M, N) ? pick_mt<2, 1, EPI_PICK>(a) : pick_mt<1, 1, EPI_PICK>(a);
+}
+
+extern "C" int mi_gemm_bf16_packed_pick(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K,
+                                        const float* temperatures, const uint64_t* rng, void* candidates,
+                                        mi_stream stream) {
+  return packed_pick(x, w_packed, y, M, N, K, temperatures, rng, candidates, 0, stream);
+}
+
+extern "C" int mi_gemm_bf16_packed_pick_shard(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, int M, int N,
+                                              int K, const float* temperatures, const uint64_t* rng,
+                                              void* candidates, int col_offset, mi_stream stream) {
+  return packed_pick(x, w_packed, y, M, N, K, temperatures, rng, candidates, col_offset, stream);
 }
 
 extern "C" int mi_gemm_fp8w_packed_pick(const mi_bf16* x, const uint8_t* w_packed, const float* scale, mi_bf16* y,
@@ -94,7 +107,7 @@ extern "C" int mi_gemm_fp8w_packed_pick(const mi_bf16* x, const uint8_t* w_packe
   if (M == 0) return MI_OK;
   GemmArgs a{x, reinterpret_cast<const uint16_t*>(w_packed), nullptr, y, nullptr, M, N, K, 1, S(stream)};
   a.scale = scale;
-  a.pick = PickArgs{temperatures, rng, static_cast<uint2*>(candidates)};
+  a.pick = PickArgs{temperatures, rng, static_cast<uint2*>(candidates), 0};
   return pick_two_tiles(M, N) ? pick_mt<2, 2, EPI_PICK>(a) : pick_mt<1, 2, EPI_PICK>(a);
 }
 
@@ -102,7 +115,15 @@ extern "C" int mi_pick_final(const void* candidates, int n_groups, int rows, int
   if (!candidates || !out || n_groups <= 0 || rows < 0) return MI_EINVAL;
   if (rows == 0) return MI_OK;
   hipLaunchKernelGGL(pick_final_kernel, dim3(rows), dim3(1024), 0, S(stream), static_cast<const uint2*>(candidates),
-                     n_groups, rows, out);
+                     n_groups, rows, out, static_cast<uint2*>(nullptr));
+  return check_launch();
+}
+
+extern "C" int mi_pick_final_pairs(const void* candidates, int n_groups, int rows, void* pairs, mi_stream stream) {
+  if (!candidates || !pairs || n_groups <= 0 || rows < 0) return MI_EINVAL;
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(pick_final_kernel, dim3(rows), dim3(1024), 0, S(stream), static_cast<const uint2*>(candidates),
+                     n_groups, rows, static_cast<int64_t*>(nullptr), static_cast<uint2*>(pairs));
   return check_launch();
 }
 

@@ -55,7 +55,7 @@ extern "C" int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, co
   if (epilogue == 1 && (bias || N % 32)) return MI_EUNSUPPORTED;
   if (M == 0) return MI_OK;
   if (epilogue == 0 && !bias && head_stream_fits(M, N, K)) {  // vocabulary-sized N: persistent workgroups
-    launch_head_stream<false>(x, w_packed, y, M, N, K, PickArgs{nullptr, nullptr, nullptr}, S(stream));
+    launch_head_stream<false>(x, w_packed, y, M, N, K, PickArgs{nullptr, nullptr, nullptr, 0}, S(stream));
     return check_launch();
   }
   const GemmArgs a{x, w_packed, bias, y, nullptr, M, N, K, 1, S(stream)};

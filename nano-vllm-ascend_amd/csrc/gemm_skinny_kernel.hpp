@@ -18,6 +18,9 @@ struct PickArgs {
   const float* temperatures;  // [M]; nullptr or <= 0: greedy
   const uint64_t* rng;        // {seed, step} in device memory (a captured graph reads the current step)
   uint2* cand;                // [M][gridDim.x] {key bits, column}: a row's candidates are contiguous
+  int col0 = 0;               // vocabulary offset of this weight shard (tensor parallelism): the sampler's noise is
+                              // keyed by the GLOBAL column and the candidates carry global columns, so that the
+                              // ranks' candidates compare as the unsharded sampler would
 };
 
 // B fragments (the activations x^T) of one wave for STEPS k-steps starting at xk = x + k0:
@@ -252,10 +255,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
           int best_c = 0x7fffffff;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float key = noisy ? gumbel_key(v[i], inv_t, rkey, col + i) : v[i];
+            const float key = noisy ? gumbel_key(v[i], inv_t, rkey, pk.col0 + col + i) : v[i];
             if (key > best) {  // ascending columns: the first of equal keys stays
               best = key;
-              best_c = col + i;
+              best_c = pk.col0 + col + i;
             }
           }
           pick_key[row][t * 4 + (l >> 4)] = best;
@@ -513,10 +516,10 @@ __global__ __launch_bounds__(WAVES * 64) void head_stream_kernel(const uint16_t*
         const float v[4] = {lo_bf(o[0]), hi_bf(o[0]), lo_bf(o[1]), hi_bf(o[1])};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float key = noisy ? gumbel_key(v[i], inv_t, rkey, col + i) : v[i];
-          if (key > best || (key == best && col + i < best_c)) {
+          const float key = noisy ? gumbel_key(v[i], inv_t, rkey, pk.col0 + col + i) : v[i];
+          if (key > best || (key == best && pk.col0 + col + i < best_c)) {
             best = key;
-            best_c = col + i;
+            best_c = pk.col0 + col + i;
           }
         }
       }
@@ -571,7 +574,7 @@ struct GemmArgs {
   int M, N, K, ksplit;
   hipStream_t st;
   const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
-  PickArgs pick = PickArgs{nullptr, nullptr, nullptr};
+  PickArgs pick = PickArgs{nullptr, nullptr, nullptr, 0};
 };
 
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>

@@ -111,6 +111,10 @@ _SIGNATURES = {
     "mi_gemm_bf16_packed_pick": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p, _p, _p, _p]),
     "mi_gemm_fp8w_packed_pick": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p, _p, _p, _p]),
     "mi_pick_final": (c_int, [_p, c_int, c_int, _p, _p]),
+    "mi_gemm_bf16_packed_pick_shard": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p, _p, _p, c_int, _p]),
+    "mi_pick_final_pairs": (c_int, [_p, c_int, c_int, _p, _p]),
+    "mi_pick_exchange": (c_int, [_p, _p, _p, c_int, _p]),
+    "mi_comm_status_async": (c_int, [_p, _p, _p]),
     "mi_xxh64_chain": (c_uint64, [_p, c_size_t, c_int, c_uint64]),
     "mi_xxh64_chain_blocks": (c_int, [_p, c_int, c_int, c_int, c_uint64, _p]),
     "mi_pack_weight_fp8": (c_int, [_p, _p, c_int, c_int, _p]),

@@ -67,10 +67,11 @@ class LLMEngine:
             config.eos = self.tokenizer.eos_token_id
         self.scheduler = Scheduler(config)
         self.ttft: dict[int, float] = {}
-        # lookahead decode (one GPU, decode graphs that end in the token choice): the step after the one
-        # running is scheduled and queued on the device before the running one's tokens reach the host
-        self.lookahead = (config.decode_lookahead and config.tensor_parallel_size == 1
-                          and os.environ.get("MI355_LOOKAHEAD", "1") != "0")
+        # lookahead decode (decode graphs that end in the token choice - one GPU, or tensor parallelism with the
+        # exchange region up, where every rank picks the same tokens on its own device): the step after the one
+        # running is scheduled and queued on the device(s) before the running one's tokens reach the host; the TP
+        # workers queue the same step when its message arrives (ModelRunner.loop)
+        self.lookahead = config.decode_lookahead and os.environ.get("MI355_LOOKAHEAD", "1") != "0"
         self._inflight = None  # (handle, sequences, rows dropped after launch) of a queued decode step
         self._exited = False
         if kwargs.get("warmup", True):
@@ -137,7 +138,7 @@ class LLMEngine:
             return self._step_lookahead(*self._inflight)
         seqs, is_prefill = self.scheduler.schedule()
         if self.lookahead and not is_prefill and seqs and self.model_runner.can_launch_decode(len(seqs)):
-            return self._step_lookahead(self.model_runner.launch_decode(seqs), seqs, set())
+            return self._step_lookahead(self.model_runner.call("launch_decode", seqs), seqs, set())
         token_ids = self.model_runner.call("run", seqs, is_prefill)
         if is_prefill:
             now = perf_counter()
@@ -164,7 +165,7 @@ class LLMEngine:
             nxt, deferred = plan
             row_of = {id(s): i for i, s in enumerate(seqs)}
             src = [row_of[id(s)] if s.token_pending else -1 for s in nxt]
-            queued = (runner.launch_decode(nxt, src), nxt, set())
+            queued = (runner.call("launch_decode", nxt, src), nxt, set())
         tokens = runner.collect(handle)
         if len(live) != len(seqs):
             tokens = [t for s, t in zip(seqs, tokens) if id(s) not in dropped]

@@ -118,6 +118,17 @@ class ModelRunner:
             self.synthetic = True
         self.model.eval()
         self.sampler = Sampler(seed=config.sampling_seed)
+        if self.world_size > 1:
+            # every rank draws the sampler's noise for its vocabulary shard: one seed (rank 0's; a seed of None is
+            # drawn from os.urandom per process) and one step counter, advanced in lockstep (run / launch_decode)
+            seed = torch.tensor([self.sampler.seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64,
+                                device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(seed, 0)
+            self.sampler.seed = int(seed.item())
+        # parity hook under tensor parallelism: gather the full logits to rank 0 although the graph already holds
+        # the step's tokens (tests compare them with the one-GPU run); a collective, so every rank reads the switch
+        self.gather_logits = os.environ.get("MI355_TP_GATHER_LOGITS", "0") != "0"
+        self._xgmi_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if self.world_size > 1 else None
         torch.cuda.empty_cache()
         self.allocate_kv_cache()
         self._alloc_staging()
@@ -182,17 +193,23 @@ class ModelRunner:
     def loop(self):
         """TP worker main loop (rank > 0): execute whatever rank 0 publishes."""
         while True:
-            method, seqs, is_prefill = self.channel.recv()
+            method, seqs, is_prefill, extra = self.channel.recv()
             if method == "exit":
                 self.exit()
                 return
-            self.run(seqs, is_prefill)
+            if method == "launch_decode":  # a step rank 0 queued behind the running one: queue the same step here
+                self.launch_decode(seqs, extra if extra else None)
+            else:
+                self.run(seqs, is_prefill)
 
     def call(self, method_name: str, *args):
         if method_name == "run" and not args[0]:
             return []  # nothing scheduled (everything preempted): no message, no collective, on any rank
         if self.channel is not None and self.rank == 0:
-            self.channel.send(method_name, *args)
+            if method_name == "launch_decode":
+                self.channel.send(method_name, args[0], False, extra=args[1] if len(args) > 1 else None)
+            else:
+                self.channel.send(method_name, *args)
         return getattr(self, method_name)(*args)
 
     # ------------------------------------------------------------------ KV cache
@@ -354,8 +371,9 @@ class ModelRunner:
     @torch.inference_mode()
     def capture_decode_graphs(self):
         cfg, d = self.config, self.dev
-        pick = (self.world_size == 1 and os.environ.get("MI355_GRAPH_SAMPLER", "1") != "0"
-                and self.model.lm_head.can_pick())
+        # the token choice is part of the graph on one GPU and, with the exchange region up, under tensor parallelism
+        # (every rank then holds the step's tokens: no logits gather, no sampler on rank 0, no host in the loop)
+        pick = os.environ.get("MI355_GRAPH_SAMPLER", "1") != "0" and self.model.lm_head.can_pick()
         self.graph_samples = {bs for bs in graph_buckets(cfg.max_num_seqs) if pick and bs <= ops.SKINNY_MAX_M}
         # neutral metadata: every row padded (context_len 0, dummy slot)
         self._fill_decode_stage([], cfg.max_num_seqs)
@@ -401,6 +419,8 @@ class ModelRunner:
         if is_prefill or bucket is None or bucket not in self.graphs:
             return self.model.compute_logits(self.model(input_ids, positions))
         self.graphs[bucket].replay()
+        if self.world_size > 1 and bucket in self.graph_samples and not self.gather_logits:
+            return self.graph_logits[bucket]  # this rank's vocabulary shard; the tokens are already picked
         return self.model.lm_head.gather(self.graph_logits[bucket])
 
     @torch.inference_mode()
@@ -419,8 +439,10 @@ class ModelRunner:
         logits = self.run_model(input_ids, positions, is_prefill, bucket)
         self.last_logits = logits  # debugging / parity hook (a reference, not a copy)
         tokens = None
+        sampled_in_graph = not is_prefill and bucket in self.graphs and bucket in self.graph_samples
+        if self.rank != 0:
+            self.sampler.step += 1  # in lockstep with rank 0, which samples exactly once per step
         if self.rank == 0:
-            sampled_in_graph = not is_prefill and bucket in self.graphs and bucket in self.graph_samples
             if sampled_in_graph:
                 self.sampler.step += 1  # the replayed graph sampled with this step (see _fill_decode_stage)
             else:
@@ -439,7 +461,7 @@ class ModelRunner:
     def can_launch_decode(self, n: int) -> bool:
         """A decode step of n sequences can be queued without waiting for its tokens: its graph ends in the
         token choice, so the step after it can read its input ids on the device."""
-        return self.world_size == 1 and self._bucket_for(n) in self.graph_samples
+        return self._bucket_for(n) in self.graph_samples
 
     @property
     def max_launch_rows(self) -> int:
@@ -452,11 +474,15 @@ class ModelRunner:
         real = len(seqs)
         bucket = self._bucket_for(real)
         assert bucket in self.graph_samples
+        self.lookahead_launches = getattr(self, "lookahead_launches", 0) + (src_rows is not None)
         b = self._fill_decode_stage(seqs, bucket, src_rows)
         self.graphs[bucket].replay()
         self.sampler.step += 1  # the graph sampled with this step (see _fill_decode_stage)
-        self.tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
-        self.step_events[b].record()
+        if self.rank == 0:
+            self.tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+            if self.xgmi is not None:  # the exchange's timeout flag travels with the tokens: no device sync here
+                self.xgmi.status_async(self._xgmi_flag)
+            self.step_events[b].record()
         self.last_logits = self.graph_logits[bucket]
         self._steps_run += 1
         return (b, real)
@@ -464,6 +490,8 @@ class ModelRunner:
     def collect(self, handle) -> list[int]:
         b, real = handle
         self.step_events[b].synchronize()
+        if self._xgmi_flag is not None and int(self._xgmi_flag[0]):
+            raise RuntimeError("rank 0: xGMI exchange timed out waiting for a peer; results are invalid")
         return self.tokens_hosts[b][:real].tolist()
 
     def _check_xgmi(self):

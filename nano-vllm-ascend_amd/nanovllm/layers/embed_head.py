@@ -7,7 +7,7 @@ from torch import nn
 
 from nanovllm import ops
 from nanovllm.layers.linear import pack_for_decode, linear_forward
-from nanovllm.layers.parallel import all_reduce_sum, tp_rank, tp_size
+from nanovllm.layers.parallel import all_reduce_sum, get_xgmi_comm, tp_rank, tp_size
 from nanovllm.utils.context import get_context
 
 
@@ -56,14 +56,28 @@ class ParallelLMHead(VocabParallelEmbedding):
         return linear_forward(x, self.weight, None, self.weight_packed)
 
     def can_pick(self) -> bool:
-        return self.tp_size == 1 and self.weight_packed is not None
+        if self.weight_packed is None:
+            return False
+        # tensor parallelism: the ranks pick among themselves over the exchange region (bf16 shards only)
+        return self.tp_size == 1 or (get_xgmi_comm() is not None and not isinstance(self.weight_packed, ops.Fp8Weight))
 
     def local_logits_pick(self, x: torch.Tensor, temperatures: torch.Tensor, rng: torch.Tensor,
                           out_tokens: torch.Tensor) -> torch.Tensor:
-        """Decode on one GPU: the logits AND the sampler's tokens (sampler.py:9-17 on the key scheme of
-        layers/sampler.py here) from one pass over the head weight; `rng` = {seed, step} on the device."""
+        """Decode: the (local) logits AND the sampler's tokens (sampler.py:9-17 on the key scheme of
+        layers/sampler.py here) from one pass over the head weight; `rng` = {seed, step} on the device.
+        Tensor parallelism: instead of gathering [B, vocab / n] logits to rank 0 for it to sample
+        (embed_head.py:62-65, sampler.py:9-17), every rank reduces its shard to its best {key, token} per row, the
+        ranks exchange those 8 bytes per row and every rank takes the same winner - the tokens of the step are then
+        on every rank's device, inside the captured graph."""
         assert not get_context().is_prefill and self.can_pick()
-        logits, _ = ops.gemm_packed_pick(x, self.weight_packed, temperatures, rng, out_tokens)
+        if self.tp_size == 1:
+            logits, _ = ops.gemm_packed_pick(x, self.weight_packed, temperatures, rng, out_tokens)
+            return logits
+        rows = x.shape[0]
+        pairs = torch.empty((rows, 2), dtype=torch.int32, device=x.device)
+        logits, _ = ops.gemm_packed_pick(x, self.weight_packed, temperatures, rng, out_tokens,
+                                         col_offset=self.vocab_start_idx, pairs_out=pairs)
+        get_xgmi_comm().pick_exchange(pairs, out_tokens)
         return logits
 
     def gather(self, logits: torch.Tensor):

@@ -51,7 +51,7 @@ class XgmiComm:
         return t
 
     def fits_rows(self, rows: int, cols: int) -> bool:
-        return 0 < rows <= 64 and 512 <= cols <= 8192 and cols % 8 == 0 and rows * cols * 2 <= self.max_bytes
+        return 0 < rows <= 512 and 512 <= cols <= 8192 and cols % 8 == 0 and rows * cols * 2 <= self.max_bytes
 
     def allreduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, w: torch.Tensor, eps: float):
         """sum over ranks of x, + residual, RMSNorm: one launch (mi_allreduce_add_rmsnorm)."""
@@ -61,6 +61,19 @@ class XgmiComm:
         check(lib.mi_allreduce_add_rmsnorm(self._comm, ptr(x), ptr(residual), ptr(w), ptr(out), ptr(residual_out),
                                            rows, cols, float(eps), stream()), "mi_allreduce_add_rmsnorm")
         return out, residual_out
+
+    def pick_exchange(self, pairs: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        """pairs [rows, 2] int32 = this rank's best {key bits, token} per row -> tokens[rows] int64, the same on
+        every rank (mi_pick_exchange)."""
+        rows = pairs.shape[0]
+        assert pairs.dtype == torch.int32 and pairs.is_contiguous() and tokens.dtype == torch.int64
+        assert tokens.numel() >= rows and rows * 8 <= self.max_bytes
+        check(lib.mi_pick_exchange(self._comm, ptr(pairs), ptr(tokens), rows, stream()), "mi_pick_exchange")
+        return tokens
+
+    def status_async(self, landing: torch.Tensor) -> None:
+        """queue a copy of the sticky timeout flag into `landing` (pinned int32) behind the stream's work"""
+        check(lib.mi_comm_status_async(self._comm, landing.data_ptr(), stream()), "mi_comm_status_async")
 
     def timed_out(self) -> bool:
         flag = ctypes.c_int(0)
@@ -109,6 +122,16 @@ class XgmiComm:
                 graph.replay()
                 torch.cuda.synchronize()
                 ok = ok and bool(torch.equal(buf, want))
+            # the sampler's pair exchange: rank r offers key = (row + r) % world (ties between ranks on purpose),
+            # token = 1000 r + row; the winner of a row is the largest key, lowest token among equals
+            rows = 70
+            row = torch.arange(rows, device=self.device, dtype=torch.int64)
+            key = ((row + self.rank) % self.world).to(torch.float32)
+            pairs = torch.stack([key.view(torch.int32), (1000 * self.rank + row).to(torch.int32)], 1).contiguous()
+            toks = torch.empty(rows, dtype=torch.int64, device=self.device)
+            self.pick_exchange(pairs, toks)
+            winner = (self.world - 1 - row) % self.world  # the rank whose key is world - 1
+            ok = ok and bool(torch.equal(toks, 1000 * winner + row))
             ok = ok and not self.timed_out()
             check(lib.mi_comm_set_spin_limit(self._comm, 1 << 26), "mi_comm_set_spin_limit")
         except Exception as e:  # noqa: BLE001 - any failure means "do not use this path"

@@ -552,10 +552,13 @@ def sample(logits, temperatures, seed: int, step: int, out=None) -> torch.Tensor
     return out
 
 
-def gemm_packed_pick(x, w_packed, temperatures, rng, out_tokens, logits=None, candidates=None):
+def gemm_packed_pick(x, w_packed, temperatures, rng, out_tokens, logits=None, candidates=None, col_offset: int = 0,
+                     pairs_out=None):
     """logits = x @ w.T (as gemm_packed) and, in the same pass, the sampler's token per row
     (as sample(logits, temperatures, seed, step) with {seed, step} = the two uint64 of the device tensor `rng`).
-    Returns (logits, tokens)."""
+    Returns (logits, tokens).  Tensor parallelism: w_packed is a vocabulary shard starting at `col_offset` and
+    `pairs_out` [M, 2] int32 receives this rank's best {key bits, global token} per row instead of tokens (the
+    ranks then pick among themselves: XgmiComm.pick_exchange)."""
     require_gpu(x, rng, out_tokens)
     _bf16(x)
     assert x.is_contiguous() and rng.dtype == torch.int64 and rng.numel() == 2 and out_tokens.dtype == torch.int64
@@ -572,14 +575,20 @@ def gemm_packed_pick(x, w_packed, temperatures, rng, out_tokens, logits=None, ca
         candidates = torch.empty((M, groups, 2), dtype=torch.int32, device=x.device)
     assert candidates.numel() >= groups * M * 2
     if isinstance(w_packed, Fp8Weight):
+        assert col_offset == 0, "fp8 head shards are not picked in the graph"
         check(lib.mi_gemm_fp8w_packed_pick(ptr(x), ptr(w_packed.data), ptr(w_packed.scale), ptr(logits), M, N, K,
                                            ptr(temperatures), ptr(rng), ptr(candidates), stream()),
               "mi_gemm_fp8w_packed_pick")
     else:
         require_gpu(w_packed)
         _bf16(w_packed)
-        check(lib.mi_gemm_bf16_packed_pick(ptr(x), ptr(w_packed), ptr(logits), M, N, K, ptr(temperatures),
-                                           ptr(rng), ptr(candidates), stream()), "mi_gemm_bf16_packed_pick")
+        check(lib.mi_gemm_bf16_packed_pick_shard(ptr(x), ptr(w_packed), ptr(logits), M, N, K, ptr(temperatures),
+                                                 ptr(rng), ptr(candidates), int(col_offset), stream()),
+              "mi_gemm_bf16_packed_pick_shard")
+    if pairs_out is not None:
+        assert pairs_out.dtype == torch.int32 and pairs_out.is_contiguous() and pairs_out.numel() >= 2 * M
+        check(lib.mi_pick_final_pairs(ptr(candidates), groups, M, ptr(pairs_out), stream()), "mi_pick_final_pairs")
+        return logits, pairs_out
     check(lib.mi_pick_final(ptr(candidates), groups, M, ptr(out_tokens), stream()), "mi_pick_final")
     return logits, out_tokens
 

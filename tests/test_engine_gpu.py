@@ -267,13 +267,16 @@ def test_lookahead_decode_equals_step_by_step_decode():
     assert a[1][:5] == b[1][:5] and a[3][:5] == b[3][:5]
 
 
-@pytest.mark.parametrize("model,enforce_eager,tol", [("MID", True, 6e-2), ("MID", False, 6e-2),
-                                                     ("QWEN3_32B_2L", False, 1.3e-1),
-                                                     # (sparse block: an expert's bf16 partial sums are rounded per
-                                                     # rank before they are added - the widest spread of the four)
-                                                     ("QWEN3_30B_A3B_2L", False, 1.6e-1)])
-def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol):
-    """Functional tensor-parallel run on a 1-GPU box: two rank processes share cuda:0 and talk over
+@pytest.mark.parametrize("model,enforce_eager,tol,world", [
+    ("MID", True, 6e-2, 2), ("MID", False, 6e-2, 2), ("QWEN3_32B_2L", False, 1.3e-1, 2),
+    # (sparse block: an expert's bf16 partial sums are rounded per rank before they are added - the widest spread)
+    ("QWEN3_30B_A3B_2L", False, 1.6e-1, 2),
+    # BASELINE.json configs[3] / configs[2] at their own world sizes: Qwen3-30B-A3B widths over FOUR ranks and
+    # Qwen3-32B widths over EIGHT (one kv head per rank), hipGraph and eager - engine, exchange kernels and RPC
+    ("QWEN3_30B_A3B_2L", False, 2.2e-1, 4), ("QWEN3_30B_A3B_2L", True, 2.2e-1, 4),
+    ("QWEN3_32B_2L", False, 1.6e-1, 8), ("QWEN3_32B_2L", True, 1.6e-1, 8)])
+def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, world):
+    """Functional tensor-parallel run on a 1-GPU box: `world` rank processes share cuda:0 and talk over
     gloo (MI355_DIST_BACKEND) - the same sharded layers, RPC channel and collectives call sites as
     the RCCL path.  Eager, and with the decode step captured in hipGraphs (the exchange kernels are
     captured; the logits gather stays outside).  Greedy tokens must equal the TP=1 run; logits agree
@@ -307,11 +310,63 @@ def test_tp2_two_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, t
 
     toks1, logits1 = run(1)
     monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
-    toks2, logits2 = run(2)
+    # the parity hook: full logits gathered to rank 0 although the graphs pick the tokens themselves; synchronous
+    # engine loop so that last_logits is the last step's (the lookahead path is test_tp_decode_picks_tokens_in_the_graph)
+    monkeypatch.setenv("MI355_TP_GATHER_LOGITS", "1")
+    monkeypatch.setenv("MI355_LOOKAHEAD", "0")
+    toks2, logits2 = run(world)
     agree = sum(int(a == b) for x, y in zip(toks1, toks2) for a, b in zip(x, y))
     assert agree >= 17, (toks1, toks2)  # 18 tokens; allow one near-tie flip
     if agree == 18 or model == "MID":  # the last step's logits: comparable if both runs fed the same tokens
         assert (logits1 - logits2).abs().max().item() <= tol
+
+
+def test_tp_decode_picks_tokens_in_the_graph(monkeypatch):
+    """Tensor-parallel decode without the host in the loop (two ranks on cuda:0 over gloo): every rank's decode graph
+    ends in the token choice - shard-local pick, 8-byte {key, token} exchange over the exchange region, the same
+    winner on every rank - so there is no logits gather and no sampler on rank 0, and the engine's lookahead queues
+    step k + 1 on both ranks before step k's tokens reach the host.  Greedy AND sampled rows must reproduce the
+    one-GPU streams (the noise is keyed by seed, step, row and GLOBAL column), up to near-ties of the slightly
+    different logits (the K sum of the row-parallel projections is split over the ranks)."""
+    import socket
+
+    from nanovllm import LLM, SamplingParams
+
+    gen = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in (9, 33, 70, 5, 21)]
+    sps = [SamplingParams(max_tokens=12, ignore_eos=True, greedy=True),
+           SamplingParams(temperature=0.8, max_tokens=12, ignore_eos=True),
+           SamplingParams(max_tokens=12, ignore_eos=True, greedy=True),
+           SamplingParams(temperature=1.2, max_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=0.5, max_tokens=12, ignore_eos=True)]
+
+    def run(tp):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+                  max_model_len=512, num_kvcache_blocks=64, warmup=False, synthetic_seed=3, sampling_seed=1234,
+                  tensor_parallel_size=tp, hccl_port=port)
+        try:
+            runner = llm.model_runner
+            assert runner.graph_samples == set(runner.graphs) and runner.graphs  # every bucket ends in the tokens
+            assert llm.lookahead and runner.can_launch_decode(5)
+            if tp > 1:
+                assert runner.xgmi is not None and not runner.gather_logits
+            outs = llm.generate(prompts, sps, use_tqdm=False)
+            assert runner.lookahead_launches >= 8  # steps were queued one ahead (on every rank, through the RPC ring)
+            return [o["token_ids"] for o in outs]
+        finally:
+            llm.exit()
+
+    one = run(1)
+    monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
+    two = run(2)
+    assert [len(t) for t in two] == [12] * 5
+    # a flipped token changes the rest of its row: compare rows up to their first difference
+    same = sum(next((i for i, (a, b) in enumerate(zip(x, y)) if a != b), len(x)) for x, y in zip(one, two))
+    assert one[0][:4] == two[0][:4] and one[1][:4] == two[1][:4], (one, two)
+    assert same >= 0.8 * 60, (same, one, two)
 
 
 def test_config0_bs1_128_token_prompt_greedy_full_qwen3_0p6b():

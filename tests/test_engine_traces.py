@@ -191,9 +191,11 @@ class _TraceRunner:
     def collect(self, handle):
         return handle
 
-    def call(self, name, seqs, is_prefill):
+    def call(self, name, seqs, *args):
+        if name == "launch_decode":  # the engine's RPC entry: a step queued behind the running one
+            return self.launch_decode(seqs, *args)
         assert name == "run"
-        return self._check_and_sample(seqs, is_prefill, [-1] * len(seqs)) if seqs else []
+        return self._check_and_sample(seqs, args[0], [-1] * len(seqs)) if seqs else []
 
 
 @pytest.mark.parametrize("sc", [s for s in SCENARIOS + FUZZ if {a[0] for a in s["arrivals"]} == {0}

@@ -559,8 +559,11 @@ class _ScriptedRunner:
     def collect(self, handle):
         return handle
 
-    def call(self, name, seqs, is_prefill):
+    def call(self, name, seqs, *args):
+        if name == "launch_decode":
+            return self.launch_decode(seqs, *args)
         assert name == "run"
+        is_prefill = args[0]
         if is_prefill:
             self.device_tokens = [self._next(s, s.last_token, s.num_tokens - 1) for s in seqs]
             return list(self.device_tokens)

@@ -137,19 +137,31 @@ def _body_rpc_channel(rank, world, port):
             s.append_token(5)
         ch.send("run", seqs, False)
         dist.barrier()
+        # two messages published back to back before anybody reads (the engine's lookahead queues one step behind
+        # the running one): the ring keeps both, in order
+        ch.send("launch_decode", seqs, False, extra=[1, -1])
+        for s in seqs:
+            s.append_token(6)
+        ch.send("launch_decode", seqs, False, extra=[0, 1])
+        dist.barrier()
         ch.send("exit")
         dist.barrier()
     else:
-        method, seqs, is_prefill = ch.recv()
+        method, seqs, is_prefill, _ = ch.recv()
         assert method == "run" and is_prefill and [len(s) for s in seqs] == [40, 7]
         assert seqs[0].token_ids == list(range(40)) and seqs[1].block_table == [3]
         assert seqs[1].temperature == 1.5 and seqs[0].num_blocks == 3 and seqs[0].last_block_num_tokens == 8
         dist.barrier()
-        method, seqs, is_prefill = ch.recv()
-        assert method == "run" and not is_prefill and [len(s) for s in seqs] == [41, 8]
+        method, seqs, is_prefill, extra = ch.recv()
+        assert method == "run" and not is_prefill and [len(s) for s in seqs] == [41, 8] and extra == []
         assert [s.last_token for s in seqs] == [5, 5]  # decode steps ship only the last token
         dist.barrier()
-        method, seqs, _ = ch.recv()
+        dist.barrier()  # both lookahead messages are out before the first is read
+        method, seqs, _, extra = ch.recv()
+        assert method == "launch_decode" and extra == [1, -1] and [len(s) for s in seqs] == [41, 8]
+        method, seqs, _, extra = ch.recv()
+        assert method == "launch_decode" and extra == [0, 1] and [s.last_token for s in seqs] == [6, 6]
+        method, seqs, _, _ = ch.recv()
         assert method == "exit" and seqs == []
         dist.barrier()
     ch.close()
