@@ -633,6 +633,8 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __re
 // ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+constexpr float kDeferMax = 8.0f;  // prefill: rescale the running softmax only when a maximum grows by more than 2^8
+
 // P as bf16 hi + lo (two MFMAs per product, fp32-softmax accuracy as in decode).  -DMI_PREFILL_SPLIT_P=0
 // drops the lo part: 118 vs 144 us at 16 x 1024 tokens, output error up to ~1.5 bf16 ulp instead of 0.5.
 #ifndef MI_PREFILL_SPLIT_P
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ kv_lens, uint16_t* __restrict__ out,
-    int n_q_heads, int n_kv_heads, int tpb, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
+    int n_q_heads, int n_kv_heads, int tpb, int tpb_shift, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
   constexpr int TQ = 32 / G;        // query tokens per wave
   constexpr int TQ_WG = 4 * TQ;     // per workgroup
   constexpr int NBUF = 3;           // LDS ring: chunk c is computed while c+1 and c+2 are landing
@@ -736,13 +738,17 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const int32_t* table_row = block_table + (int64_t)seq * table_stride;
   const KvStrides st = default_strides(n_kv_heads, tpb);
   const int piece = wave;
+  // this wave's cache (K or V) at this kv head; the tile of a chunk is then one scalar load + one 64-bit multiply-add
+  // away (tiles per block are a power of two for every block size but 48, 80, ...: shifts, not divisions - the
+  // request of a chunk is ~40 scalar instructions shorter, and the loop is issue-bound)
+  const uint16_t* const cache_h = ((piece & 2) ? vc : kc) + (int64_t)h * st.head + lane * 8;
   auto issue = [&](int c) {
     c = min(c, wg_chunks - 1);  // past the end: re-load the last chunk into a buffer nobody reads (keeps vmcnt uniform)
     const int tile0 = 2 * c;
     const int tile = (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
-    const int blk = table_row[tile / tpb];
-    const uint16_t* src = ((piece & 2) ? vc : kc) + (int64_t)blk * st.block + (int64_t)h * st.head +
-                          (int64_t)(tile % tpb) * st.tile + lane * 8;
+    const int blk = table_row[tpb_shift >= 0 ? tile >> tpb_shift : tile / tpb];
+    const int in_block = tpb_shift >= 0 ? tile & (tpb - 1) : tile % tpb;
+    const uint16_t* src = cache_h + (int64_t)blk * st.block + (int64_t)in_block * st.tile;
     uint16_t* dst = &stage[c % NBUF][piece][0];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -775,6 +781,9 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     issue(0);
     issue(1);
   }
+  // (Scores one chunk ahead of the softmax - the eight dependent score MFMAs of chunk c + 1 in the basic block of
+  // chunk c's exponentials, a fourth ring buffer - was built and measured in round 3: 145-147 us against 137-139
+  // for this form at 16 x 1024 tokens; removed.)
   for (int c = 0; c < wg_chunks; ++c) {
     // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
     // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
@@ -798,12 +807,18 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         for (int i = 0; i < 16; ++i)
           if (tok0 + (i & 3) + 8 * (i >> 2) >= limit) s[i] = -INFINITY;
       }
-      float mc = s[0];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) mc = fmaxf(mc, s[i]);
+      // sixteen scores -> one maximum: nested pairs that the compiler folds into v_max3_f32 (8 instead of 15)
+      float mc = fmaxf(fmaxf(fmaxf(fmaxf(s[0], s[1]), s[2]), fmaxf(fmaxf(s[3], s[4]), s[5])),
+                       fmaxf(fmaxf(fmaxf(s[6], s[7]), s[8]), fmaxf(fmaxf(s[9], s[10]), s[11])));
+      mc = fmaxf(mc, fmaxf(fmaxf(fmaxf(s[12], s[13]), s[14]), s[15]));
       mc = xor32_max(mc) * scale_log2e;  // scale > 0: the max commutes with it
       const float mn = fmaxf(m, mc);     // finite from chunk 0 on: key 0 is visible to every column
-      if (__any(mn != m)) {  // some column's running maximum moved: rescale (rare after the first chunks)
+      // The reference point m of the exponentials only has to stay within kDeferMax (log2 units) of the true running
+      // maximum: probabilities then reach at most 2^kDeferMax, which P - carried as bf16 hi + lo, 16 significant bits at
+      // any magnitude - and the fp32 sums hold without loss.  On random scores some column's maximum moves in most
+      // chunks (the rescale below then ran in ~85 % of them: 64 multiplies + the exp, in an issue-bound loop); it
+      // moves by more than 2^8 practically once, at the first chunk.
+      if (__any(mc > m + kDeferMax)) {  // some column's maximum ran away from the reference: rescale
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         l *= alpha;
 #pragma unroll
@@ -1022,6 +1037,9 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   const int n_qblocks = (max_seqlen_q + tq_wg - 1) / tq_wg, n_pairs = n_seqs * n_kv_heads;
   const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8 * n_qblocks));
   const float sl2 = scale * 1.4426950408889634f;
+  int tpb_shift = -1;
+  for (int sft = 0; sft < 12; ++sft)
+    if ((1 << sft) == block_size / 16) tpb_shift = sft;
   hipStream_t st = S(stream);
   constexpr bool kSplitP = MI_PREFILL_SPLIT_P;
   const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
@@ -1030,15 +1048,15 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
     if (prep && early)                                                                                          \
       hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true, true>), grid, dim3(256), 0, st, q,        \
                          q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
-                         n_q_heads, n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                  \
+                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
     else if (prep)                                                                                              \
       hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true>), grid, dim3(256), 0, st, q, q_row_stride, \
                          k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads,     \
-                         n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                             \
+                         n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);                  \
     else                                                                                                        \
       hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, false>), grid, dim3(256), 0, st, q,             \
                          q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
-                         n_q_heads, n_kv_heads, block_size / 16, sl2, n_qblocks, n_pairs, qp);                  \
+                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
   } while (0)
   switch (G) {
     case 1: LAUNCH_PRE(1); break;
