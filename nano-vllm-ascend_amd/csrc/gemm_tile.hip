@@ -25,7 +25,7 @@
 //     group one barrier later); the workgroup barrier behind the wait publishes the pieces to the next readers;
 //   * the two waves that share a SIMD (wave w and w + 4) run one barrier apart: while one issues its MFMA cluster,
 //     the other reads the next phase's fragments - the matrix pipe of a SIMD always has one wave feeding it;
-//   * past-the-end pieces (no further tile) are fetched into a spare 1 KiB block: the wait counts never change.
+//   * a workgroup's last tile requests nothing past its end; the waits of its last two K steps count accordingly.
 //     The first R_P0 of every tile waits vmcnt(0): the previous tile's stores sit on the same counter.
 // Tile order: plain (see tile_of_block).
 //
@@ -60,6 +60,10 @@ struct TileArgs {
 //   V & 4    XCD-rectangle tile order instead of the plain one (tile_of_block; measured equal or slower)
 //   V & 8    8-byte stores in the epilogue (no v_permlane32_swap widening)
 //   V & 16   one tile per workgroup (grid = tiles, not persistent)
+//   V & 1024 workgroups start up to 6 us apart (their output bursts interleave)
+//   V & 8192 output rows staged through a per-wave 4 KiB LDS buffer and stored as whole 128-byte lines (a CU's store
+//            path moves 49 instead of 17 bytes per cycle that way, tools/ubench/store_pattern.hip; with every CU
+//            storing at once the burst is HBM-bound either way: 130.8 vs 132.2 us on qkv, 69.5 vs 64.3 on o_proj)
 //   V & 512  ABLATION: no output stores
 //   V & 32 / 64 / 128   ABLATIONS for timing only (wrong results): no DMA in the K loop / no fragment reads in the K
 //            loop / no workgroup barriers in the K loop
@@ -143,12 +147,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
   // the same for step ke (0 or 1) of the workgroup's NEXT tile (src_off[h] already points at it); without a next
-  // tile the piece goes to the spare block, from an address that is valid in any case
-  char* const dummy = lds + SLOTS * HALF_BYTES;
+  // tile nothing is requested, and the waits of the last two K steps ask for correspondingly fewer pieces in flight
   auto issue_next = [&](int h, int i, int ke, int p) __attribute__((always_inline)) {
-    if (V & 32) return;
-    const char* src = reinterpret_cast<const char*>(is_weight_half(h) ? a.w : a.x) + kbeg_bytes + (has_next ? (int64_t)ke * (BK * 2) : 0) + src_off[h][i];
-    char* dst = has_next ? lds + (p * 4 + h) * HALF_BYTES + dma_block(wave, i) * 1024 : dummy;
+    if ((V & 32) || !has_next) return;
+    const char* src = reinterpret_cast<const char*>(is_weight_half(h) ? a.w : a.x) + kbeg_bytes + (int64_t)ke * (BK * 2) + src_off[h][i];
+    char* dst = lds + (p * 4 + h) * HALF_BYTES + dma_block(wave, i) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
     // a tile's first wait: the previous tile's stores share the counter with the loads, drain it once
     if (V & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else if (V & 256) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ablation: DMA never waited for
-    else if (kt == 0 || (V & 32)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (kt == 0 || (V & 32) || (MODE == 2 && !has_next))  // (a workgroup's last K step: nothing newer is in flight)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // M_P0
@@ -268,7 +272,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (V & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else if (V & 256) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (V & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if ((V & 32) || (MODE == 2 && !has_next)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (MODE == 1 && !has_next)  // the last tile's second-to-last step requested nothing here: only A1 of the last step flies
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // M_P1
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
   // for the same bytes.
   const int n_out = EPI == TEPI_SILU ? a.N >> 1 : a.N;
   const bool wide = !(V & 8) && n_out % 8 == 0 && a.ldy % 8 == 0;
+  char* const stg = lds + SLOTS * HALF_BYTES + wave * STAGE_BYTES;
   auto epilogue = [&]() __attribute__((always_inline)) {
     if (V & 512) {  // ablation: no output (the accumulators are kept alive by an empty asm)
 #pragma unroll
@@ -353,15 +360,35 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
         }
         if (wide) {
 #pragma unroll
-          for (int rq = 0; rq < 4; rq += 2) {
-            // lanes 32..63 of quad rq <-> lanes 0..31 of quad rq + 1: lanes < 32 then hold features 8 rq .. 8 rq + 7,
-            // lanes >= 32 features 8 (rq + 1) .. 8 (rq + 1) + 7
-            const auto sx = __builtin_amdgcn_permlane32_swap(pk[rq][0], pk[rq + 1][0], false, false);
-            const auto sy = __builtin_amdgcn_permlane32_swap(pk[rq][1], pk[rq + 1][1], false, false);
-            const int col = col0 + 8 * (rq + hi);
-            // (plain stores: non-temporal ones measured 185 vs 140 us on the qkv shape; rows staged through LDS and
-            // stored whole 147 vs 132; counted waits over the stores instead of the drain at the next tile's start: equal)
-            if (tok_ok && col < n_out) *reinterpret_cast<u32x4*>(yrow + col) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+          for (int p2 = 0; p2 < 2; ++p2) {
+            // lanes 32..63 of quad 2 p2 <-> lanes 0..31 of quad 2 p2 + 1: lanes < 32 then hold features
+            // 16 p2 .. 16 p2 + 7 of the fragment, lanes >= 32 features 16 p2 + 8 .. 16 p2 + 15
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+            const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+            if (!(V & 8192)) {  // straight from the accumulator layout: 32 rows x 32 bytes per instruction (the default)
+              const int col = col0 + 8 * (2 * p2 + hi);
+              if (tok_ok && col < n_out) *reinterpret_cast<u32x4*>(yrow + col) = v;
+            } else {
+              // into the wave's stage: row l31, 16-byte chunk (j & 1) * 4 + 2 p2 + hi of a 128-byte line, XOR-swizzled by
+              // the row so that the eight lanes of a ds_write_b128 group hit eight different chunks
+              const int chunk = ((j & 1) * 4 + 2 * p2 + hi) ^ (l31 & 7);
+              *reinterpret_cast<u32x4*>(stg + l31 * 128 + chunk * 16) = v;
+            }
+          }
+          if ((V & 8192) && (j & 1)) {
+            // Whole cache lines to memory.  Stored straight from the accumulator layout an instruction writes 32 bytes
+            // of 32 different rows and a CU's store path moves 17 bytes per cycle; as complete 128-byte lines - eight
+            // lanes per row, eight rows per instruction - it moves 49 (tools/ubench/store_pattern.hip).  The 32 x 64
+            // features of two fragments pass through the wave's private 4 KiB stage; LDS operations of one wave
+            // execute in order: no barrier.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 8 * r + (lane >> 3), c = lane & 7;
+              const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((c ^ (row & 7)) << 4));
+              const int t2 = m0 + acc_token(tq, bh, row), col = col0 - 32 + 8 * c;
+              if (t2 < a.M && col < n_out) *reinterpret_cast<u32x4*>(a.y + (int64_t)t2 * a.ldy + col) = v;
+            }
           }
         } else {
 #pragma unroll
@@ -374,6 +401,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
     }
   };
 
+  if (V & 1024) {  // workgroups start up to 6 us apart, in four groups per XCD: their output bursts interleave
+    for (int d = ((int)blockIdx.x >> 3) & 3; d > 0; --d) __builtin_amdgcn_s_sleep(63);
+  }
   // prologue, in the stream's order (R_P1 issues A0, B0 two steps ahead; R_P0 issues B1, A1 one step ahead):
   // A0, B0 of step 0 | B1, A1 of step 0 | A0, B0 of step 1; everything but the six newest pieces - that is A0, B0,
   // B1 of step 0 - landed and published.  (K = 64: "step 1" is the next tile's step 0.)
@@ -399,7 +429,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
       for (int i = 0; i < 2; ++i) issue_next(h, i, 0, 1);
   }
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  if (KT > 1 || has_next) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");  // one K step, one tile: only A half 1 still flies
   if (!(V & 2) && fh == 1) MI_GT_BARRIER();  // the second wave of every SIMD runs one barrier behind the first
   __builtin_amdgcn_sched_barrier(0);
 
@@ -525,6 +556,9 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
     case 224: return launch_tile<TEPI_NONE, false, 224>(a, st);
     case 256: return launch_tile<TEPI_NONE, false, 256>(a, st);
     case 512: return launch_tile<TEPI_NONE, false, 512>(a, st);
+    case 1024: return launch_tile<TEPI_NONE, false, 1024>(a, st);
+    case 8192: return launch_tile<TEPI_NONE, false, 8192>(a, st);
+    case 9216: return launch_tile<TEPI_NONE, false, 9216>(a, st);
     default: return MI_EUNSUPPORTED;
   }
 }

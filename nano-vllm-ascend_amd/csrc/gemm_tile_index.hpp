@@ -36,7 +36,8 @@ namespace gt {
 
 constexpr int TILE_F = 256, TILE_T = 256, BK = 64;
 constexpr int HALF_BYTES = 16384, SLOTS = 8;         // two K steps x four half-tiles
-constexpr int LDS_BYTES = SLOTS * HALF_BYTES + 1024;  // + one block that absorbs the past-the-end loads
+constexpr int STAGE_BYTES = 4096;  // per wave: 32 output rows x 128 bytes on their way to memory as whole cache lines
+constexpr int LDS_BYTES = SLOTS * HALF_BYTES + 8 * STAGE_BYTES;  // 160 KiB: everything a CU has
 
 // row of the workgroup tile (feature row for h = 0 / 3, token row for h = 1 / 2) held by local row lr of half-tile h
 MI_HD constexpr int tile_row(int h, int lr) {

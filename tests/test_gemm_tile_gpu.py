@@ -77,8 +77,9 @@ def test_gemm_tile_swiglu_epilogue(ops, M, N, K):
     got = ops.gemm_tile(x.to(DEV), w.to(DEV), silu_mul=True)
     two_pass = ops.silu_mul(ops.gemm_tile(x.to(DEV), w.to(DEV)))
     # (the plain GEMM of few-tile shapes sums K in slices: where a gate cancels to ~0 the two fp32 sums differ by
-    # K * 2^-24 * |terms| - the absolute floor of every GEMM comparison here)
-    assert_bf16_close(got, two_pass.cpu(), max_ulp=2, max_frac=1e-3, atol=32 * K * 2.0 ** -22)
+    # K * 2^-24 * |terms| - the absolute floor of every GEMM comparison here -
+    # and flip the bf16 rounding of a gate or up value in ~0.1 % of the elements at K = 5120)
+    assert_bf16_close(got, two_pass.cpu(), max_ulp=3, max_frac=5e-3, atol=32 * K * 2.0 ** -22)
     atol = K * 2.0 ** -22
     # a 1-ulp flip of the gate (summation order) times |up| <= ~6: widen the near-zero floor
     assert_bf16_close(got, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=4, max_frac=3e-2, atol=32 * atol)
@@ -105,7 +106,7 @@ def test_gemm_tile_full_prefill_shape_and_variants(ops):
     want = oracle.linear(x[:2048], w)  # the oracle on the first 2048 rows and on the last tile's rows
     assert_bf16_close(y[:2048], want, max_frac=2e-2, atol=K * 2.0 ** -22)
     assert_bf16_close(y[-300:], oracle.linear(x[-300:], w), max_frac=2e-2, atol=K * 2.0 ** -22)
-    for variant in (2, 8, 16):
+    for variant in (2, 8, 16, 1024, 8192):
         yv = ops.gemm_tile(xd, wd, variant=variant)
         assert torch.equal(yv.view(torch.int16), y.view(torch.int16)), variant
     side = torch.cuda.Stream()

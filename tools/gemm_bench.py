@@ -42,7 +42,8 @@ def main():
         (16384, 1024, 3072, "down"), (4096, 4096, 1024, "qkv@4k"), (1024, 4096, 1024, "qkv@1k"),
         (1024, 1024, 3072, "down@1k"), (256, 4096, 1024, "qkv@256"), (8192, 8192, 8192, "8k^3"),
     ]
-    variants = {"tile": 0, "lockstep": 2, "narrow_stores": 8, "one_tile_per_wg": 16}
+    variants = {"tile": 0, "lockstep": 2, "narrow_stores": 8, "one_tile_per_wg": 16, "staggered": 1024, "staged_line_stores": 8192,
+                "staged+staggered": 9216}
     if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
         variants = {"tile": 0, "no_dma": 32, "no_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
                     "dma_never_waited": 256, "no_stores": 512}
