@@ -453,6 +453,166 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
   if (!(V & 2) && fh == 0) MI_GT_BARRIER();         // barrier counts match again
 }
 
+// ---------------------------------------------------------------------------
+// The same GEMM on 128 x 128 tiles, for shapes whose 256 x 256 tiles cannot fill the chip (64 < M <= ~2048 rows:
+// large decode batches, short prompts).  Four waves, each 64 features x 64 tokens (2 x 2 accumulators); one K step of
+// the tile is two 16 KiB half-tiles in the layout of gemm_tile_index.hpp (A: local row = tile feature row, B: local
+// row = tile token row) in a ring of NST stages.  One barrier per K step: "my pieces of step t have landed" (a COUNTED
+// wait: the pieces of the NST - 2 steps behind it may still fly) -> barrier (everybody's have, and everybody is done
+// reading step t - 1) -> request step t + NST - 1 into the buffer step t - 1 used -> fragments of step t -> sixteen
+// MFMAs.  These shapes have at most a workgroup or two per CU and a K loop of 16-80 steps: with one step of
+// prefetch (NST = 2, two workgroups per CU) every step waits out most of a DMA round trip (0.75 us per step
+// measured); NST = 4 (128 KiB, one workgroup per CU) keeps three steps in flight.
+// Same summation order and epilogues as the large kernel: results are bit-identical.
+// SwiGLU: the tile's 128 weight rows are, per wave, 32 gate rows (fragment 0) and the 32 up rows that pair with them.
+// ---------------------------------------------------------------------------
+constexpr int MID_F = 128, MID_T = 128, MID_STAGE = 2 * HALF_BYTES;
+
+template <int EPI, bool BIAS, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_mid_kernel(const TileArgs a) {
+  __shared__ __attribute__((aligned(1024))) char lds[NST * MID_STAGE];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fw = wave >> 1, tw = wave & 1, hi = lane >> 5, l31 = lane & 31;
+  const int KT_all = a.K / BK;
+  const int KT = EPI == TEPI_PARTIAL ? KT_all / (int)gridDim.y : KT_all;
+  const int64_t kbeg_bytes = EPI == TEPI_PARTIAL ? (int64_t)blockIdx.y * KT * (BK * 2) : 0;
+  const int n0 = ((int)blockIdx.x % a.tiles_f) * MID_F, m0 = ((int)blockIdx.x / a.tiles_f) * MID_T;
+
+  // LDS-DMA: wave w moves the 1 KiB blocks 4 w .. 4 w + 3 (8 local rows each) of both half-tiles
+  const char* srcA[4];
+  const char* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lr = (wave * 4 + i) * 8 + (lane >> 3), c = (lane & 7) ^ swizzle(lr);
+    const int rowA = EPI == TEPI_SILU ? ((lr >> 5) & 1) * (a.N >> 1) + (n0 >> 1) + (lr >> 6) * 32 + (lr & 31) : n0 + lr;
+    srcA[i] = reinterpret_cast<const char*>(a.w) + kbeg_bytes + ((int64_t)min(rowA, a.N - 1) * a.K + c * 8) * 2;
+    srcB[i] = reinterpret_cast<const char*>(a.x) + kbeg_bytes + ((int64_t)min(m0 + lr, a.M - 1) * a.ldx + c * 8) * 2;
+  }
+  auto issue = [&](int kt, int p) __attribute__((always_inline)) {
+    char* dst = lds + p * MID_STAGE + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)kt * (BK * 2)),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)kt * (BK * 2)),
+                                       (__attribute__((address_space(3))) void*)(dst + HALF_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+  int kx[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    kx[kk] = (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][b][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < KT) issue(s, s);
+  int p = 0, pn = NST - 1;  // ring slots of step kt and of step kt + NST - 1
+  for (int kt = 0; kt < KT; ++kt) {
+    // requested so far: steps <= kt + NST - 2; eight pieces per step and wave, completing in order
+    const int behind = min(KT - 1 - kt, NST - 2);
+    if (behind >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NST - 1 < KT) issue(kt + NST - 1, pn);
+    const char* sa = lds + p * MID_STAGE + fw * 8192;
+    const char* sb = lds + p * MID_STAGE + HALF_BYTES + tw * 8192;
+    u32x4 A[2][4], B[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) A[f][kk] = *reinterpret_cast<const u32x4*>(sa + f * 4096 + kx[kk]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) B[b][kk] = *reinterpret_cast<const u32x4*>(sb + b * 4096 + kx[kk]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[f][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(A[f][kk]), as_frag(B[b][kk]), acc[f][b], 0, 0, 0);
+    p = p + 1 == NST ? 0 : p + 1;
+    pn = pn + 1 == NST ? 0 : pn + 1;
+  }
+
+  // epilogue: lane (hi, l31) holds token tw * 64 + b * 32 + l31, features 8 rq + 4 hi + {0..3} of each 32-row fragment
+  const int n_out = EPI == TEPI_SILU ? a.N >> 1 : a.N;
+  const bool wide = n_out % 8 == 0 && a.ldy % 8 == 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int tok = m0 + tw * 64 + b * 32 + l31;
+    const bool tok_ok = tok < a.M;
+    if (EPI == TEPI_PARTIAL) {
+      float* prow = a.part + ((int64_t)blockIdx.y * a.M + min(tok, a.M - 1)) * a.N;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int col = n0 + fw * 64 + f * 32 + 8 * rq + 4 * hi;
+          if (tok_ok && col < a.N)
+            *reinterpret_cast<f32x4*>(prow + col) =
+                f32x4{acc[f][b][4 * rq], acc[f][b][4 * rq + 1], acc[f][b][4 * rq + 2], acc[f][b][4 * rq + 3]};
+        }
+      continue;
+    }
+    uint16_t* yrow = a.y + (int64_t)min(tok, a.M - 1) * a.ldy;
+#pragma unroll
+    for (int f = 0; f < (EPI == TEPI_SILU ? 1 : 2); ++f) {
+      const int col0 = EPI == TEPI_SILU ? (n0 >> 1) + fw * 32 : n0 + fw * 64 + f * 32;
+      u32x2 pk[4];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = col0 + 8 * rq + 4 * hi;
+        float o[4];
+        if (EPI == TEPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {  // the roundings and the silu form of the large kernel's epilogue
+            const float gb = rbf(acc[0][b][4 * rq + e]);
+            const float sb = rbf(gb * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb * -1.4426950408889634f)));
+            o[e] = sb * rbf(acc[1][b][4 * rq + e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[f][b][4 * rq + e];
+          if (BIAS && col < n_out) {
+            const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + col);
+            o[0] += lo_bf(bw[0]);
+            o[1] += hi_bf(bw[0]);
+            o[2] += lo_bf(bw[1]);
+            o[3] += hi_bf(bw[1]);
+          }
+        }
+        pk[rq] = u32x2{pack_bf(o[0], o[1]), pack_bf(o[2], o[3])};
+      }
+      if (wide) {
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+          const int col = col0 + 8 * (2 * p2 + hi);
+          if (tok_ok && col < n_out) *reinterpret_cast<u32x4*>(yrow + col) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+        }
+      } else {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int col = col0 + 8 * rq + 4 * hi;
+          if (tok_ok && col < n_out) *reinterpret_cast<u32x2*>(yrow + col) = pk[rq];
+        }
+      }
+    }
+  }
+}
+
 // sum of the split-K slices in slice order, (+ bias), one rounding to bf16: four features per thread
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit,
                                                                    const uint16_t* __restrict__ bias,
@@ -492,13 +652,62 @@ static int launch_tile(const TileArgs& a, hipStream_t st, int ksplit = 1) {
   return check_launch();
 }
 
+// ---- which kernel, how many K slices ----
+// The 128-tile kernel takes the shapes whose 256-tiles are too few for the chip; both kernels give the same bits,
+// the choice is a matter of time only.  Modelled time of a launch: rounds of workgroups x K steps x time per step
+// (measured: tools/gemm_bench.py), plus - with K slices - the fp32 partial sums out and back and the second launch.
+constexpr double kMidStepUs = 0.5, kMidPairStepUs = 0.62, kLaunchUs = 3.8, kPartialBytesPerUs = 4.0e6;
+
+// fewer 256-tiles than CUs: the 128-tile kernel
+static bool use_mid(int M, int N, int K) {
+  return (int64_t)((M + TILE_T - 1) / TILE_T) * ((N + TILE_F - 1) / TILE_F) < kPersistentGrid;
+}
+
+static int mid_ksplit(int M, int N, int K) {
+  const int tiles = ((M + MID_T - 1) / MID_T) * ((N + MID_F - 1) / MID_F), kt = K / BK;
+  double best = 1e30;
+  int best_ks = 1;
+  for (int ks = 1; ks <= 16; ks *= 2) {
+    if (kt % ks || (ks > 1 && kt / ks < 2)) break;
+    // one workgroup on a CU takes ~0.5 us per K step (DMA issue and MFMAs of a wave do not overlap), two sharing
+    // it ~0.62 us for both
+    const int per_cu = (tiles * ks + kPersistentGrid - 1) / kPersistentGrid;
+    double t = (per_cu == 1 ? kMidStepUs : (per_cu + 1) / 2 * kMidPairStepUs) * (kt / ks) + kLaunchUs;
+    if (ks > 1) t += 2.0 * ks * (double)M * N * sizeof(float) / kPartialBytesPerUs + kLaunchUs;
+    if (t < best) {
+      best = t;
+      best_ks = ks;
+    }
+  }
+  return best_ks;
+}
+
+// NST = 0: by workgroup count - at most one workgroup per CU: the deep ring (nothing else hides the DMA round trip);
+// more: the two-stage ring, two workgroups per CU (measured, tools/gemm_bench.py GEMM_MID=1: 22 vs 27 us on
+// 1024 x 6144 x 1024, 31 vs 34 the other way round on 1024 x 1024 x 3072)
+template <int EPI, bool BIAS, int NST = 0>
+static int launch_mid(TileArgs a, hipStream_t st, int ksplit = 1) {
+  a.tiles_f = (a.N + MID_F - 1) / MID_F;
+  a.tiles_t = (a.M + MID_T - 1) / MID_T;
+  const dim3 grid(a.tiles_f * a.tiles_t, ksplit);
+  if (NST == 0) {
+    if ((int64_t)grid.x * grid.y > kPersistentGrid) hipLaunchKernelGGL((gemm_mid_kernel<EPI, BIAS, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_mid_kernel<EPI, BIAS, 4>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((gemm_mid_kernel<EPI, BIAS, (NST ? NST : 2)>), grid, dim3(256), 0, st, a);
+  }
+  return check_launch();
+}
+
+static int gemm_ksplit(int M, int N, int K) { return use_mid(M, N, K) ? mid_ksplit(M, N, K) : tile_ksplit(M, N, K); }
+
 static int check_tile_gemm(const void* x, int64_t ldx, const void* w, const void* bias, const void* y, int64_t ldy,
                            int M, int N, int K, int epilogue) {
   if (!x || !w || !y || M < 0 || N <= 0 || K <= 0 || ldx < K) return MI_EINVAL;
   if (epilogue != 0 && epilogue != 1) return MI_EINVAL;
   if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias))) return MI_EINVAL;
   if (K % BK || N % 4 || ldx % 8 || ldy % 4) return MI_EUNSUPPORTED;
-  if (epilogue == 1 && (bias || (N / 2) % 128)) return MI_EUNSUPPORTED;
+  if (epilogue == 1 && (bias || (N / 2) % 128)) return MI_EUNSUPPORTED;  // (the 128-tile kernel alone would take % 64)
   if (ldy < (epilogue == 1 ? N / 2 : N)) return MI_EINVAL;
   // the DMA sources are 32-bit byte offsets from the operand bases
   if ((int64_t)N * K * 2 >= (int64_t)1 << 32 || (int64_t)M * ldx * 2 >= (int64_t)1 << 32) return MI_EUNSUPPORTED;
@@ -511,7 +720,7 @@ using namespace mi;
 
 extern "C" size_t mi_gemm_bf16_workspace(int M, int N, int K, int epilogue) {
   if (M <= 0 || N <= 0 || K <= 0 || K % BK || epilogue != 0) return 0;
-  const int ks = tile_ksplit(M, N, K);
+  const int ks = gemm_ksplit(M, N, K);
   return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
@@ -522,18 +731,20 @@ extern "C" int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, con
   if (rc != MI_OK || M == 0) return rc;
   TileArgs a{x, w, bias, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T, nullptr};
   hipStream_t st = S(stream);
-  if (epilogue == 1) return launch_tile<TEPI_SILU, false>(a, st);
-  const int ks = tile_ksplit(M, N, K);
+  const bool mid = use_mid(M, N, K);
+  if (epilogue == 1) return mid ? launch_mid<TEPI_SILU, false>(a, st) : launch_tile<TEPI_SILU, false>(a, st);
+  const int ks = gemm_ksplit(M, N, K);
   if (ks > 1) {  // two launches: K slices as fp32 partial sums, then their sum (+ bias) rounded once
     if (!workspace || !aligned16(workspace) || ws_bytes < mi_gemm_bf16_workspace(M, N, K, 0)) return MI_EWORKSPACE;
     a.part = static_cast<float*>(workspace);
-    const int rc2 = launch_tile<TEPI_PARTIAL, false>(a, st, ks);
+    const int rc2 = mid ? launch_mid<TEPI_PARTIAL, false>(a, st, ks) : launch_tile<TEPI_PARTIAL, false>(a, st, ks);
     if (rc2 != MI_OK) return rc2;
     const int64_t quads = (int64_t)M * (N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.part, ks, bias, y,
                        ldy, M, N);
     return check_launch();
   }
+  if (mid) return bias ? launch_mid<TEPI_NONE, true>(a, st) : launch_mid<TEPI_NONE, false>(a, st);
   return bias ? launch_tile<TEPI_NONE, true>(a, st) : launch_tile<TEPI_NONE, false>(a, st);
 }
 
@@ -559,6 +770,9 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
     case 1024: return launch_tile<TEPI_NONE, false, 1024>(a, st);
     case 8192: return launch_tile<TEPI_NONE, false, 8192>(a, st);
     case 9216: return launch_tile<TEPI_NONE, false, 9216>(a, st);
+    case 65536: return launch_mid<TEPI_NONE, false, 4>(a, st);  // the 128-tile kernel, no K slices, four-stage ring
+    case 65538: return launch_mid<TEPI_NONE, false, 2>(a, st);  // ... with a two-stage ring, two workgroups per CU
+    case 65539: return launch_mid<TEPI_NONE, false, 3>(a, st);
     default: return MI_EUNSUPPORTED;
   }
 }

@@ -1,10 +1,10 @@
 """Tensor-parallel linear layers (reference: nanovllm/layers/linear.py) — same class
 names, constructor arguments and per-parameter `weight_loader` sharding rules.
 
-forward(): decode-sized activations (at most ops.SKINNY_MAX_M rows) go through the hand-written
-weight-streaming MFMA kernels (mi_gemm_bf16_packed / _skinny, the rows in chunks of 64); everything
-larger - every prefill projection - through the 256 x 256 MFMA tile kernel mi_gemm_bf16
-(csrc/gemm_tile.hip).  No library GEMM anywhere on the path.
+forward(): decode-sized activations (ops.prefers_tile: at most 128 rows, up to 512 for the narrow
+projections) go through the hand-written weight-streaming MFMA kernels (mi_gemm_bf16_packed / _skinny,
+the rows in chunks of 64); everything larger - every prefill projection - through the MFMA tile
+kernels of mi_gemm_bf16 (csrc/gemm_tile.hip).  No library GEMM anywhere on the path.
 """
 from __future__ import annotations
 
@@ -18,7 +18,9 @@ from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
 def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None,
                    packed: torch.Tensor | None = None) -> torch.Tensor:
     rows = x.numel() // x.shape[-1]
-    if rows <= ops.SKINNY_MAX_M and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0:
+    tileable = weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0 and not isinstance(packed, ops.Fp8Weight)
+    if (rows <= ops.SKINNY_MAX_M and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0
+            and not (tileable and ops.prefers_tile(rows, weight.shape[0]))):
         if isinstance(packed, ops.Fp8Weight):  # the fp8 GEMM has no bias operand
             y = ops.gemm_packed(x, packed)
             return y if bias is None else y.add_(bias)

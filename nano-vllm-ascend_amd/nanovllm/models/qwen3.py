@@ -129,8 +129,8 @@ class Qwen3MLP(nn.Module):
     def forward(self, x):
         gu = self.gate_up_proj
         rows = x.numel() // x.shape[-1]
-        if (rows > ops.SKINNY_MAX_M and gu.bias is None and x.is_cuda and gu.weight.shape[1] % 64 == 0
-                and (gu.weight.shape[0] // 2) % 128 == 0):
+        if (ops.prefers_tile(rows, gu.weight.shape[0]) and gu.bias is None and x.is_cuda and gu.weight.shape[1] % 64 == 0
+                and (gu.weight.shape[0] // 2) % 128 == 0 and not isinstance(gu.weight_packed, ops.Fp8Weight)):
             # prefill-sized: SiluAndMul is the tile GEMM's epilogue (the reference's three roundings; the
             # 2 x intermediate wide gate_up output never exists in memory)
             shape = x.shape
@@ -277,10 +277,20 @@ class Qwen3Model(nn.Module):
                 return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
             return ops.add_rmsnorm(y, res, ln.weight, ln.eps)
 
-        def norm_linear(y, is_partials, res, ln, w_packed, silu_mul=False):
+        def column_parallel(x, lin, silu_mul=False):
+            """qkv / gate_up (+ SwiGLU): the weight-streaming kernel, or - large batches, wide projections - the
+            128-tile MFMA kernel on the weight as stored (ops.prefers_tile)"""
+            w = lin.weight
+            if (ops.prefers_tile(rows, w.shape[0]) and w.shape[1] % 64 == 0
+                    and not isinstance(lin.weight_packed, ops.Fp8Weight)
+                    and (not silu_mul or (w.shape[0] // 2) % 128 == 0)):
+                return ops.gemm_tile(x, w, silu_mul=silu_mul)
+            return ops.gemm_packed(x, lin.weight_packed, silu_mul=silu_mul)
+
+        def norm_linear(y, is_partials, res, ln, lin, silu_mul=False):
             """linear(rmsnorm(y + res)) -> (out, new residual)"""
             x, res = add_norm(y, is_partials, res, ln)
-            return ops.gemm_packed(x, w_packed, silu_mul=silu_mul), res
+            return column_parallel(x, lin, silu_mul), res
 
         residual, parts, is_partials = None, None, False
         for layer in self.layers:
@@ -288,17 +298,16 @@ class Qwen3Model(nn.Module):
             ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
             if residual is None:  # first layer: the residual stream starts as the embedding (qwen3.py:137-138)
                 residual = h
-                qkv = ops.gemm_packed(ops.rmsnorm(h, ln1.weight, ln1.eps), attn.qkv_proj.weight_packed)
+                qkv = column_parallel(ops.rmsnorm(h, ln1.weight, ln1.eps), attn.qkv_proj)
             else:
-                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj.weight_packed)
+                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj)
             o = attend(attn, qkv)
             parts, is_partials = row_parallel(o, attn.o_proj)
             if hasattr(mlp, "experts"):  # sparse block (models/qwen3_moe.py): five launches over expert-sorted pairs
                 x, residual = add_norm(parts, is_partials, residual, ln2)
                 parts, is_partials = mlp(x), False  # summed over the ranks inside the block (before the combine)
             else:
-                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj.weight_packed,
-                                            silu_mul=True)
+                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj, silu_mul=True)
                 parts, is_partials = row_parallel(act, mlp.down_proj)
         x, _ = add_norm(parts, is_partials, residual, self.norm)
         return x

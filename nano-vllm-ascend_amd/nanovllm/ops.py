@@ -288,6 +288,16 @@ def silu_mul(x, out=None) -> torch.Tensor:
 # rows the weight-streaming decode kernels take in one launch (chunks of 64 rows, csrc kSkinnyMaxRows); the decode
 # fast path of the models, the in-graph sampler and the engine's lookahead all go up to this many sequences
 SKINNY_MAX_M = 512
+# ... but above this many rows a WIDE projection (qkv, gate_up: thousands of output features = enough 128 x 128 tiles
+# for the chip) is faster on the MFMA tile kernel: 12.7 vs 15.1 us (qkv) and 13.1 vs 21.7 us (gate_up + SwiGLU) at 256
+# rows, 13.4 vs 28.0 and 14.3 vs 50.0 at 512; the narrow row-parallel projections (o_proj, down: N = hidden) stay on
+# the streaming kernels up to SKINNY_MAX_M rows (7.4 vs 13.2 us at 256) - tools/gemm_bench.py, GEMM_MID=1
+TILE_MIN_ROWS = 128
+TILE_MIN_FEATURES = 2048
+
+
+def prefers_tile(rows: int, n_features: int) -> bool:
+    return rows > SKINNY_MAX_M or (rows > TILE_MIN_ROWS and n_features >= TILE_MIN_FEATURES)
 
 
 def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
@@ -306,7 +316,8 @@ def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
 
 
 def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | None = None) -> torch.Tensor:
-    """y = x @ w.T (+ bias) for any number of rows on the 256 x 256 MFMA tile kernel (mi_gemm_bf16); silu_mul:
+    """y = x @ w.T (+ bias) for any number of rows on the MFMA tile kernels (mi_gemm_bf16: 256 x 256 tiles, 128 x 128
+    for shapes with few of those); silu_mul:
     w stacks gate | up rows and y = SiluAndMul(x @ w.T).  x may be a row-strided 2-D view."""
     require_gpu(x, w, bias)
     _bf16(x, w, bias)
@@ -334,6 +345,7 @@ def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | 
 
 
 _GEMM_WS: dict[torch.device, torch.Tensor] = {}
+_GEMM_WS_RETIRED: list[torch.Tensor] = []
 
 
 def _gemm_workspace(device, nbytes: int) -> torch.Tensor:
@@ -341,6 +353,8 @@ def _gemm_workspace(device, nbytes: int) -> torch.Tensor:
     ordered, so consecutive GEMMs may share it)"""
     ws = _GEMM_WS.get(device)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:  # a captured graph may hold the old buffer's address: it stays allocated
+            _GEMM_WS_RETIRED.append(ws)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _GEMM_WS[device] = ws
     return ws

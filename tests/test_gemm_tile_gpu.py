@@ -38,6 +38,13 @@ def test_gemm_tile_vs_oracle(ops, M, N, K):
     assert_bf16_close(y, oracle.linear(x, w), max_ulp=1, max_frac=2e-2, atol=atol)
     yb = ops.gemm_tile(x.to(DEV), w.to(DEV), b.to(DEV))
     assert_bf16_close(yb, oracle.linear(x, w, b), max_ulp=1, max_frac=2e-2, atol=atol)
+    # these row counts go to the 128-tile kernel (possibly in K slices); the 256-tile kernel and the unsliced
+    # 128-tile kernel run the same fp32 chain per output element: the same bits
+    big = ops.gemm_tile(x.to(DEV), w.to(DEV), variant=0)
+    for variant in (65536, 65538, 65539):  # ring of 4 / 2 / 3 stages
+        mid = ops.gemm_tile(x.to(DEV), w.to(DEV), variant=variant)
+        assert torch.equal(big.view(torch.int16), mid.view(torch.int16)), variant
+    assert_bf16_close(big, oracle.linear(x, w), max_ulp=1, max_frac=2e-2, atol=atol)
     # transpose / fragment-layout detector: asymmetric weights, one-hot activations
     xe = torch.zeros(M, K).bfloat16()
     xe[M - 3, 5] = 1.0
@@ -83,6 +90,21 @@ def test_gemm_tile_swiglu_epilogue(ops, M, N, K):
     atol = K * 2.0 ** -22
     # a 1-ulp flip of the gate (summation order) times |up| <= ~6: widen the near-zero floor
     assert_bf16_close(got, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=4, max_frac=3e-2, atol=32 * atol)
+
+
+@pytest.mark.parametrize("M", [129, 3840, 4096, 4097])
+def test_gemm_tile_kernel_choice_boundary(ops, M):
+    """either side of the tile count (256 tiles of 256 x 256) at which the 128-tile kernel hands over to the large one"""
+    N, K = 4096, 128
+    g, x, w = _case(M, N, K, seed=13)
+    b = torch.randn(N, generator=g).bfloat16()
+    y = ops.gemm_tile(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert_bf16_close(y, oracle.linear(x, w, b), max_ulp=1, max_frac=2e-2, atol=K * 2.0 ** -22)
+    for variant in (0, 65536, 65538, 65539):  # large kernel; 128-tile kernel with 4 / 2 / 3 ring stages
+        yv = ops.gemm_tile(x.to(DEV), w.to(DEV), variant=variant)
+        assert_bf16_close(yv, oracle.linear(x, w), max_ulp=1, max_frac=2e-2, atol=K * 2.0 ** -22)
+    gu = ops.gemm_tile(x.to(DEV), w.to(DEV), silu_mul=True)
+    assert_bf16_close(gu, oracle.silu_and_mul(oracle.linear(x, w)), max_ulp=4, max_frac=3e-2, atol=32 * K * 2.0 ** -22)
 
 
 def test_gemm_tile_strided_rows(ops):

@@ -40,10 +40,15 @@ def main():
     shapes = [  # (M, N, K, label)
         (16384, 4096, 1024, "qkv"), (16384, 1024, 2048, "o_proj"), (16384, 6144, 1024, "gate_up"),
         (16384, 1024, 3072, "down"), (4096, 4096, 1024, "qkv@4k"), (1024, 4096, 1024, "qkv@1k"),
-        (1024, 1024, 3072, "down@1k"), (256, 4096, 1024, "qkv@256"), (8192, 8192, 8192, "8k^3"),
+        (1024, 1024, 3072, "down@1k"), (2048, 1024, 3072, "down@2k"), (512, 4096, 1024, "qkv@512"),
+        (256, 4096, 1024, "qkv@256"), (128, 4096, 1024, "qkv@128"), (128, 1024, 3072, "down@128"), (8192, 8192, 8192, "8k^3"),
     ]
     variants = {"tile": 0, "lockstep": 2, "narrow_stores": 8, "one_tile_per_wg": 16, "staggered": 1024, "staged_line_stores": 8192,
                 "staged+staggered": 9216}
+    if os.environ.get("GEMM_MID"):  # the two kernels side by side over the mid-size shapes
+        variants = {"tile": 0, "mid128": 65536, "mid128_2stage": 65538, "mid128_3stage": 65539}
+        shapes = [(M, N, K, f"{name}@{M}") for M in (128, 256, 512, 1024, 2048, 4096)
+                  for N, K, name in ((4096, 1024, "qkv"), (1024, 2048, "o_proj"), (6144, 1024, "gate_up"), (1024, 3072, "down"))]
     if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
         variants = {"tile": 0, "no_dma": 32, "no_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
                     "dma_never_waited": 256, "no_stores": 512}
@@ -62,6 +67,13 @@ def main():
             t = timed(lambda: ops.gemm_tile(x, w, out=y, variant=v))
             row[name + "_us"] = round(t, 2)
             row[name + "_tflops"] = round(flops / t / 1e6, 1)
+        t = timed(lambda: ops.gemm_tile(x, w, out=y))  # the product entry point (K slices for few-tile shapes)
+        row["product_us"] = round(t, 2)
+        row["product_tflops"] = round(flops / t / 1e6, 1)
+        if M <= 512:  # decode-sized: what the layers actually call
+            wp = ops.pack_weight(w)
+            t = timed(lambda: ops.gemm_packed(x, wp))
+            row["skinny_chunked_us"] = round(t, 2)
         ref = F.linear(x, w)
         ops.gemm_tile(x, w, out=y, variant=0)
         row["max_abs_diff_vs_library"] = float((y.float() - ref.float()).abs().max())
