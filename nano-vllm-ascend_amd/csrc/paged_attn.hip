@@ -768,8 +768,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   // finished and the counter drained to zero before the first chunk request; inside the loop the wave issues no
   // other vector-memory operation (block ids come through the scalar cache: lgkmcnt), and the output stores follow
   // the final vmcnt(0).  EARLY: the two requests go out first and the drain behind the Q preparation waits for
-  // them as well - the same invariant at loop entry, one DMA latency more of overlap in exchange for nothing
-  // measurable (profiles/r03_prefill_attention_order.txt).
+  // them as well - the same invariant at loop entry; measured slower (149-158 vs 145-150 us per launch,
+  // profiles/r03_prefill_attention_order.txt).
   if (EARLY) {
     issue(0);
     issue(1);

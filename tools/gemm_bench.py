@@ -47,7 +47,7 @@ def main():
                 "staged+staggered": 9216}
     if os.environ.get("GEMM_MID"):  # the two kernels side by side over the mid-size shapes
         variants = {"tile": 0, "mid128": 65536, "mid128_2stage": 65538, "mid128_3stage": 65539}
-        shapes = [(M, N, K, f"{name}@{M}") for M in (128, 256, 512, 1024, 2048, 4096)
+        shapes = [(M, N, K, f"{name}@{M}") for M in ((16384,) if os.environ.get("GEMM_MID") == "big" else (128, 256, 512, 1024, 2048, 4096))
                   for N, K, name in ((4096, 1024, "qkv"), (1024, 2048, "o_proj"), (6144, 1024, "gate_up"), (1024, 3072, "down"))]
     if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
         variants = {"tile": 0, "no_dma": 32, "no_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,

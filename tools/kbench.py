@@ -64,6 +64,35 @@ def prefill_attention():
           f"({flops / t / 2.5e15:.3f} of 2.5 PFLOP/s bf16)")
 
 
+def prefill_attention_order():
+    """The fused-Q prefill attention (q-norm + RoPE in the Q-operand load) with the first two K/V chunks requested
+    behind the Q preparation (the default) and ahead of it (variant 1), alternating rounds."""
+    n, T, bs, hq, hkv, L = 16, int(os.environ.get("CTX", 1024)), 16, 16, 8, 4
+    nb = (T + bs - 1) // bs
+    g = torch.Generator(device="cpu").manual_seed(0)
+    kc = [torch.randn(ops.kv_cache_shape(n * nb, hkv, bs), device=DEV).bfloat16() for _ in range(L)]
+    vc = [torch.randn(ops.kv_cache_shape(n * nb, hkv, bs), device=DEV).bfloat16() for _ in range(L)]
+    tables = torch.randperm(n * nb, generator=g).to(torch.int32).view(n, nb).to(DEV)
+    qkv = torch.randn(n * T, (hq + 2 * hkv) * 128, device=DEV).bfloat16()
+    qw = torch.ones(128, device=DEV).bfloat16()
+    pos = torch.arange(T, dtype=torch.int64).repeat(n).to(DEV)
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128))
+    fr = torch.arange(T).float()[:, None] * inv[None]
+    cos_sin = torch.cat([fr.cos(), fr.sin()], -1).to(DEV)
+    out = torch.empty(n * T, hq * 128, device=DEV).bfloat16()
+    cu = (torch.arange(n + 1, dtype=torch.int32) * T).to(DEV)
+    kvl = torch.full((n,), T, dtype=torch.int32, device=DEV)
+    res = {"requests behind the Q preparation (default)": [], "requests ahead of it (variant 1)": []}
+    for rnd in range(4):
+        for name, v in (("requests behind the Q preparation (default)", None), ("requests ahead of it (variant 1)", 1)):
+            t = timeit(lambda l: ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[l], vc[l], tables, cu, kvl, T,
+                                                              hq, hkv, bs, 128 ** -0.5, out=out, variant=v), L)
+            res[name].append(round(t * 1e6, 1))
+    print(f"fused-Q prefill attention 16x{T}, us per launch, four alternating rounds:")
+    for k, v in res.items():
+        print(f"  {k}: {v}")
+
+
 def head_and_sampler():
     """The head GEMM (151936 x 1024, 32 rows) alone, with the pick epilogue, and the standalone sampler."""
     M, N, K = 32, 151936, 1024
@@ -174,6 +203,8 @@ def main():
         return moe_block()
     if os.environ.get("KBENCH_ONLY") == "32b":
         return chain_32b_shard()
+    if os.environ.get("KBENCH_ONLY") == "prefill_order":
+        return prefill_attention_order()
     if os.environ.get("KBENCH_ONLY") == "prefill":
         return prefill_attention()
     if os.environ.get("KBENCH_ONLY") == "head":
