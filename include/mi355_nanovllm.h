@@ -311,6 +311,29 @@ int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* resi
                           const mi_bf16* w, mi_bf16* y, mi_bf16* residual_out, int rows,
                           int cols, float eps, mi_stream stream);
 
+/* mi_add_rmsnorm_splitk for the decode chain (rows <= 64, cols <= 1024) with the CUs the norm leaves idle
+ * (a launch of `rows` workgroups on a 256-CU part) pulling the packed weights of the launches BEHIND it - the
+ * projections this norm feeds (linear.py:73,150 of the same layer) - into the L2 of the XCD that will read them.
+ * warmN: mi_pack_weight output (or NULL), warmN_tile_bytes = 32 * K (one 16-row tile), a multiple of 4096.
+ * Results are those of mi_add_rmsnorm_splitk bit for bit; only the timing of the following launches changes. */
+int mi_add_rmsnorm_splitk_warm(const float* partials, int nsplit, const mi_bf16* residual,
+                               const mi_bf16* w, mi_bf16* y, mi_bf16* residual_out, int rows,
+                               int cols, float eps, const void* warm0, size_t warm0_bytes,
+                               int warm0_tile_bytes, const void* warm1, size_t warm1_bytes,
+                               int warm1_tile_bytes, mi_stream stream);
+
+/* EXPERIMENT, not on the product path (decode chain): the MLP half of a decode layer
+ * (layernorm.py:27-38 -> linear.py:73 + activation.py:10-12 -> linear.py:150) as ONE persistent launch of 256
+ * workgroups with in-launch hand-offs instead of three launches; bit-identical to
+ * mi_add_rmsnorm_splitk + mi_gemm_bf16_packed(epilogue 1) + mi_gemm_bf16_packed_splitk(ksplit 4).
+ * hidden 1024, intermediate 3072, 1 <= rows <= 32, partials_in / partials_out [4][rows][1024] fp32;
+ * sync_words: 8 x uint32, zeroed once by the caller (word 6 != 0 afterwards: a hand-off timed out). */
+int mi_mlp_half_fused(const float* partials_in, const mi_bf16* residual, const mi_bf16* norm_w, float eps,
+                      const mi_bf16* w_gate_up_packed, const mi_bf16* w_down_packed,
+                      mi_bf16* residual_out, mi_bf16* xn_scratch, mi_bf16* act_scratch,
+                      float* partials_out, uint32_t* sync_words, int rows, int hidden, int intermediate,
+                      mi_stream stream);
+
 /* ---- embedding / head (reference: layers/embed_head.py) ------------------- */
 /* VocabParallelEmbedding.forward (embed_head.py:34-42): out[t] = w[ids[t]-vocab_start]
  * if vocab_start <= ids[t] < vocab_start+vocab_local else 0 (TP mask). */

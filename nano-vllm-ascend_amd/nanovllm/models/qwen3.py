@@ -268,11 +268,19 @@ class Qwen3Model(nn.Module):
                 y = all_reduce_sum(y)
             return y, ("ranks" if fused_seam else False)
 
-        def add_norm(y, is_partials, res, ln):
+        # measured: 1.52-1.54 ms per decode step with the warming, 1.50-1.51 without (bench, same box, alternating):
+        # off unless asked for ("first": only the column-parallel projection's weights)
+        warm_l2 = os.environ.get("MI355_WARM_L2", "0") != "0"
+        warm_n = 1 if os.environ.get("MI355_WARM_L2") == "first" else 2
+
+        def add_norm(y, is_partials, res, ln, warm=()):
             """is_partials: True = fp32 split-K partials of this rank (TP 1); "ranks" = bf16 partial sums that
-            still have to be summed over the TP ranks (fused seam); False = a finished bf16 tensor."""
+            still have to be summed over the TP ranks (fused seam); False = a finished bf16 tensor.
+            warm: the linear layers this norm feeds - the norm launch (rows workgroups on 256 CUs) pulls their
+            packed weights into L2 with its idle CUs."""
             if is_partials is True:
-                return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps)
+                return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps,
+                                              warm=[m.weight_packed for m in warm][:warm_n] if warm_l2 else ())
             if is_partials == "ranks":  # all-reduce over xGMI + add + RMSNorm in one launch
                 return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
             return ops.add_rmsnorm(y, res, ln.weight, ln.eps)
@@ -287,9 +295,9 @@ class Qwen3Model(nn.Module):
                 return ops.gemm_tile(x, w, silu_mul=silu_mul)
             return ops.gemm_packed(x, lin.weight_packed, silu_mul=silu_mul)
 
-        def norm_linear(y, is_partials, res, ln, lin, silu_mul=False):
-            """linear(rmsnorm(y + res)) -> (out, new residual)"""
-            x, res = add_norm(y, is_partials, res, ln)
+        def norm_linear(y, is_partials, res, ln, lin, silu_mul=False, then=None):
+            """linear(rmsnorm(y + res)) -> (out, new residual); `then`: the row-parallel projection behind it"""
+            x, res = add_norm(y, is_partials, res, ln, warm=(lin,) if then is None else (lin, then))
             return column_parallel(x, lin, silu_mul), res
 
         residual, parts, is_partials = None, None, False
@@ -300,14 +308,15 @@ class Qwen3Model(nn.Module):
                 residual = h
                 qkv = column_parallel(ops.rmsnorm(h, ln1.weight, ln1.eps), attn.qkv_proj)
             else:
-                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj)
+                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj, then=attn.o_proj)
             o = attend(attn, qkv)
             parts, is_partials = row_parallel(o, attn.o_proj)
             if hasattr(mlp, "experts"):  # sparse block (models/qwen3_moe.py): five launches over expert-sorted pairs
                 x, residual = add_norm(parts, is_partials, residual, ln2)
                 parts, is_partials = mlp(x), False  # summed over the ranks inside the block (before the combine)
             else:
-                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj, silu_mul=True)
+                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj, silu_mul=True,
+                                            then=mlp.down_proj)
                 parts, is_partials = row_parallel(act, mlp.down_proj)
         x, _ = add_norm(parts, is_partials, residual, self.norm)
         return x

@@ -481,7 +481,29 @@ def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:
     return out
 
 
-def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out=None):
+def mlp_half_fused(partials, residual, norm_w, eps: float, w_gate_up_packed, w_down_packed, sync_words, scratch=None):
+    """EXPERIMENT (csrc/mlp_half.hip): add+RMSNorm -> gate_up+SwiGLU -> down split-K as one persistent launch.
+    -> (fp32 partials [4, rows, hidden], new residual); sync_words: 8 zeroed int32 on the device, kept across calls."""
+    require_gpu(partials, residual, norm_w, w_gate_up_packed, w_down_packed, sync_words)
+    _bf16(residual, norm_w, w_gate_up_packed, w_down_packed)
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[0] == 4
+    rows, hidden = residual.shape
+    inter = w_down_packed.shape[1]
+    assert sync_words.dtype == torch.int32 and sync_words.numel() >= 8
+    if scratch is None:
+        scratch = (torch.empty_like(residual), torch.empty(rows, hidden, dtype=_BF16, device=residual.device),
+                   torch.empty(rows, inter, dtype=_BF16, device=residual.device),
+                   torch.empty(4, rows, hidden, dtype=torch.float32, device=residual.device))
+    res_out, xn, act, out = scratch
+    check(lib.mi_mlp_half_fused(ptr(partials), ptr(residual), ptr(norm_w), float(eps), ptr(w_gate_up_packed),
+                                ptr(w_down_packed), ptr(res_out), ptr(xn), ptr(act), ptr(out), ptr(sync_words), rows,
+                                hidden, inter, stream()), "mi_mlp_half_fused")
+    return out, res_out
+
+
+def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out=None, warm=()):
+    """warm: up to two packed bf16 weights ([N, K], mi_pack_weight) of the GEMMs behind this norm; decode-sized
+    inputs then use the launch's idle CUs to pull them into L2 (mi_add_rmsnorm_splitk_warm)."""
     require_gpu(partials, residual, w)
     _bf16(residual, w)
     assert partials.dtype == torch.float32 and partials.is_contiguous() and residual.is_contiguous()
@@ -491,6 +513,18 @@ def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out
         out = torch.empty_like(residual)
     if residual_out is None:
         residual_out = torch.empty_like(residual)
+    warm = [t for t in warm if isinstance(t, torch.Tensor) and t.dtype == _BF16 and t.dim() == 2
+            and (32 * t.shape[1]) % 4096 == 0 and t.numel() * 2 < (1 << 32)]
+    if warm and rows <= 64 and cols <= 1024 and cols % 4 == 0:
+        w0, w1 = warm[0], (warm[1] if len(warm) > 1 else None)
+        check(
+            lib.mi_add_rmsnorm_splitk_warm(ptr(partials), nsplit, ptr(residual), ptr(w), ptr(out), ptr(residual_out),
+                                           rows, cols, float(eps), ptr(w0), w0.numel() * 2, 32 * w0.shape[1],
+                                           ptr(w1), w1.numel() * 2 if w1 is not None else 0,
+                                           32 * w1.shape[1] if w1 is not None else 0, stream()),
+            "mi_add_rmsnorm_splitk_warm",
+        )
+        return out, residual_out
     check(
         lib.mi_add_rmsnorm_splitk(ptr(partials), nsplit, ptr(residual), ptr(w), ptr(out), ptr(residual_out), rows,
                                   cols, float(eps), stream()),
