@@ -419,6 +419,10 @@ int mi_gemm_fp8w_packed_splitk(const mi_bf16* x, const uint8_t* w_packed, const 
  * [E][2*inter][hidden] with rows gate | up (MergedColumnParallelLinear, :104-108), down [E][hidden][inter];
  * under tensor parallelism `inter` is this rank's shard and the bf16 outputs of mi_moe_down are partial sums
  * to be all-reduced before mi_moe_combine (RowParallelLinear, :109-113). */
+/* Whether mi_moe_gate_up / mi_moe_down have a kernel for experts of [2 * inter][hidden] / [hidden][inter]
+ * (inter: this rank's share of moe_intermediate_size, qwen3_moe.py:104-115): MI_OK or MI_EUNSUPPORTED.  Host only. */
+int mi_moe_shapes_supported(int hidden, int inter);
+
 /* Routing (:153-161): softmax over the experts in fp32, top-k, renormalise by the top-k sum, cast to bf16.
  * topk_ids / topk_w [n_tokens][top_k], each token's picks in ASCENDING expert id (the order the reference's
  * expert loop adds them in, :171-172); equal probabilities: lower expert id first.  n_experts <= 512. */

@@ -226,6 +226,27 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
       u32x4{pack_bf(acc[0], acc[1]), pack_bf(acc[2], acc[3]), pack_bf(acc[4], acc[5]), pack_bf(acc[6], acc[7])};
 }
 
+// contraction lengths launch_moe_gemm has an instantiation for (K = WAVES * 32 * STEPS, see there)
+static bool moe_k_supported(int K) {
+  if (K <= 0) return false;
+  if (K % 64 == 0 && K / 64 <= 16)
+    switch (K / 64) {
+      case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: return true;
+      default: break;
+    }
+  if (K % 128 == 0 && K / 128 <= 16)
+    switch (K / 128) {
+      case 5: case 10: case 12: case 16: return true;
+      default: break;
+    }
+  if (K % 256 == 0 && K / 256 <= 16)
+    switch (K / 256) {
+      case 10: case 16: return true;
+      default: break;
+    }
+  return false;
+}
+
 template <bool GATE_UP>
 static int launch_moe_gemm(const uint16_t* x, const uint16_t* w, const int32_t* offsets, const int32_t* pair_token,
                            uint16_t* y, int N, int K, int E, hipStream_t st) {
@@ -272,6 +293,15 @@ static int launch_moe_gemm(const uint16_t* x, const uint16_t* w, const int32_t* 
 }
 
 }  // namespace mi
+
+// MI_OK if mi_moe_gate_up / mi_moe_down take an expert of [2 * inter][hidden] / [hidden][inter] (inter = this rank's
+// share of moe_intermediate_size): asked before the model is built, so that an unsupported width is a message at
+// start-up and not MI_EUNSUPPORTED inside warm-up or graph capture
+extern "C" int mi_moe_shapes_supported(int hidden, int inter) {
+  if (hidden <= 0 || inter <= 0) return MI_EINVAL;
+  if (hidden % 64 || inter % 64 || hidden % 16) return MI_EUNSUPPORTED;
+  return mi::moe_k_supported(hidden) && mi::moe_k_supported(inter) ? MI_OK : MI_EUNSUPPORTED;
+}
 
 using namespace mi;
 

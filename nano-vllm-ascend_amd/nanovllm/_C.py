@@ -102,6 +102,7 @@ _SIGNATURES = {
     "mi_pack_weight_rows4": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_rows4": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
+    "mi_moe_shapes_supported": (c_int, [c_int, c_int]),
     "mi_mlp_half_fused": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk_warm": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, c_size_t, c_int, _p,
                                            c_size_t, c_int, _p]),

@@ -166,6 +166,16 @@ class ModelRunner:
                                       "GQA group sizes 1, 2, 4, 8 and 16")
         if hq % self.world_size or hkv % self.world_size:
             raise ValueError(f"tensor_parallel_size {self.world_size} does not divide {hq} query / {hkv} kv heads")
+        if getattr(hf, "num_experts", 0) and getattr(hf, "moe_intermediate_size", 0):
+            from nanovllm._C import lib
+
+            inter = hf.moe_intermediate_size
+            if inter % self.world_size:
+                raise ValueError(f"tensor_parallel_size {self.world_size} does not divide moe_intermediate_size {inter}")
+            if lib.mi_moe_shapes_supported(hf.hidden_size, inter // self.world_size) != 0:
+                raise NotImplementedError(
+                    f"MoE experts of hidden {hf.hidden_size} x intermediate {inter // self.world_size} per rank: the "
+                    "grouped expert GEMMs (csrc/moe.hip) have no instantiation for these contraction lengths")
 
     # ------------------------------------------------------------------ lifecycle / RPC
     def exit(self):

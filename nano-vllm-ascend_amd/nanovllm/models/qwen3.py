@@ -10,6 +10,7 @@ mi_qknorm_rope_store, whose rounding points are identical (tests require equal b
 from __future__ import annotations
 
 import os
+import warnings
 
 import torch
 from torch import nn
@@ -37,6 +38,8 @@ def rope_theta_of(config) -> float:
 
 
 class Qwen3Attention(nn.Module):
+    _warned_rope_scaling = False
+
     def __init__(self, hidden_size: int, num_heads: int, num_kv_heads: int, max_position: int = 4096 * 32,
                  head_dim: int | None = None, rms_norm_eps: float = 1e-06, qkv_bias: bool = False,
                  rope_theta: float = 10000, rope_scaling: tuple | None = None, fused: bool = True,
@@ -60,6 +63,13 @@ class Qwen3Attention(nn.Module):
 
         self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=qkv_bias)
         self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias)
+        if rope_scaling is not None and not Qwen3Attention._warned_rope_scaling:
+            # the reference hands rope_scaling to get_rope, which asserts it away or ignores it
+            # (rotary_embedding.py:52-69); a checkpoint with scaled RoPE (Llama-3.1 "llama3" type) runs with the
+            # UNscaled table there and here - logits differ from HF's beyond the original context length
+            Qwen3Attention._warned_rope_scaling = True
+            warnings.warn(f"rope_scaling={rope_scaling!r} is ignored (as in the reference): positions use the plain "
+                          f"RoPE table with base {rope_theta}", stacklevel=2)
         self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim, max_position=max_position,
                                    base=rope_theta)
         self.attn = Attention(self.num_heads, self.head_dim, None, self.num_kv_heads)
@@ -144,6 +154,7 @@ class Qwen3DecoderLayer(nn.Module):
         """attn_overrides / mlp_bias: the Llama wiring (models/llama.py) of the same layer."""
         super().__init__()
         mlp_bias = attn_overrides.pop("mlp_bias", False)
+        build_mlp = attn_overrides.pop("build_mlp", True)  # False: the subclass installs its own block (sparse MoE)
         attn_kw = dict(
             hidden_size=config.hidden_size,
             num_heads=config.num_attention_heads,
@@ -158,7 +169,8 @@ class Qwen3DecoderLayer(nn.Module):
         )
         attn_kw.update(attn_overrides)
         self.self_attn = Qwen3Attention(**attn_kw)
-        self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act, bias=mlp_bias)
+        if build_mlp:
+            self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act, bias=mlp_bias)
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
@@ -174,12 +186,14 @@ class Qwen3DecoderLayer(nn.Module):
 
 
 class Qwen3Model(nn.Module):
-    def __init__(self, config, fused: bool = True, **layer_overrides) -> None:
+    def __init__(self, config, fused: bool = True, layer_factory=None, **layer_overrides) -> None:
+        """layer_factory(layer_idx) -> decoder layer: models whose layers differ (Qwen3-MoE) build ONLY their own
+        layers - no dense stack is allocated first and thrown away."""
         super().__init__()
         self.fused = fused
         self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
-        self.layers = nn.ModuleList([Qwen3DecoderLayer(config, fused, **layer_overrides)
-                                     for _ in range(config.num_hidden_layers)])
+        make = layer_factory or (lambda i: Qwen3DecoderLayer(config, fused, **layer_overrides))
+        self.layers = nn.ModuleList([make(i) for i in range(config.num_hidden_layers)])
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
@@ -331,9 +345,9 @@ class Qwen3ForCausalLM(nn.Module):
         "up_proj": ("gate_up_proj", 1),
     }
 
-    def __init__(self, config, fused: bool = True, **layer_overrides) -> None:
+    def __init__(self, config, fused: bool = True, layer_factory=None, **layer_overrides) -> None:
         super().__init__()
-        self.model = Qwen3Model(config, fused, **layer_overrides)
+        self.model = Qwen3Model(config, fused, layer_factory, **layer_overrides)
         self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
         if getattr(config, "tie_word_embeddings", False):
             self.lm_head.weight.data = self.model.embed_tokens.weight.data

@@ -11,13 +11,15 @@ MergedColumnParallelLinear / RowParallelLinear experts do (:104-115); the router
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 from torch import nn
 
 from nanovllm import ops
 from nanovllm.layers.linear import linear_forward
 from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
-from nanovllm.models.qwen3 import Qwen3DecoderLayer, Qwen3ForCausalLM, Qwen3MLP
+from nanovllm.models.qwen3 import Qwen3DecoderLayer, Qwen3ForCausalLM
 
 
 class _ExpertProj(nn.Module):
@@ -84,17 +86,21 @@ class Qwen3MoeSparseMoeBlock(nn.Module):
 
 class Qwen3MoeDecoderLayer(Qwen3DecoderLayer):
     def __init__(self, config, layer_idx: int, fused: bool = True) -> None:
-        super().__init__(config, fused, qk_norm=True, qkv_bias=getattr(config, "attention_bias", False))
         sparse = (layer_idx not in (getattr(config, "mlp_only_layers", None) or [])
                   and config.num_experts > 0 and (layer_idx + 1) % config.decoder_sparse_step == 0)  # :208-212
+        # a sparse layer never allocates the dense MLP of config.intermediate_size
+        super().__init__(config, fused, qk_norm=True, qkv_bias=getattr(config, "attention_bias", False),
+                         build_mlp=not sparse)
         if sparse:
             self.mlp = Qwen3MoeSparseMoeBlock(config)
-        else:
-            self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act)
 
 
 class Qwen3MoeForCausalLM(Qwen3ForCausalLM):
     def __init__(self, config, fused: bool = True) -> None:
-        super().__init__(config, fused)
-        self.model.layers = nn.ModuleList([Qwen3MoeDecoderLayer(config, i, fused)
-                                           for i in range(config.num_hidden_layers)])
+        if getattr(config, "norm_topk_prob", True) is False:
+            # the reference's block renormalises the top-k weights unconditionally (qwen3_moe.py:156-158) and so does
+            # mi_moe_route: a checkpoint trained with norm_topk_prob = false gets logits that differ from HF's
+            warnings.warn("norm_topk_prob=False is ignored (as in the reference): the top-k router weights are "
+                          "renormalised to sum to one", stacklevel=2)
+        # only the MoE layers are built (no dense Qwen3 stack first)
+        super().__init__(config, fused, layer_factory=lambda i: Qwen3MoeDecoderLayer(config, i, fused))

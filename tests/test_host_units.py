@@ -367,6 +367,35 @@ def test_safetensors_checkpoint_lands_in_the_packed_parameters(tmp_path, tied):
     assert torch.equal(model.lm_head.weight, sd["lm_head.weight"])
 
 
+def test_moe_model_builds_only_its_own_layers_and_flags_ignored_config_fields():
+    """models/qwen3_moe.py: a sparse layer allocates no dense MLP (and no dense stack is built and thrown away);
+    config fields the reference ignores - norm_topk_prob = false (qwen3_moe.py:156-158 renormalises always),
+    rope_scaling (rotary_embedding.py:52-69) - are reported, not silently dropped; expert widths without a grouped
+    GEMM instantiation are known before the model is built"""
+    from nanovllm import _C
+    from nanovllm.models import qwen3
+    from nanovllm.models.qwen3_moe import Qwen3MoeForCausalLM, Qwen3MoeSparseMoeBlock
+    from model_configs import TINY_MOE
+
+    built = []
+    orig = qwen3.Qwen3MLP.__init__
+    qwen3.Qwen3MLP.__init__ = lambda self, *a, **k: (built.append(a), orig(self, *a, **k))[1]
+    try:
+        cfg = SimpleNamespace(**dict(TINY_MOE, mlp_only_layers=[1]))
+        with pytest.warns(UserWarning, match="norm_topk_prob"):
+            model = Qwen3MoeForCausalLM(SimpleNamespace(**dict(vars(cfg), norm_topk_prob=False)))
+        assert len(built) == 1  # layer 1 is dense, layer 0 sparse: ONE dense MLP in total
+        assert isinstance(model.model.layers[0].mlp, Qwen3MoeSparseMoeBlock)
+        assert isinstance(model.model.layers[1].mlp, qwen3.Qwen3MLP)
+        qwen3.Qwen3Attention._warned_rope_scaling = False
+        with pytest.warns(UserWarning, match="rope_scaling"):
+            qwen3.Qwen3ForCausalLM(SimpleNamespace(**dict(TINY_MOE, rope_scaling={"rope_type": "llama3", "factor": 8.0})))
+    finally:
+        qwen3.Qwen3MLP.__init__ = orig
+    assert _C.lib.mi_moe_shapes_supported(2048, 768) == 0 and _C.lib.mi_moe_shapes_supported(2048, 192) == 0
+    assert _C.lib.mi_moe_shapes_supported(2048, 96) == -2  # Qwen3-30B-A3B experts at TP 8: no kernel, said at start-up
+
+
 def test_chained_block_hashes_in_one_call_equal_the_per_block_chain():
     import random
     from array import array
