@@ -662,7 +662,8 @@ struct QPrep {
 
 // EARLY (tuning / stress-test variant, mi_paged_attn_prefill_fused_ex): the first two chunks are requested ahead of
 // the Q preparation instead of behind it.
-template <int G, bool SPLIT_P, bool FUSE_Q, bool EARLY = false>
+// PAIR (tuning variant 2): a ring of four buffers and ONE barrier per TWO chunks.
+template <int G, bool SPLIT_P, bool FUSE_Q, bool EARLY = false, bool PAIR = false>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     int n_q_heads, int n_kv_heads, int tpb, int tpb_shift, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
   constexpr int TQ = 32 / G;        // query tokens per wave
   constexpr int TQ_WG = 4 * TQ;     // per workgroup
-  constexpr int NBUF = 3;           // LDS ring: chunk c is computed while c+1 and c+2 are landing
+  constexpr int NBUF = PAIR ? 4 : 3;  // LDS ring: chunk c is computed while c+1 and c+2 are landing
   __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][4][2048];  // [buffer][K0,K1,V0,V1][tile]
 
   // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All query blocks of one
@@ -784,11 +785,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   // (Scores one chunk ahead of the softmax - the eight dependent score MFMAs of chunk c + 1 in the basic block of
   // chunk c's exponentials, a fourth ring buffer - was built and measured in round 3: 145-147 us against 137-139
   // for this form at 16 x 1024 tokens; removed.)
-  for (int c = 0; c < wg_chunks; ++c) {
-    // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
-    // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    issue(c + 2);
+  auto attend = [&](int c) __attribute__((always_inline)) {
     if (c < wave_chunks) {
       const int buf = c % NBUF;
       const uint16_t* kt = &stage[buf][n >> 4][k_off];
@@ -853,6 +850,25 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
             acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(pl[sgm]), acc[db], 0, 0, 0);
         }
       }
+    }
+  };
+  if (PAIR) {
+    for (int c = 0; c < wg_chunks; c += 2) {
+      // this wave's pieces of chunks c and c + 1 (its only requests in flight) have landed; after the barrier
+      // everybody's have, and everybody is done with chunks c - 2 and c - 1, whose buffers c + 2 and c + 3 re-use
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      issue(c + 2);
+      issue(c + 3);
+      attend(c);
+      if (c + 1 < wg_chunks) attend(c + 1);
+    }
+  } else {
+    for (int c = 0; c < wg_chunks; ++c) {
+      // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
+      // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      issue(c + 2);
+      attend(c);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two padding loads
@@ -1024,7 +1040,8 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
                         const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
                         const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs, int max_seqlen_q,
                         mi_bf16* out, int n_q_heads, int n_kv_heads, int head_dim, int block_size, float scale,
-                        mi_stream stream, bool early = false) {
+                        mi_stream stream, int variant = 0) {
+  const bool early = variant == 1, pair = variant == 2;
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -1045,7 +1062,11 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
 #define LAUNCH_PRE(GG)                                                                                          \
   do {                                                                                                          \
-    if (prep && early)                                                                                          \
+    if (prep && pair)                                                                                           \
+      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true, false, true>), grid, dim3(256), 0, st, q, \
+                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
+                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
+    else if (prep && early)                                                                                     \
       hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true, true>), grid, dim3(256), 0, st, q,        \
                          q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
                          n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
@@ -1091,7 +1112,7 @@ extern "C" int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_s
 }
 
 // tuning / stress-test form of mi_paged_attn_prefill_fused: variant 1 requests the first two K/V chunks ahead of the
-// Q preparation (tests/test_kernels_gpu.py::test_prefill_attention_chunk_pipeline_stress)
+// Q preparation, variant 2 synchronises the workgroup once per two chunks (tests/test_kernels_gpu.py::test_prefill_attention_chunk_pipeline_stress)
 extern "C" int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
                                               const int64_t* positions, const float* cos_sin, const mi_bf16* k_cache,
                                               const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
@@ -1099,8 +1120,8 @@ extern "C" int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_ro
                                               int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
                                               int head_dim, int block_size, float scale, int variant, mi_stream stream) {
   if (!positions || !cos_sin || !aligned16(cos_sin) || (q_w && !aligned16(q_w))) return MI_EINVAL;
-  if (variant != 0 && variant != 1) return MI_EUNSUPPORTED;
+  if (variant < 0 || variant > 2) return MI_EUNSUPPORTED;
   const QPrep prep{q_w, positions, cos_sin, eps};
   return prefill_impl(qkv, qkv_row_stride, &prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
-                      n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream, variant == 1);
+                      n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream, variant);
 }

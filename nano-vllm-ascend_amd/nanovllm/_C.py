@@ -207,7 +207,9 @@ def xxh64_chain_blocks(token_ids, n_blocks: int, block_size: int, prefix: int = 
 
     if n_blocks <= 0:
         return []
-    toks = array("q", token_ids[: n_blocks * block_size])
+    # an array('q') (Sequence.ids_array) is hashed in place, a list is converted first
+    toks = token_ids if isinstance(token_ids, array) else array("q", token_ids[: n_blocks * block_size])
+    assert len(toks) >= n_blocks * block_size
     out = (c_uint64 * n_blocks)()
     addr, _ = toks.buffer_info()
     check(lib.mi_xxh64_chain_blocks(addr, n_blocks, block_size, int(prefix != -1),

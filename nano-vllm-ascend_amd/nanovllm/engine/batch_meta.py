@@ -78,7 +78,7 @@ def prefill_meta(seqs: list[Sequence], block_size: int, skip_cached: bool = Fals
     for s, a, n, k in zip(seqs, cu[:-1], lens, skip):
         a, n, k = int(a), int(n), int(k)
         w = within[k:k + n]
-        ids[a:a + n] = s.token_ids[k:k + n] if k else s.token_ids
+        ids[a:a + n] = np.frombuffer(s.ids_array(), dtype=np.int64)[k:k + n]
         pos[a:a + n] = w
         if s.block_table:
             table = np.asarray(s.block_table[: s.num_blocks], dtype=np.int64)

@@ -82,40 +82,50 @@ class BlockManager:
         assert not seq.block_table
         seq.table_gen = getattr(seq, "table_gen", 0) + 1  # a fresh table: cached device rows of it are stale
         bs, lookup = self.block_size, self.hash_to_block_id
-        missed, hits = False, 0
-        hashes = xxh64_chain_blocks(seq.token_ids, len(seq) // bs, bs)  # the whole chain in one C call
+        n_blocks, n_full = seq.num_blocks, len(seq) // bs
+        hashes = xxh64_chain_blocks(seq.ids_array(), n_full, bs)  # the whole chain in one C call
         blocks, free, used, table = self.blocks, self.free_block_ids, self.used_block_ids, seq.block_table
-        guard = self.non_cache_token_ids
-        for i in range(seq.num_blocks):
-            toks = seq.block(i)
-            if guard and not guard.isdisjoint(toks):
-                missed = True
-            chain = hashes[i] if len(toks) == bs else _NO_HASH
-            if not missed:
-                hit_id = lookup.get(chain, -1)
-                if hit_id == -1 or blocks[hit_id].token_ids != toks:
-                    missed = True
-            if missed:  # take the head of the free list (same as _take(free[0]), without the search)
-                hit_id = free.popleft()
+        tokens, guard = seq.token_ids, self.non_cache_token_ids
+        # leading run of cache hits (block_manager.py:65-88: after the first miss every later block misses)
+        hits = 0
+        while hits < n_full:
+            chain = hashes[hits]
+            hit_id = lookup.get(chain, -1)
+            if hit_id == -1:
+                break
+            toks = tokens[hits * bs:(hits + 1) * bs]
+            if blocks[hit_id].token_ids != toks or (guard and not guard.isdisjoint(toks)):
+                break
+            seq.num_cached_tokens += bs  # reporting counter: only ever grows (block_manager.py:79)
+            if hit_id in used:
                 blk = blocks[hit_id]
-                assert blk.ref_count == 0
-                blk.ref_count, blk.hash, blk.token_ids = 1, _NO_HASH, []
-                used.add(hit_id)
-            else:
-                seq.num_cached_tokens += bs  # reporting counter: only ever grows (block_manager.py:79)
-                hits += 1
-                if hit_id in used:
-                    blk = blocks[hit_id]
-                    blk.ref_count += 1
-                else:  # freed but not yet recycled: revive it
-                    blk = self._take(hit_id)
-            if chain != _NO_HASH:
-                blk.hash, blk.token_ids = chain, toks
-                lookup[chain] = hit_id
+                blk.ref_count += 1
+            else:  # freed but not yet recycled: revive it
+                blk = self._take(hit_id)
+            blk.hash, blk.token_ids = chain, toks
+            lookup[chain] = hit_id
             table.append(hit_id)
-        # hits are always a leading run (after the first miss everything misses), and a hit block
-        # holds valid KV rows by the time this prefill's attention reads it: it was written by an
-        # earlier step, or is written earlier in the same forward pass by the sequence that owns it
+            hits += 1
+        # everything behind it takes the head of the free list, in block order (same as _take(free[0]) per block,
+        # without the search); full blocks are registered under their chained hash
+        ids = [free.popleft() for _ in range(n_blocks - hits)]
+        used.update(ids)
+        table.extend(ids)
+        k = hits
+        for bid in ids:
+            blk = blocks[bid]
+            assert blk.ref_count == 0
+            blk.ref_count = 1
+            if k < n_full:
+                chain = hashes[k]
+                blk.hash, blk.token_ids = chain, tokens[k * bs:(k + 1) * bs]
+                lookup[chain] = bid
+            else:
+                blk.hash, blk.token_ids = _NO_HASH, []
+            k += 1
+        # hits are always a leading run, and a hit block holds valid KV rows by the time this prefill's attention
+        # reads it: it was written by an earlier step, or is written earlier in the same forward pass by the
+        # sequence that owns it
         seq.num_prefix_tokens = hits * bs
 
     def deallocate(self, seq: Sequence) -> None:

@@ -32,7 +32,7 @@ class Sequence:
     __slots__ = ("block_size", "seq_id", "request_id", "status", "token_ids", "last_token", "num_tokens",
                  "num_prompt_tokens", "num_cached_tokens", "block_table", "temperature", "max_tokens",
                  "ignore_eos", "greedy", "finish_reason", "arrival_time", "first_token_time", "table_gen", "num_prefix_tokens",
-                 "token_pending")
+                 "token_pending", "_prompt_q")
 
     def __init__(self, token_ids: list[int], sampling_params: SamplingParams | None = None,
                  request_id: str | None = None, block_size: int = 256, **_ignored_multimodal):
@@ -56,6 +56,7 @@ class Sequence:
         self.num_prefix_tokens = 0  # leading tokens whose KV rows the current block table already holds (cache hits)
         self.token_pending = False  # the last entry of token_ids stands for a token still on the device (lookahead)
         self.table_gen = 0  # bumped every time the block table is rebuilt (allocate after a preemption)
+        self._prompt_q = None  # the prompt as array('q'), built on first use (hashing and prefill staging read it)
 
     # -- container protocol ------------------------------------------------------------------
     def __len__(self) -> int:
@@ -96,6 +97,20 @@ class Sequence:
     @property
     def last_block_num_tokens(self) -> int:
         return self.num_tokens - (self.num_blocks - 1) * self.block_size
+
+    def ids_array(self):
+        """All token ids as a contiguous int64 array (array('q')).  The prompt part is converted once per sequence
+        (a 1024-token list costs ~20 us per conversion, and a prefill step needs it twice: block hashes and the
+        staged input ids); the completion part - non-empty only when a preempted sequence is prefilled again - is
+        converted on every call."""
+        from array import array
+
+        pq = getattr(self, "_prompt_q", None)
+        if pq is None:
+            pq = self._prompt_q = array("q", self.token_ids[: self.num_prompt_tokens])
+        if self.num_tokens == self.num_prompt_tokens:
+            return pq
+        return pq + array("q", self.token_ids[self.num_prompt_tokens:])
 
     def block(self, i: int) -> list[int]:
         assert 0 <= i < self.num_blocks

@@ -63,7 +63,9 @@ class Qwen3Attention(nn.Module):
 
         self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=qkv_bias)
         self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias)
-        if rope_scaling is not None and not Qwen3Attention._warned_rope_scaling:
+        rope_type = (rope_scaling.get("rope_type") or rope_scaling.get("type")) if isinstance(rope_scaling, dict) \
+            else rope_scaling
+        if rope_type not in (None, "default") and not Qwen3Attention._warned_rope_scaling:
             # the reference hands rope_scaling to get_rope, which asserts it away or ignores it
             # (rotary_embedding.py:52-69); a checkpoint with scaled RoPE (Llama-3.1 "llama3" type) runs with the
             # UNscaled table there and here - logits differ from HF's beyond the original context length

@@ -724,8 +724,10 @@ def test_prefill_attention_chunk_pipeline_stress(ops):
     ref, _ = run(straight, 0, 3)
     late, (kc, vc, bt) = run(scrambled, 0, 100)
     early, _ = run(scrambled, 1, 100)
+    paired, _ = run(scrambled, 2, 100)
     assert torch.equal(late.view(torch.int16), ref.view(torch.int16))    # paging invariance
     assert torch.equal(early.view(torch.int16), late.view(torch.int16))  # request order does not matter
+    assert torch.equal(paired.view(torch.int16), late.view(torch.int16))  # nor does one barrier per two chunks
     # the fp32 oracle on the last 40 query rows of two sequences (full causal context)
     qo = oracle.apply_rope(pos.cpu(), oracle.rms_norm(qkv[:, : hq * 128].cpu().view(T, hq, 128), qw.cpu(), 1e-6), table.cpu())
     kc_l, vc_l = to_logical(kc.cpu(), bs, False), to_logical(vc.cpu(), bs, True)

@@ -82,9 +82,11 @@ def prefill_attention_order():
     out = torch.empty(n * T, hq * 128, device=DEV).bfloat16()
     cu = (torch.arange(n + 1, dtype=torch.int32) * T).to(DEV)
     kvl = torch.full((n,), T, dtype=torch.int32, device=DEV)
-    res = {"requests behind the Q preparation (default)": [], "requests ahead of it (variant 1)": []}
+    res = {"requests behind the Q preparation (default)": [], "requests ahead of it (variant 1)": [],
+           "one barrier per two chunks, ring of four (variant 2)": []}
     for rnd in range(4):
-        for name, v in (("requests behind the Q preparation (default)", None), ("requests ahead of it (variant 1)", 1)):
+        for name, v in (("requests behind the Q preparation (default)", None), ("requests ahead of it (variant 1)", 1),
+                        ("one barrier per two chunks, ring of four (variant 2)", 2)):
             t = timeit(lambda l: ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[l], vc[l], tables, cu, kvl, T,
                                                               hq, hkv, bs, 128 ** -0.5, out=out, variant=v), L)
             res[name].append(round(t * 1e6, 1))
