@@ -101,7 +101,7 @@ def cpu_baseline(sample_steps: int = 5):
     dt = time.perf_counter() - t0
     return {"value": BATCH * sample_steps / dt, "unit": "tokens/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{sample_steps} decode step(s) of bs={BATCH} ctx={PROMPT_LEN} "
-            f"(oracle/ CPU port, random KV contents), {dt:.1f} s"}
+            f"(oracle/ CPU port, random KV contents), {dt:.1f} s; threads capped at 32 of {cores} host cores"}
 
 
 def attention_roofline(llm, seqs, iters: int = 20):
@@ -195,6 +195,8 @@ def _attention_roofline(llm, seqs, iters):
     return {"kernel": "paged_attn_decode_kernel" + (" (fused step: q/k-norm + RoPE + KV store + attention)" if fused else ""),
             "bound": "hbm", "achieved": algo / dur / 1e9,
             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / dur / HBM_PEAK, "traffic": traffic,
+            "traffic_kind": "derived: this run's algorithmic bytes x the PMC-measured traffic ratio of the committed "
+                            "profile (not a counter of this run)",
             "traffic_source": traffic_src,
             "bytes_per_launch": algo, "avg_launch_us": dur * 1e6, "launches_timed": iters * len(attn_mods)}
 
