@@ -55,7 +55,7 @@ enum {
   MI_ERUNTIME      = -5  /* a HIP runtime call (allocation, IPC) failed           */
 };
 
-#define MI_HEAD_DIM        128  /* the only head_dim compiled (all Qwen3 sizes)   */
+#define MI_HEAD_DIM        128  /* head_dim of the fragment-native kernels (all Qwen3 sizes); 64: mi_*_plain */
 #define MI_KV_TILE_TOKENS  16
 #define MI_KV_TILE_ELEMS   2048
 
@@ -333,6 +333,37 @@ int mi_mlp_half_fused(const float* partials_in, const mi_bf16* residual, const m
                       mi_bf16* residual_out, mi_bf16* xn_scratch, mi_bf16* act_scratch,
                       float* partials_out, uint32_t* sync_words, int rows, int hidden, int intermediate,
                       mi_stream stream);
+
+/* ---- plain-layout attention (csrc/attn_plain.hip) -------------------------
+ * The same operators (attention.py:22-93, rotary_embedding.py:6-14) for the head geometries the fragment-native
+ * kernels above are not built for: head_dim 64 and GQA groups that are not a power of two (Llama-3.2-1B, Qwen2-0.5B,
+ * Qwen2.5-7B - models the reference's README benchmarks).  Cache layout of this family:
+ *     k_cache / v_cache  [num_blocks][n_kv_heads][block_size][head_dim]  bf16, any block_size.
+ * head_dim 64 or 128, n_q_heads / n_kv_heads <= 8 (any integer). */
+/* _npu_reshape_and_cache / scatter_update_ (attention.py:25-35): slots flat int32 (slots_2d = 0; negative: skip)
+ * or [n_tokens][2] (block, offset) pairs (slots_2d = 1). */
+int mi_kv_store_plain(const mi_bf16* k, const mi_bf16* v, int64_t k_row_stride, int64_t v_row_stride,
+                      mi_bf16* k_cache, mi_bf16* v_cache, const int32_t* slots, int slots_2d, int n_tokens,
+                      int n_kv_heads, int head_dim, int block_size, mi_stream stream);
+/* apply_rotary_emb (rotary_embedding.py:6-14,37-47) for any head_dim % 16 == 0: q [T][Hq][D] and k [T][Hkv][D]
+ * rows of the given token strides -> contiguous q_out / k_out; cos_sin [max_pos][D] fp32 = (cos | sin). */
+int mi_rope_plain(const int64_t* positions, const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k,
+                  int64_t k_row_stride, const float* cos_sin, mi_bf16* q_out, mi_bf16* k_out, int n_tokens,
+                  int n_q_heads, int n_kv_heads, int head_dim, mi_stream stream);
+/* decode attention (attention.py:63-93): out [batch][n_q_heads * head_dim]; workspace of
+ * mi_paged_attn_decode_plain_workspace bytes (context splits of small batches). */
+size_t mi_paged_attn_decode_plain_workspace(int batch, int n_q_heads, int head_dim);
+int mi_paged_attn_decode_plain(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                               const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                               const int32_t* context_lens, mi_bf16* out, void* workspace, size_t ws_bytes,
+                               int batch, int n_q_heads, int n_kv_heads, int head_dim, int block_size,
+                               float scale, mi_stream stream);
+/* causal prefill attention through the block table (attention.py:46-59; kv_lens >= query lengths: cached prefixes) */
+int mi_paged_attn_prefill_plain(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
+                                const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
+                                int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads, int head_dim,
+                                int block_size, float scale, mi_stream stream);
 
 /* ---- embedding / head (reference: layers/embed_head.py) ------------------- */
 /* VocabParallelEmbedding.forward (embed_head.py:34-42): out[t] = w[ids[t]-vocab_start]

@@ -635,6 +635,7 @@ static int pick_waves(const GemmArgs& a) {
         case 4: return try_waves<MT, RT, 4, WF, EPI>(a);
         case 5: return try_waves<MT, RT, 5, WF, EPI>(a);
         case 6: return try_waves<MT, RT, 6, WF, EPI>(a);
+        case 7: return try_waves<MT, RT, 7, WF, EPI>(a);  // K = 7 * 2^n * 64: hidden 896 (Qwen2-0.5B), 448
         case 8: return try_waves<MT, RT, 8, WF, EPI>(a);
         case 10: return try_waves<MT, RT, 10, WF, EPI>(a);
         case 12: return try_waves<MT, RT, 12, WF, EPI>(a);

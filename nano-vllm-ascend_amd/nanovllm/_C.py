@@ -103,6 +103,13 @@ _SIGNATURES = {
     "mi_gemm_bf16_rows4": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_moe_shapes_supported": (c_int, [c_int, c_int]),
+    "mi_kv_store_plain": (c_int, [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p]),
+    "mi_rope_plain": (c_int, [_p, _p, c_int64, _p, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_paged_attn_decode_plain_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "mi_paged_attn_decode_plain": (c_int, [_p, c_int64, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int,
+                                           c_int, c_int, c_float, _p]),
+    "mi_paged_attn_prefill_plain": (c_int, [_p, c_int64, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int,
+                                            c_int, c_int, c_float, _p]),
     "mi_mlp_half_fused": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk_warm": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, c_size_t, c_int, _p,
                                            c_size_t, c_int, _p]),

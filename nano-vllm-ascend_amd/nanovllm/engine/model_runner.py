@@ -158,12 +158,15 @@ class ModelRunner:
         hf = getattr(self.hf_config, "text_config", self.hf_config)
         head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
         hq, hkv = hf.num_attention_heads, hf.num_key_value_heads
-        if head_dim != 128:
-            raise NotImplementedError(f"head_dim {head_dim}: the paged-attention kernels are built for head_dim 128 "
-                                      "(all Qwen3 sizes)")
-        if hq % hkv or hq // hkv not in (1, 2, 4, 8, 16):
-            raise NotImplementedError(f"{hq} query heads over {hkv} kv heads: the attention kernels are built for "
-                                      "GQA group sizes 1, 2, 4, 8 and 16")
+        from nanovllm import ops
+
+        if hq % hkv:
+            raise NotImplementedError(f"{hq} query heads over {hkv} kv heads: not a whole GQA group size")
+        if ops.attention_is_plain(hq, hkv, head_dim) and not ops.attention_plain_supported(hq, hkv, head_dim):
+            raise NotImplementedError(
+                f"head_dim {head_dim} with {hq} query heads over {hkv} kv heads: the fragment-native attention kernels "
+                "take head_dim 128 with GQA groups 1, 2, 4, 8, 16; the plain-layout kernels head_dim 64 or 128 with "
+                "groups up to 8")
         if hq % self.world_size or hkv % self.world_size:
             raise ValueError(f"tensor_parallel_size {self.world_size} does not divide {hq} query / {hkv} kv heads")
         if getattr(hf, "num_experts", 0) and getattr(hf, "moe_intermediate_size", 0):
@@ -253,8 +256,14 @@ class ModelRunner:
         # a tile's K and V copies, which one wavefront loads together) off large powers of two: with
         # 4096 blocks K and V of a tile shared all low 27 address bits and the attention kernel lost ~4 %
         alloc_blocks = cfg.num_kvcache_blocks | 1
-        self.kv_cache = torch.zeros((2, layers, alloc_blocks, n_kv, self.block_size // 16, 2048),
-                                    dtype=torch.bfloat16, device=self.device)
+        from nanovllm import ops
+
+        hq = hf.num_attention_heads // self.world_size
+        if ops.attention_is_plain(hq, n_kv, head_dim):  # head_dim 64 / odd GQA groups: [blocks, kv heads, block, head_dim]
+            shape = ops.kv_cache_shape_plain(alloc_blocks, n_kv, self.block_size, head_dim)
+        else:
+            shape = ops.kv_cache_shape(alloc_blocks, n_kv, self.block_size)
+        self.kv_cache = torch.zeros((2, layers, *shape), dtype=torch.bfloat16, device=self.device)
         layer_id = 0
         for module in self.model.modules():
             if hasattr(module, "k_cache") and hasattr(module, "v_cache"):

@@ -4,7 +4,9 @@ mi_reshape_and_cache / mi_scatter_update_kv / mi_paged_attn_prefill / mi_paged_a
 Same constructor and forward signature as the reference class; the runner injects
 `k_cache` / `v_cache` into every module that has both attributes
 (model_runner.py:222-229) and the per-step metadata arrives through get_context().
-The caches use the fragment-native layout of include/mi355_nanovllm.h.
+The caches use the fragment-native layout of include/mi355_nanovllm.h - or, for the head geometries those kernels
+are not built for (head_dim 64, GQA groups that are not a power of two: `self.plain`), the plain
+[blocks, kv heads, block, head_dim] layout and the mi_*_plain kernels (csrc/attn_plain.hip).
 """
 from __future__ import annotations
 
@@ -25,10 +27,13 @@ class Attention(nn.Module):
         self.scale = scaling if scaling is not None else 1.0 / (head_dim ** 0.5)
         self.k_cache = torch.tensor([])
         self.v_cache = torch.tensor([])
+        self.plain = ops.attention_is_plain(num_heads, num_kv_heads, head_dim)
 
     def _store_kvcache(self, k: torch.Tensor, v: torch.Tensor, context) -> None:
         """attention.py:22-35: flat slots in prefill, [block, offset] pairs in decode."""
-        if context.slot_mapping.dim() == 2:
+        if self.plain:
+            ops.kv_store_plain(k, v, self.k_cache, self.v_cache, context.slot_mapping, self.num_kv_heads, self.block_size)
+        elif context.slot_mapping.dim() == 2:
             ops.scatter_update_kv(k, v, self.k_cache, self.v_cache, context.slot_mapping, self.num_kv_heads,
                                   self.block_size)
         else:
@@ -47,8 +52,15 @@ class Attention(nn.Module):
             kv_lens = context.kv_lens
             if kv_lens is None:
                 kv_lens = (context.cu_seqlens_k[1:] - context.cu_seqlens_k[:-1]).contiguous()
+            if self.plain:
+                return ops.paged_attn_prefill_plain(q, self.k_cache, self.v_cache, context.block_tables,
+                                                    context.cu_seqlens_q, kv_lens, context.max_seqlen_q, self.num_heads,
+                                                    self.num_kv_heads, self.block_size, self.scale)
             return ops.paged_attn_prefill(q, self.k_cache, self.v_cache, context.block_tables,
                                           context.cu_seqlens_q, kv_lens, context.max_seqlen_q, self.num_heads,
                                           self.num_kv_heads, self.block_size, self.scale)
+        if self.plain:
+            return ops.paged_attn_decode_plain(q, self.k_cache, self.v_cache, context.block_tables, context.context_lens,
+                                               self.num_heads, self.num_kv_heads, self.block_size, self.scale)
         return ops.paged_attn_decode(q, self.k_cache, self.v_cache, context.block_tables, context.context_lens,
                                      self.num_heads, self.num_kv_heads, self.block_size, self.scale)

@@ -81,19 +81,24 @@ class Qwen3Attention(nn.Module):
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
-        if self.fused and self.attn.k_cache.numel() > 0:
+        if self.fused and self.attn.k_cache.numel() > 0 and not self.attn.plain:
             o = self._attend_fused(positions, qkv)
         else:
-            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-            q = q.view(-1, self.num_heads, self.head_dim)
-            k = k.view(-1, self.num_kv_heads, self.head_dim)
-            v = v.view(-1, self.num_kv_heads, self.head_dim)
-            if self.qk_norm:
-                q = self.q_norm(q)
-                k = self.k_norm(k)
-            q, k = self.rotary_emb(positions, q, k)
-            o = self.attn(q, k, v)
+            o = self._attend_unfused(positions, qkv)
         return self.o_proj(o.flatten(1, -1))
+
+    def _attend_unfused(self, positions: torch.Tensor, qkv: torch.Tensor) -> torch.Tensor:
+        """The reference's operator sequence (qwen3.py:79-90): split, per-head q/k norm, RoPE, store + attention - one
+        launch each.  The path of the plain-layout head geometries (head_dim 64, GQA 7:1)."""
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        q = q.view(-1, self.num_heads, self.head_dim)
+        k = k.view(-1, self.num_kv_heads, self.head_dim)
+        v = v.view(-1, self.num_kv_heads, self.head_dim)
+        if self.qk_norm:
+            q = self.q_norm(q)
+            k = self.k_norm(k)
+        q, k = self.rotary_emb(positions, q, k)
+        return self.attn(q, k, v)
 
     def _attend_fused(self, positions: torch.Tensor, qkv: torch.Tensor) -> torch.Tensor:
         ctx, attn = get_context(), self.attn
@@ -259,6 +264,8 @@ class Qwen3Model(nn.Module):
                       and os.environ.get("MI355_XGMI_FUSED", "1") != "0")
 
         def attend(attn, qkv):
+            if attn.attn.plain:
+                return attn._attend_unfused(positions, qkv).flatten(1, -1)
             if not fuse_attn:
                 return attn._attend_fused(positions, qkv)
             a, rope = attn.attn, attn.rotary_emb

@@ -228,13 +228,96 @@ def add_rmsnorm(x, residual, w, eps: float, out=None, residual_out=None):
 
 
 # --------------------------------------------------------------------------- rope (+ fused)
+# ---- plain-layout attention family (csrc/attn_plain.hip): head_dim 64, GQA groups that are not a power of two ----
+def attention_is_plain(n_q_heads: int, n_kv_heads: int, head_dim: int) -> bool:
+    """True: this head geometry runs on the mi_*_plain kernels and the [blocks, kv heads, block, head_dim] cache."""
+    return head_dim != HEAD_DIM or n_q_heads % n_kv_heads != 0 or (n_q_heads // n_kv_heads) not in (1, 2, 4, 8, 16)
+
+
+def attention_plain_supported(n_q_heads: int, n_kv_heads: int, head_dim: int) -> bool:
+    return head_dim in (64, 128) and n_q_heads % n_kv_heads == 0 and n_q_heads // n_kv_heads <= 8
+
+
+def kv_cache_shape_plain(num_blocks: int, n_kv_heads: int, block_size: int, head_dim: int) -> tuple[int, int, int, int]:
+    return (num_blocks, n_kv_heads, block_size, head_dim)
+
+
+def kv_store_plain(k, v, k_cache, v_cache, slots, n_kv_heads: int, block_size: int) -> None:
+    """k, v: [T, Hkv, D] (token stride free); slots: flat int32 [T] or [T, 2] (block, offset) pairs."""
+    require_gpu(k, v, k_cache, v_cache, slots)
+    _bf16(k, v, k_cache, v_cache)
+    T, D = k.shape[0], k_cache.shape[-1]
+    k3 = k.view(T, n_kv_heads, D) if k.dim() == 2 else k
+    v3 = v.view(T, n_kv_heads, D) if v.dim() == 2 else v
+    assert k3.stride(2) == 1 and k3.stride(1) == D and v3.stride(2) == 1 and v3.stride(1) == D
+    assert slots.dtype == torch.int32 and slots.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    check(lib.mi_kv_store_plain(ptr(k3), ptr(v3), k3.stride(0), v3.stride(0), ptr(k_cache), ptr(v_cache), ptr(slots),
+                                int(slots.dim() == 2), T, n_kv_heads, D, block_size, stream()), "mi_kv_store_plain")
+
+
+_PLAIN_WS: dict[torch.device, torch.Tensor] = {}
+
+
+def paged_attn_decode_plain(q, k_cache, v_cache, block_tables, context_lens, n_q_heads: int, n_kv_heads: int,
+                            block_size: int, scale: float, out=None) -> torch.Tensor:
+    require_gpu(q, k_cache, v_cache, block_tables, context_lens)
+    _bf16(q, k_cache, v_cache)
+    batch, D = q.shape[0], k_cache.shape[-1]
+    q2 = q.view(batch, -1) if q.dim() == 3 else q
+    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * D and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
+    if out is None:
+        out = torch.empty((batch, n_q_heads * D), dtype=_BF16, device=q.device)
+    need = lib.mi_paged_attn_decode_plain_workspace(max(batch, 1), n_q_heads, D)
+    ws = _PLAIN_WS.get(q.device)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _GEMM_WS_RETIRED.append(ws)  # a captured graph may hold its address
+        ws = _PLAIN_WS[q.device] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    check(lib.mi_paged_attn_decode_plain(ptr(q2), q2.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                         block_tables.stride(0), ptr(context_lens), ptr(out), ptr(ws), ws.numel(), batch,
+                                         n_q_heads, n_kv_heads, D, block_size, float(scale), stream()),
+          "mi_paged_attn_decode_plain")
+    return out
+
+
+def paged_attn_prefill_plain(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens, max_seqlen_q: int, n_q_heads: int,
+                             n_kv_heads: int, block_size: int, scale: float, out=None) -> torch.Tensor:
+    require_gpu(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
+    _bf16(q, k_cache, v_cache)
+    T, D = q.shape[0], k_cache.shape[-1]
+    q2 = q.view(T, -1) if q.dim() == 3 else q
+    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * D and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert cu_seqlens_q.dtype == torch.int32 and kv_lens.dtype == torch.int32
+    if out is None:
+        out = torch.empty((T, n_q_heads * D), dtype=_BF16, device=q.device)
+    check(lib.mi_paged_attn_prefill_plain(ptr(q2), q2.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                          block_tables.stride(0), ptr(cu_seqlens_q), ptr(kv_lens),
+                                          cu_seqlens_q.numel() - 1, int(max_seqlen_q), ptr(out), n_q_heads, n_kv_heads, D,
+                                          block_size, float(scale), stream()), "mi_paged_attn_prefill_plain")
+    return out
+
+
 def rope(positions, q, k, cos_sin, n_q_heads: int, n_kv_heads: int):
-    """q: [T, Hq, 128] / k: [T, Hkv, 128] views (token stride free) -> contiguous copies."""
+    """q: [T, Hq, D] / k: [T, Hkv, D] views (token stride free) -> contiguous copies (D = 128: mi_rope, else
+    mi_rope_plain)."""
     require_gpu(positions, q, k, cos_sin)
     _bf16(q, k)
     T = q.shape[0]
     assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == T
     assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
+    D = cos_sin.shape[-1]
+    if D != HEAD_DIM:
+        q3 = q.view(T, n_q_heads, D) if q.dim() == 2 else q
+        k3 = k.view(T, n_kv_heads, D) if k.dim() == 2 else k
+        assert q3.stride(2) == 1 and q3.stride(1) == D and k3.stride(2) == 1 and k3.stride(1) == D
+        q_out = torch.empty((T, n_q_heads, D), dtype=_BF16, device=q.device)
+        k_out = torch.empty((T, n_kv_heads, D), dtype=_BF16, device=q.device)
+        check(lib.mi_rope_plain(ptr(positions), ptr(q3), q3.stride(0), ptr(k3), k3.stride(0), ptr(cos_sin), ptr(q_out),
+                                ptr(k_out), T, n_q_heads, n_kv_heads, D, stream()), "mi_rope_plain")
+        return q_out, k_out
     q3 = q.view(T, n_q_heads, HEAD_DIM) if q.dim() == 2 else q
     k3 = k.view(T, n_kv_heads, HEAD_DIM) if k.dim() == 2 else k
     assert q3.stride(2) == 1 and q3.stride(1) == HEAD_DIM and k3.stride(2) == 1 and k3.stride(1) == HEAD_DIM

@@ -21,6 +21,12 @@ TINY_MOE = dict(TINY, architectures=["Qwen3MoeForCausalLM"], model_type="qwen3_m
                 num_experts_per_tok=2, moe_intermediate_size=64, decoder_sparse_step=1, mlp_only_layers=[],
                 norm_topk_prob=True)
 
+# head geometries of the plain-layout attention kernels (csrc/attn_plain.hip): Qwen2-0.5B's (head_dim 64, 7 query
+# heads per kv head, qkv bias, no q/k norm) and Llama-3.2-1B's (head_dim 64, 4 per kv head) on tiny widths
+TINY_QWEN2_HD64 = dict(TINY, architectures=["Qwen2ForCausalLM"], model_type="qwen2", hidden_size=128, head_dim=64,
+                       num_attention_heads=7, num_key_value_heads=1, attention_bias=True)
+TINY_LLAMA_HD64 = dict(TINY_LLAMA, hidden_size=256, head_dim=64, num_attention_heads=4, num_key_value_heads=1)
+
 MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
            bos_token_id=0)
 

@@ -66,11 +66,11 @@ def test_tiny_model_golden_run(golden_tiny, golden_tiny_bias, golden_tiny_llama,
 
 
 def _oracle_for(llm, cfg_dict, seed):
-    from transformers import Qwen3Config, Qwen3MoeConfig
+    from transformers import LlamaConfig, Qwen3Config, Qwen3MoeConfig
 
     from oracle.model import OracleConfig, OracleQwen3, random_weights
 
-    cls = Qwen3MoeConfig if cfg_dict.get("model_type") == "qwen3_moe" else Qwen3Config
+    cls = {"qwen3_moe": Qwen3MoeConfig, "llama": LlamaConfig}.get(cfg_dict.get("model_type"), Qwen3Config)
     hf = cls(**{k: v for k, v in cfg_dict.items() if k not in ("architectures", "model_type", "torch_dtype")})
     ocfg = OracleConfig.from_hf(hf)
     return OracleQwen3(ocfg, random_weights(ocfg, seed=seed), llm.config.num_kvcache_blocks,
