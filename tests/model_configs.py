@@ -27,6 +27,20 @@ TINY_QWEN2_HD64 = dict(TINY, architectures=["Qwen2ForCausalLM"], model_type="qwe
                        num_attention_heads=7, num_key_value_heads=1, attention_bias=True)
 TINY_LLAMA_HD64 = dict(TINY_LLAMA, hidden_size=256, head_dim=64, num_attention_heads=4, num_key_value_heads=1)
 
+# the two small models the reference's README benchmarks next to Qwen3-0.6B (README.md:316-318), full shapes
+QWEN2_0_5B = dict(
+    architectures=["Qwen2ForCausalLM"], model_type="qwen2", hidden_size=896, num_hidden_layers=24,
+    num_attention_heads=14, num_key_value_heads=2, intermediate_size=4864, vocab_size=151936,
+    max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=True,
+    hidden_act="silu", torch_dtype="bfloat16", bos_token_id=151643, eos_token_id=151645,
+)
+LLAMA_3_2_1B = dict(
+    architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=2048, num_hidden_layers=16,
+    num_attention_heads=32, num_key_value_heads=8, head_dim=64, intermediate_size=8192, vocab_size=128256,
+    max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=True,
+    hidden_act="silu", torch_dtype="bfloat16", bos_token_id=128000, eos_token_id=128001, attention_bias=False, mlp_bias=False,
+)
+
 MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
            bos_token_id=0)
 
