@@ -66,5 +66,13 @@ def golden_tiny_moe():
 
 
 @pytest.fixture(scope="session")
+def golden_tiny_hd64():
+    """The reference's Qwen3ForCausalLM (qkv bias, no q/k norm: the Qwen2 wiring) and LlamaForCausalLM at head_dim 64
+    with 7 / 4 query heads per kv head - Qwen2-0.5B's and Llama-3.2-1B's head geometry (csrc/attn_plain.hip)."""
+    return {"qwen2_hd64": np.load(os.path.join(GOLDEN, "tiny_model_qwen2_hd64.npz")),
+            "llama_hd64": np.load(os.path.join(GOLDEN, "tiny_model_llama_hd64.npz"))}
+
+
+@pytest.fixture(scope="session")
 def golden_moe_block():
     return np.load(os.path.join(GOLDEN, "moe_block.npz"))

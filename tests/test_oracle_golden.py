@@ -104,14 +104,16 @@ def test_sampler_probabilities(golden_layers):
     assert torch.equal(p, torch.from_numpy(g["samp_probs"]))
 
 
-def _tiny_oracle(g, llama=False, moe=False):
+def _tiny_oracle(g, llama=False, moe=False, variant=None):
     from transformers import LlamaConfig, Qwen3Config, Qwen3MoeConfig
 
     weights = {k[3:]: bf(g[k]) for k in g.files if k.startswith("w::")}
-    from model_configs import TINY, TINY_LLAMA, TINY_MOE
+    from model_configs import TINY, TINY_LLAMA, TINY_LLAMA_HD64, TINY_MOE, TINY_QWEN2_HD64
 
     tiny = dict(TINY, attention_bias=True) if "attention_bias" in g.files and int(g["attention_bias"]) else TINY
     tiny = TINY_LLAMA if llama else (TINY_MOE if moe else tiny)
+    if variant in ("qwen2_hd64", "llama_hd64"):
+        tiny, llama = {"qwen2_hd64": TINY_QWEN2_HD64, "llama_hd64": TINY_LLAMA_HD64}[variant], variant == "llama_hd64"
     cls = LlamaConfig if llama else (Qwen3MoeConfig if moe else Qwen3Config)
     hf = cls(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
@@ -145,15 +147,17 @@ def test_moe_block_matches_reference(golden_moe_block):
         assert float((d / ulp).max()) <= 2.0 and float((d > 0).float().mean()) <= 0.05, (float((d / ulp).max()), float((d > 0).float().mean()))
 
 
-@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias", "llama", "moe"])
-def test_tiny_model_matches_reference_run(golden_tiny, golden_tiny_bias, golden_tiny_llama, golden_tiny_moe, variant):
+@pytest.mark.parametrize("variant", ["qwen3", "qkv_bias", "llama", "moe", "qwen2_hd64", "llama_hd64"])
+def test_tiny_model_matches_reference_run(golden_tiny, golden_tiny_bias, golden_tiny_llama, golden_tiny_moe, golden_tiny_hd64,
+                                          variant):
     """Replay the reference's own greedy run (its scheduler, block manager, prepare_*,
     model) through the oracle model with the same token stream.  The reference
     pipeline is bf16 end to end with bf16 S/P in attention, so logits agree to a
     bf16-ulp-scale bound, and greedy tokens agree wherever the reference's top-2
     margin exceeds that bound."""
-    g = {"qwen3": golden_tiny, "qkv_bias": golden_tiny_bias, "llama": golden_tiny_llama, "moe": golden_tiny_moe}[variant]
-    model, bs = _tiny_oracle(g, llama=variant == "llama", moe=variant == "moe")
+    g = {"qwen3": golden_tiny, "qkv_bias": golden_tiny_bias, "llama": golden_tiny_llama, "moe": golden_tiny_moe,
+         **golden_tiny_hd64}[variant]
+    model, bs = _tiny_oracle(g, llama=variant == "llama", moe=variant == "moe", variant=variant)
     lens = g["prompt_lens"].tolist()
     flat = g["prompts"].tolist()
     prompts, o = [], 0
@@ -203,7 +207,9 @@ def test_tiny_model_matches_reference_run(golden_tiny, golden_tiny_bias, golden_
             if margin[i] > 0.25:  # 4x the logit bound: both candidates may move
                 assert mine[i] == ref_tokens[i], (step, i)
             toks[s].append(ref_tokens[i])  # follow the reference's token stream
-    assert worst <= 6e-2, worst
+    # the reference's bf16 pipeline (bf16 scores and probabilities) against fp32 internals: ~2 bf16 ulps of the largest
+    # logits (4.6 on the 128-wide models: ulp 2^-5); the 256-wide llama_hd64 reaches logits of 5.5 over twice as long sums
+    assert worst <= (1e-1 if variant == "llama_hd64" else 6e-2), worst
     assert sum(toks, []) == g["final_tokens"].tolist()
 
 

@@ -454,13 +454,18 @@ def gen_tiny_model(variant: str = ""):
     ref_llama.Attention = NativeAdapter
     ref_moe.Attention = NativeAdapter
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from model_configs import TINY, TINY_LLAMA, TINY_MOE  # the same dicts the tests build their model directories from
+    # the same dicts the tests build their model directories from
+    from model_configs import TINY, TINY_LLAMA, TINY_LLAMA_HD64, TINY_MOE, TINY_QWEN2_HD64
 
-    tiny = {"bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA, "moe": TINY_MOE}.get(variant, TINY)
-    cfg_cls = {"llama": LlamaConfig, "moe": Qwen3MoeConfig}.get(variant, Qwen3Config)
+    # "qwen2_hd64" / "llama_hd64": head_dim 64 with 7 / 4 query heads per kv head (Qwen2-0.5B's and Llama-3.2-1B's head
+    # geometry: the plain-layout attention family of csrc/attn_plain.hip)
+    tiny = {"bias": dict(TINY, attention_bias=True), "llama": TINY_LLAMA, "moe": TINY_MOE,
+            "qwen2_hd64": TINY_QWEN2_HD64, "llama_hd64": TINY_LLAMA_HD64}.get(variant, TINY)
+    cfg_cls = {"llama": LlamaConfig, "llama_hd64": LlamaConfig, "moe": Qwen3MoeConfig}.get(variant, Qwen3Config)
     hf = cfg_cls(**{k: v for k, v in tiny.items() if k not in ("architectures", "model_type", "torch_dtype")})
     cfg = OracleConfig.from_hf(hf)
-    weights = random_weights(cfg, seed={"": 3, "bias": 13, "llama": 23, "moe": 33}[variant], std=0.08)
+    weights = random_weights(cfg, seed={"": 3, "bias": 13, "llama": 23, "moe": 33, "qwen2_hd64": 43, "llama_hd64": 53}[variant],
+                             std=0.08)
     if variant == "moe":  # a wider router so that the top-2 choice is not a coin flip between near-equal logits
         for name in list(weights):
             if name.endswith("mlp.gate.weight"):
@@ -471,8 +476,8 @@ def gen_tiny_model(variant: str = ""):
         if "norm" in name:
             weights[name] = (1.0 + 0.1 * torch.randn(weights[name].shape, generator=g)).to(torch.bfloat16)
     torch.set_default_dtype(torch.bfloat16)
-    model = {"llama": ref_llama.LlamaForCausalLM, "moe": ref_moe.Qwen3MoeForCausalLM}.get(
-        variant, ref_qwen3.Qwen3ForCausalLM)(hf)
+    model = {"llama": ref_llama.LlamaForCausalLM, "llama_hd64": ref_llama.LlamaForCausalLM,
+             "moe": ref_moe.Qwen3MoeForCausalLM}.get(variant, ref_qwen3.Qwen3ForCausalLM)(hf)
     torch.set_default_dtype(torch.float32)
     sd = dict(model.named_parameters())
     for name, w in weights.items():
@@ -483,11 +488,11 @@ def gen_tiny_model(variant: str = ""):
             sd[name].data.copy_(w)
     # rope table must be fp32 (default dtype was bf16 while constructing)
     from nanovllm.layers.rotary_embedding import RotaryEmbedding
-    rope = RotaryEmbedding(128, 128, 512, cfg.rope_theta)
+    rope = RotaryEmbedding(cfg.head_dim, cfg.head_dim, 512, cfg.rope_theta)
     li = 0
     for m in model.modules():
         if isinstance(m, NativeAdapter):
-            m.k_cache = torch.zeros(nblk, block_size, 1, 128, dtype=torch.bfloat16)
+            m.k_cache = torch.zeros(nblk, block_size, cfg.num_key_value_heads, cfg.head_dim, dtype=torch.bfloat16)
             m.v_cache = torch.zeros_like(m.k_cache)
             li += 1
         if hasattr(m, "rotary_emb"):
@@ -525,7 +530,7 @@ def gen_tiny_model(variant: str = ""):
             step += 1
     out["n_steps"] = np.array(step)
     out["final_tokens"] = np.array(sum([s.token_ids for s in seqs_all], []), dtype=np.int64)
-    out["attention_bias"] = np.array(int(variant == "bias"))
+    out["attention_bias"] = np.array(int(variant in ("bias", "qwen2_hd64")))
     np.savez_compressed(os.path.join(OUT, f"tiny_model{'_' + variant if variant else ''}.npz"), **out)
 
 
@@ -538,7 +543,9 @@ def main():
                      ("engine", gen_engine), ("engine_fuzz", gen_engine_fuzz), ("tiny_model", gen_tiny_model),
                      ("tiny_model_bias", lambda: gen_tiny_model("bias")),
                      ("tiny_model_llama", lambda: gen_tiny_model("llama")), ("moe_block", gen_moe_block),
-                     ("tiny_model_moe", lambda: gen_tiny_model("moe"))):
+                     ("tiny_model_moe", lambda: gen_tiny_model("moe")),
+                     ("tiny_model_qwen2_hd64", lambda: gen_tiny_model("qwen2_hd64")),
+                     ("tiny_model_llama_hd64", lambda: gen_tiny_model("llama_hd64"))):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
