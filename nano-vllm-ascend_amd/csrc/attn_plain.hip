@@ -15,6 +15,8 @@
 //                                the workgroup's four waves share the 32-key K / V chunk through LDS (V stored
 //                                transposed), P goes from the C layout to the A layout through a wave-private LDS tile.
 // fp32 softmax; P enters the second product as bf16 hi + lo (prefill) / unrounded (decode).
+#include <stdlib.h>
+
 #include "mi_common.hpp"
 
 namespace mi {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_decode_plain_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ ctx_lens,
     uint16_t* __restrict__ out, float* __restrict__ part, int n_q_heads, int n_kv_heads, int G, int block_size,
-    float scale_log2e) {
+    int bs_shift, float scale_log2e) {
   constexpr int LPT = D / 8;     // lanes per token row
   constexpr int TPW = 64 / LPT;  // token rows per wave-load
   __shared__ float sm_acc[4][GMAX][D];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void attn_decode_plain_kernel(
   const int slot = lane / LPT, dl = lane % LPT;  // token slot of the wave-load, 8-dim piece of the row
   const int len = ctx_lens[b];
   // this split's token range: whole multiples of the workgroup's stride (4 * TPW tokens)
-  const int per = ((len + nsplit - 1) / nsplit + 4 * TPW - 1) / (4 * TPW) * (4 * TPW);
+  const int per = ((len + nsplit - 1) / nsplit + 4 * TPW - 1) / (4 * TPW) * (4 * TPW);  // (wave w: groups w, w + 4, ...)
   const int t_beg = split * per, t_end = min(len, t_beg + per);
 
   float qf[GMAX][8], acc[GMAX][8], m[GMAX], l[GMAX];
@@ -141,41 +143,56 @@ __global__ __launch_bounds__(256) void attn_decode_plain_kernel(
     }
   }
   const int32_t* table = block_table + (int64_t)b * table_stride;
-  for (int t0 = t_beg + wave * TPW; t0 < t_end; t0 += 4 * TPW) {
-    const int t = t0 + slot;
-    const bool valid = t < t_end;
-    float kf[8], vf[8];
-    if (valid) {
-      const int64_t blk = table[t / block_size];
-      const int64_t row = ((blk * n_kv_heads + h) * block_size + t % block_size) * D + dl * 8;
-      const u32x4 kr = *reinterpret_cast<const u32x4*>(kc + row);
-      const u32x4 vr = *reinterpret_cast<const u32x4*>(vc + row);
+  // U wave-loads of K and of V in flight: the block ids of all U first (independent loads), then the 2 U row loads -
+  // two dependent memory round trips per U token groups instead of per group
+  constexpr int U = 4;
+  for (int t0 = t_beg + wave * TPW; t0 < t_end; t0 += U * 4 * TPW) {
+    int64_t row[U];
+    bool valid[U];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        kf[2 * j] = lo_bf(kr[j]);
-        kf[2 * j + 1] = hi_bf(kr[j]);
-        vf[2 * j] = lo_bf(vr[j]);
-        vf[2 * j + 1] = hi_bf(vr[j]);
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 4 * TPW + slot;
+      valid[u] = t < t_end;
+      const int tb = bs_shift >= 0 ? t >> bs_shift : t / block_size;
+      const int64_t blk = valid[u] ? table[tb] : 0;
+      row[u] = ((blk * n_kv_heads + h) * block_size + (t - tb * block_size)) * D + dl * 8;
+    }
+    u32x4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      kr[u] = vr[u] = u32x4{0, 0, 0, 0};
+      if (valid[u]) {
+        kr[u] = *reinterpret_cast<const u32x4*>(kc + row[u]);
+        vr[u] = *reinterpret_cast<const u32x4*>(vc + row[u]);
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) kf[i] = vf[i] = 0.f;
     }
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-      if (g < G) {
-        float s = 0.f;
+    for (int u = 0; u < U; ++u) {
+      if (t0 + u * 4 * TPW >= t_end) break;  // wave-uniform: no lane of this group has a token
+      float kf[8], vf[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += qf[g][i] * kf[i];
+      for (int j = 0; j < 4; ++j) {
+        kf[2 * j] = lo_bf(kr[u][j]);
+        kf[2 * j + 1] = hi_bf(kr[u][j]);
+        vf[2 * j] = lo_bf(vr[u][j]);
+        vf[2 * j + 1] = hi_bf(vr[u][j]);
+      }
 #pragma unroll
-        for (int o = 1; o < LPT; o <<= 1) s += __shfl_xor(s, o, 64);  // the row's LPT lanes hold the full dot product
-        const float mn = valid ? fmaxf(m[g], s) : m[g];
-        const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
-        const float p = valid ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
-        l[g] = l[g] * alpha + p;
+      for (int g = 0; g < GMAX; ++g) {
+        if (g < G) {
+          float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[g][i] = acc[g][i] * alpha + p * vf[i];
-        m[g] = mn;
+          for (int i = 0; i < 8; ++i) s += qf[g][i] * kf[i];
+#pragma unroll
+          for (int o = 1; o < LPT; o <<= 1) s += __shfl_xor(s, o, 64);  // the row's LPT lanes hold the full dot product
+          const float mn = valid[u] ? fmaxf(m[g], s) : m[g];
+          const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
+          const float p = valid[u] ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
+          l[g] = l[g] * alpha + p;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[g][i] = acc[g][i] * alpha + p * vf[i];
+          m[g] = mn;
+        }
       }
     }
   }
@@ -249,8 +266,12 @@ __global__ __launch_bounds__(D) void attn_merge_plain_kernel(const float* __rest
 static int decode_plain_splits(int batch, int n_kv_heads, int max_blocks_hint) {
   (void)max_blocks_hint;
   const int wgs = batch * n_kv_heads;
+  static const int target = [] {
+    const char* e = getenv("MI355_PLAIN_SPLIT_TARGET");
+    return e ? atoi(e) : 512;
+  }();
   int ns = 1;
-  while (wgs * ns < 512 && ns < 16) ns *= 2;
+  while (wgs * ns < target && ns < 16) ns *= 2;
   return ns;
 }
 
@@ -462,10 +483,14 @@ extern "C" int mi_paged_attn_decode_plain(const mi_bf16* q, int64_t q_row_stride
   float* part = static_cast<float*>(workspace);
   const dim3 grid(ns, n_kv_heads, batch);
   const float sl2 = scale * 1.4426950408889634f;
+  int bs_shift = -1;  // block sizes that are a power of two: shifts instead of per-lane integer divisions
+  for (int sft = 0; sft < 16; ++sft)
+    if ((1 << sft) == block_size) bs_shift = sft;
   hipStream_t st = S(stream);
 #define DEC_PLAIN(DD, GM)                                                                                          \
   hipLaunchKernelGGL((attn_decode_plain_kernel<DD, GM>), grid, dim3(256), 0, st, q, q_row_stride, k_cache, v_cache, \
-                     block_table, table_stride, context_lens, out, part, n_q_heads, n_kv_heads, G, block_size, sl2)
+                     block_table, table_stride, context_lens, out, part, n_q_heads, n_kv_heads, G, block_size, bs_shift, \
+                     sl2)
   if (head_dim == 64) {
     if (G <= 4) DEC_PLAIN(64, 4);
     else DEC_PLAIN(64, 8);
