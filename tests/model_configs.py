@@ -44,6 +44,12 @@ LLAMA_3_2_1B = dict(
 MID = dict(QWEN3_0_6B, num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096, eos_token_id=4095,
            bos_token_id=0)
 
+# a Llama-wired model with the plain-layout head geometry (head_dim 64, 8 query / 2 kv heads) that two TP ranks can
+# share: one kv head per rank
+MID_LLAMA_HD64 = dict(MID, architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=512, head_dim=64,
+                      num_attention_heads=8, num_key_value_heads=2, intermediate_size=1024, rope_theta=10000.0,
+                      attention_bias=False, mlp_bias=False)
+
 # BASELINE.json configs[2]: Qwen3-32B widths (hidden 5120, 64 q / 8 kv heads, intermediate 25600), cut to
 # 2 layers and a 4096 vocabulary so that the CPU oracle finishes in seconds
 QWEN3_32B_2L = dict(QWEN3_0_6B, hidden_size=5120, num_hidden_layers=2, num_attention_heads=64,

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import bf16_from_bits as bf
-from model_configs import QWEN3_32B_2L, MID, TINY, TINY_LLAMA, TINY_LLAMA_HD64, TINY_MOE, TINY_QWEN2_HD64, make_model_dir
+from model_configs import QWEN3_32B_2L, MID, MID_LLAMA_HD64, TINY, TINY_LLAMA, TINY_LLAMA_HD64, TINY_MOE, TINY_QWEN2_HD64, make_model_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -279,7 +279,9 @@ def test_lookahead_decode_equals_step_by_step_decode():
     # BASELINE.json configs[3] / configs[2] at their own world sizes: Qwen3-30B-A3B widths over FOUR ranks and
     # Qwen3-32B widths over EIGHT (one kv head per rank), hipGraph and eager - engine, exchange kernels and RPC
     ("QWEN3_30B_A3B_2L", False, 2.2e-1, 4), ("QWEN3_30B_A3B_2L", True, 2.2e-1, 4),
-    ("QWEN3_32B_2L", False, 1.6e-1, 8), ("QWEN3_32B_2L", True, 1.6e-1, 8)])
+    ("QWEN3_32B_2L", False, 1.6e-1, 8), ("QWEN3_32B_2L", True, 1.6e-1, 8),
+    # the plain-layout attention family (head_dim 64) sharded: one kv head per rank
+    ("MID_LLAMA_HD64", False, 6e-2, 2)])
 def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, world):
     """Functional tensor-parallel run on a 1-GPU box: `world` rank processes share cuda:0 and talk over
     gloo (MI355_DIST_BACKEND) - the same sharded layers, RPC channel and collectives call sites as
@@ -292,7 +294,8 @@ def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, w
 
     from nanovllm import LLM, SamplingParams
 
-    cfg = {"MID": MID, "QWEN3_32B_2L": QWEN3_32B_2L, "QWEN3_30B_A3B_2L": QWEN3_30B_A3B_2L}[model]
+    cfg = {"MID": MID, "QWEN3_32B_2L": QWEN3_32B_2L, "QWEN3_30B_A3B_2L": QWEN3_30B_A3B_2L,
+           "MID_LLAMA_HD64": MID_LLAMA_HD64}[model]
     gen = torch.Generator().manual_seed(5)
     prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in (9, 33, 70)]
     sp = SamplingParams(max_tokens=6, ignore_eos=True, greedy=True)
