@@ -322,6 +322,13 @@ int mi_add_rmsnorm_splitk_warm(const float* partials, int nsplit, const mi_bf16*
                                int warm0_tile_bytes, const void* warm1, size_t warm1_bytes,
                                int warm1_tile_bytes, mi_stream stream);
 
+/* The warming workgroups of mi_add_rmsnorm_splitk_warm as a launch of their own: n_workgroups (a multiple of 8)
+ * workgroups pull the given packed weights into L2.  The tensor-parallel decode path queues it on a forked stream
+ * beside mi_allreduce_add_rmsnorm (MI355_SEAM_OVERLAP=1, SURVEY 8(f)1: the all-reduce overlapped with the next
+ * projection's weight stream). */
+int mi_warm_l2(const void* warm0, size_t warm0_bytes, int warm0_tile_bytes, const void* warm1,
+               size_t warm1_bytes, int warm1_tile_bytes, int n_workgroups, mi_stream stream);
+
 /* EXPERIMENT, not on the product path (decode chain): the MLP half of a decode layer
  * (layernorm.py:27-38 -> linear.py:73 + activation.py:10-12 -> linear.py:150) as ONE persistent launch of 256
  * workgroups with in-launch hand-offs instead of three launches; bit-identical to

@@ -6,6 +6,7 @@
 
 #include "mi_common.hpp"
 #include "kv_store.hpp"
+#include "warm_l2.hpp"
 
 namespace mi {
 
@@ -180,43 +181,7 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
 // that every thread of the workgroup has work - PART + 2 loads per lane, all issued before the first use.
 // Same arithmetic and summation order per element; the sum of squares adds the lanes' partial sums in a
 // different grouping than the 8-wide form (both are fp32 sums of the same squares).
-// WARM: the launch has rows workgroups of work and a chip of 256 CUs - the workgroups from block `first` on pull the
-// weights of the NEXT launches (the GEMMs this norm feeds) into L2 while the norm's own dependent chain (partials ->
-// sum of squares -> barrier -> scale) runs.  L2 is per XCD: a weight tile must land in the L2 of the XCD whose
-// workgroup will read it.  The dispatcher deals workgroups to the eight XCDs round-robin by linear block id (a speed
-// assumption only - a wrong guess costs the benefit, never the result), and every consumer kernel here maps its
-// 16-row weight tile t to a block id = t mod 8 (gemm_skinny_kernel: tile bx, the SwiGLU pair bx and bx + N/32, the
-// K slices of tile bx on blockIdx.y with gridDim.x a multiple of 8), so tile t belongs to XCD t % 8, and so do the
-// warming workgroups `first` + p with p % 8 == t % 8.
-struct WarmArgs {
-  const char* base[2];   // packed weights (fragment-native: a 16-row tile is one contiguous run of tile_bytes)
-  uint32_t bytes[2];
-  uint32_t tile_bytes[2];
-  int first;             // block id of the first warming workgroup, a multiple of 8
-};
-
-// The lines are requested by LDS-DMA into a scratch block nobody reads: a load with a register destination would
-// need its registers kept free until it returns (an `asm` load's destination is invisible to the compiler's liveness).
-__device__ __forceinline__ void warm_l2(const WarmArgs& wa, int p, int n_warm, int tid, char* scratch) {
-  const int xcd = p & 7, q = p >> 3, nq = n_warm >> 3;
-  char* dst = scratch + (tid >> 6) * 1024;  // one 1 KiB landing block per wave (the DMA destination is lane-linear)
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    if (!wa.base[r]) continue;
-    const uint32_t tb = wa.tile_bytes[r], ntiles = wa.bytes[r] / tb;
-    if ((uint32_t)xcd >= ntiles) continue;
-    const uint32_t mine = (ntiles - xcd + 7) >> 3;            // tiles xcd, xcd + 8, ... of this XCD
-    const uint32_t pieces = mine * (tb >> 12);                // in 4 KiB pieces, dealt to the XCD's warming workgroups
-    for (uint32_t j = q; j < pieces; j += nq) {
-      const uint32_t t = j / (tb >> 12), o = (j % (tb >> 12)) << 12;
-      const char* src = wa.base[r] + (size_t)(xcd + 8 * t) * tb + o + tid * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
+// WARM: see warm_l2.hpp - the workgroups from block `first` on pull the weights of the NEXT launches into L2
 template <int PART, int WPR, bool WARM = false>
 __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
     const float* __restrict__ part, const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
@@ -721,6 +686,30 @@ extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const m
   if (rows == 0) return MI_OK;
   return launch_rmsnorm<true>(x, nullptr, 0, (int64_t)cols, 1, residual, w, y, residual_out, rows, cols, eps,
                               S(stream));
+}
+
+// the same as a launch of its own (a forked graph branch beside the tensor-parallel seam, models/qwen3.py)
+static __global__ __launch_bounds__(256) void warm_l2_kernel(const WarmArgs wa) {
+  __shared__ __attribute__((aligned(1024))) char scratch[4096];
+  warm_l2(wa, (int)blockIdx.x, (int)gridDim.x, threadIdx.x, scratch);
+}
+
+extern "C" int mi_warm_l2(const void* warm0, size_t warm0_bytes, int warm0_tile_bytes, const void* warm1,
+                          size_t warm1_bytes, int warm1_tile_bytes, int n_workgroups, mi_stream stream) {
+  const void* wp[2] = {warm0, warm1};
+  const size_t wb[2] = {warm0_bytes, warm1_bytes};
+  const int wt[2] = {warm0_tile_bytes, warm1_tile_bytes};
+  if ((!warm0 && !warm1) || n_workgroups < 8 || n_workgroups % 8) return MI_EINVAL;
+  WarmArgs wa{};
+  for (int r = 0; r < 2; ++r) {
+    if (wp[r] && (!aligned16(wp[r]) || wt[r] <= 0 || wt[r] % 4096 || wb[r] % (size_t)wt[r] || wb[r] >= ((size_t)1 << 32)))
+      return MI_EINVAL;
+    wa.base[r] = static_cast<const char*>(wp[r]);
+    wa.bytes[r] = (uint32_t)wb[r];
+    wa.tile_bytes[r] = (uint32_t)wt[r];
+  }
+  hipLaunchKernelGGL(warm_l2_kernel, dim3(n_workgroups), dim3(256), 0, S(stream), wa);
+  return check_launch();
 }
 
 // mi_add_rmsnorm_splitk for decode-sized inputs with the otherwise idle CUs warming L2 for the launches behind it

@@ -110,6 +110,7 @@ _SIGNATURES = {
                                            c_int, c_int, c_float, _p]),
     "mi_paged_attn_prefill_plain": (c_int, [_p, c_int64, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int,
                                             c_int, c_int, c_float, _p]),
+    "mi_warm_l2": (c_int, [_p, c_size_t, c_int, _p, c_size_t, c_int, c_int, _p]),
     "mi_mlp_half_fused": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk_warm": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, c_size_t, c_int, _p,
                                            c_size_t, c_int, _p]),

@@ -192,6 +192,17 @@ class Qwen3DecoderLayer(nn.Module):
         return hidden_states, residual
 
 
+_SEAM_STREAMS: dict = {}
+
+
+def _seam_stream(device):
+    """one side stream per device for the forked branch of the tensor-parallel seam (MI355_SEAM_OVERLAP)"""
+    st = _SEAM_STREAMS.get(device)
+    if st is None:
+        st = _SEAM_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 class Qwen3Model(nn.Module):
     def __init__(self, config, fused: bool = True, layer_factory=None, **layer_overrides) -> None:
         """layer_factory(layer_idx) -> decoder layer: models whose layers differ (Qwen3-MoE) build ONLY their own
@@ -318,9 +329,26 @@ class Qwen3Model(nn.Module):
                 return ops.gemm_tile(x, w, silu_mul=silu_mul)
             return ops.gemm_packed(x, lin.weight_packed, silu_mul=silu_mul)
 
+        # SURVEY 8(f)1, the tensor-parallel seam (linear.py:149-153): the only work that can overlap the all-reduce is the
+        # NEXT projections' weight stream (their activations are the all-reduce's result).  MI355_SEAM_OVERLAP=1 forks the
+        # stream - under capture: a parallel graph branch - behind the row-parallel GEMM, queues mi_warm_l2 for those
+        # weights beside mi_allreduce_add_rmsnorm and joins before the column-parallel GEMM.  Off by default: on one GPU
+        # the same warming inside the norm launch measured slower (MI355_WARM_L2); whether the longer seam on links
+        # changes that is for the 8-GPU box to say.
+        overlap = fused_seam and os.environ.get("MI355_SEAM_OVERLAP", "0") != "0"
+        side = _seam_stream(h.device) if overlap else None
+
         def norm_linear(y, is_partials, res, ln, lin, silu_mul=False, then=None):
             """linear(rmsnorm(y + res)) -> (out, new residual); `then`: the row-parallel projection behind it"""
+            forked = overlap and is_partials == "ranks"
+            if forked:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.warm_l2([m.weight_packed for m in ((lin,) if then is None else (lin, then))])
             x, res = add_norm(y, is_partials, res, ln, warm=(lin,) if then is None else (lin, then))
+            if forked:
+                main.wait_stream(side)
             return column_parallel(x, lin, silu_mul), res
 
         residual, parts, is_partials = None, None, False

@@ -564,6 +564,18 @@ def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:
     return out
 
 
+def warm_l2(weights, n_workgroups: int = 64) -> None:
+    """queue a launch that pulls up to two packed bf16 weights ([N, K], mi_pack_weight) into L2 (mi_warm_l2)"""
+    ws = [t for t in weights if isinstance(t, torch.Tensor) and t.dtype == _BF16 and t.dim() == 2
+          and (32 * t.shape[1]) % 4096 == 0 and t.numel() * 2 < (1 << 32)][:2]
+    if not ws:
+        return
+    require_gpu(*ws)
+    w0, w1 = ws[0], (ws[1] if len(ws) > 1 else None)
+    check(lib.mi_warm_l2(ptr(w0), w0.numel() * 2, 32 * w0.shape[1], ptr(w1), w1.numel() * 2 if w1 is not None else 0,
+                         32 * w1.shape[1] if w1 is not None else 0, n_workgroups, stream()), "mi_warm_l2")
+
+
 def mlp_half_fused(partials, residual, norm_w, eps: float, w_gate_up_packed, w_down_packed, sync_words, scratch=None):
     """EXPERIMENT (csrc/mlp_half.hip): add+RMSNorm -> gate_up+SwiGLU -> down split-K as one persistent launch.
     -> (fp32 partials [4, rows, hidden], new residual); sync_words: 8 zeroed int32 on the device, kept across calls."""

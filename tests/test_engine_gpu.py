@@ -329,6 +329,35 @@ def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, w
         assert (logits1 - logits2).abs().max().item() <= tol
 
 
+def test_tp_seam_overlap_branch_keeps_the_tokens(monkeypatch):
+    """MI355_SEAM_OVERLAP=1: a forked graph branch warms L2 with the next projections' weights beside
+    the fused all-reduce + add + RMSNorm seam.  Two ranks on one GPU, hipGraph decode: the same tokens as without it."""
+    import socket
+
+    from nanovllm import LLM, SamplingParams
+
+    gen = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in (9, 33, 70, 5)]
+    sp = SamplingParams(max_tokens=8, ignore_eos=True, greedy=True)
+    monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
+
+    def run(overlap):
+        monkeypatch.setenv("MI355_SEAM_OVERLAP", "1" if overlap else "0")
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+                  max_model_len=512, num_kvcache_blocks=64, enforce_eager=False, warmup=False, synthetic_seed=3,
+                  tensor_parallel_size=2, hccl_port=port)
+        try:
+            assert llm.model_runner.xgmi is not None and llm.model_runner.graphs
+            return [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+        finally:
+            llm.exit()
+
+    assert run(True) == run(False)
+
+
 def test_tp_decode_picks_tokens_in_the_graph(monkeypatch):
     """Tensor-parallel decode without the host in the loop (two ranks on cuda:0 over gloo): every rank's decode graph
     ends in the token choice - shard-local pick, 8-byte {key, token} exchange over the exchange region, the same
