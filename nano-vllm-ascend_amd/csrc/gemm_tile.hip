@@ -466,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
 // Same summation order and epilogues as the large kernel: results are bit-identical.
 // SwiGLU: the tile's 128 weight rows are, per wave, 32 gate rows (fragment 0) and the 32 up rows that pair with them.
 // ---------------------------------------------------------------------------
-constexpr int MID_F = 128, MID_T = 128, MID_STAGE = 2 * HALF_BYTES;
+constexpr int MID_STAGE = 2 * HALF_BYTES;  // (MID_F, MID_T and the index arithmetic: gemm_tile_index.hpp)
 
 template <int EPI, bool BIAS, int NST>
 __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_mid_kernel(const TileArgs a) {
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_mid_kernel(const T
   const char* srcB[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int lr = (wave * 4 + i) * 8 + (lane >> 3), c = (lane & 7) ^ swizzle(lr);
-    const int rowA = EPI == TEPI_SILU ? ((lr >> 5) & 1) * (a.N >> 1) + (n0 >> 1) + (lr >> 6) * 32 + (lr & 31) : n0 + lr;
+    const int lr = mid_dma_local_row(wave, i, lane), c = mid_dma_chunk(wave, i, lane);
+    const int rowA = mid_weight_row(lr, n0, a.N, EPI == TEPI_SILU);
     srcA[i] = reinterpret_cast<const char*>(a.w) + kbeg_bytes + ((int64_t)min(rowA, a.N - 1) * a.K + c * 8) * 2;
     srcB[i] = reinterpret_cast<const char*>(a.x) + kbeg_bytes + ((int64_t)min(m0 + lr, a.M - 1) * a.ldx + c * 8) * 2;
   }

@@ -69,5 +69,22 @@ MI_HD constexpr int acc_feature(int fh, int ah, int a, int r, int hi) {
 }
 MI_HD constexpr int acc_token(int tq, int bh, int l31) { return tq * 64 + bh * 32 + l31; }
 
+// ---- the 128 x 128 kernel (gemm_mid_kernel): four waves, fw = wave >> 1 (64 features), tw = wave & 1 (64 tokens);
+// a K step = one A half-tile (local row = tile feature row) + one B half-tile (local row = tile token row) ----
+constexpr int MID_F = 128, MID_T = 128;
+MI_HD constexpr int mid_dma_block(int wave, int i) { return wave * 4 + i; }  // i = 0..3: 1 KiB block of either half-tile
+MI_HD constexpr int mid_dma_local_row(int wave, int i, int lane) { return mid_dma_block(wave, i) * 8 + (lane >> 3); }
+MI_HD constexpr int mid_dma_chunk(int wave, int i, int lane) { return (lane & 7) ^ swizzle(mid_dma_local_row(wave, i, lane)); }
+// weight row of local row lr of the A half-tile of the tile at feature n0: plain, or SwiGLU (each wave's first fragment
+// = 32 gate rows, its second the 32 up rows that pair with them; n0 counts gate + up rows, n0 / 2 output columns)
+MI_HD constexpr int mid_weight_row(int lr, int n0, int N, bool silu) {
+  return silu ? ((lr >> 5) & 1) * (N >> 1) + (n0 >> 1) + (lr >> 6) * 32 + (lr & 31) : n0 + lr;
+}
+MI_HD constexpr int mid_a_local_row(int fw, int f, int l31) { return fw * 64 + f * 32 + l31; }
+MI_HD constexpr int mid_b_local_row(int tw, int b, int l31) { return tw * 64 + b * 32 + l31; }
+// accumulator acc[f][b], register r of lane (hi, l31): feature row inside the tile / token inside the tile
+MI_HD constexpr int mid_acc_feature(int fw, int f, int r, int hi) { return fw * 64 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+MI_HD constexpr int mid_acc_token(int tw, int b, int l31) { return tw * 64 + b * 32 + l31; }
+
 }  // namespace gt
 }  // namespace mi

@@ -5,6 +5,7 @@
 //   3. no ds_read_b128 lane group touches a 16-byte bank slot twice
 //   4. a whole 256 x 256 tile computed the way the kernel does it (DMA image -> fragments -> 32x32x16 MFMA
 //      semantics -> accumulator layout -> output columns, plain and SwiGLU row pairing) equals x @ w^T
+//   5. the same for the 128 x 128 kernel (gemm_mid_kernel)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -161,6 +162,89 @@ int main() {
           CHECK(got[t * n_out + c] == ref, "output (%d, %d): %f vs %f", t, c, got[t * n_out + c], ref);
         }
       }
+  }
+  // ---- 5: the 128 x 128 kernel: DMA image of its two half-tiles, fragment reads, one tile end to end ----
+  {
+    std::vector<std::vector<Cell>> mimg(2, std::vector<Cell>(HALF_BYTES / 16));  // [A | B]
+    for (int h = 0; h < 2; ++h)
+      for (int wave = 0; wave < 4; ++wave)
+        for (int i = 0; i < 4; ++i)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int byte = mid_dma_block(wave, i) * 1024 + lane * 16;
+            const int lr = mid_dma_local_row(wave, i, lane), c = mid_dma_chunk(wave, i, lane);
+            CHECK(byte == half_off(lr, c), "mid DMA wave %d i %d lane %d lands at %d, layout says %d", wave, i, lane, byte, half_off(lr, c));
+            Cell& cell = mimg[h][byte / 16];
+            cell.row = lr;
+            cell.chunk = c;
+            cell.writers++;
+          }
+    for (int h = 0; h < 2; ++h)
+      for (const Cell& c : mimg[h]) CHECK(c.writers == 1 && c.row >= 0 && c.row < 128, "mid half %d: cell writers %d row %d", h, c.writers, c.row);
+    for (int wave = 0; wave < 4; ++wave) {
+      const int fw = wave >> 1, tw = wave & 1;
+      for (int kk = 0; kk < 4; ++kk)
+        for (int op = 0; op < 2; ++op)      // 0: A fragments, 1: B fragments
+          for (int f = 0; f < 2; ++f) {
+            int addr[64];
+            for (int lane = 0; lane < 64; ++lane) {
+              const int hi = lane >> 5, l31 = lane & 31;
+              // the kernel's form: (fw | tw) * 8192 + f * 4096 + kx[kk]
+              addr[lane] = (op ? tw : fw) * 8192 + f * 4096 + (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
+              const int lr = op ? mid_b_local_row(tw, f, l31) : mid_a_local_row(fw, f, l31);
+              CHECK(addr[lane] == half_off(lr, frag_chunk(kk, hi)), "mid fragment address form");
+              const Cell& c = mimg[op][addr[lane] / 16];
+              CHECK(c.row == lr && c.chunk == frag_chunk(kk, hi), "mid fragment lane %d: row %d chunk %d", lane, c.row, c.chunk);
+            }
+            for (const auto& g : groups) {
+              int used[16] = {0};
+              for (int l : g) used[(addr[l] / 16) % 16]++;
+              for (int sl = 0; sl < 16; ++sl) CHECK(used[sl] <= 1, "mid: bank slot %d used %d times in one lane group", sl, used[sl]);
+            }
+          }
+    }
+    for (int silu = 0; silu < 2; ++silu) {
+      const int K = 64, N = silu ? 512 : 256, M = 128, n0 = 128, m0 = 0;  // the second feature tile
+      std::vector<float> x(M * K), w(N * K);
+      unsigned sd = 777u + silu;
+      auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)((int)(sd >> 24) - 128) / 64.0f; };
+      for (auto& v : x) v = rnd();
+      for (auto& v : w) v = rnd();
+      for (int wave = 0; wave < 4; ++wave) {
+        const int fw = wave >> 1, tw = wave & 1;
+        for (int b = 0; b < 2; ++b)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 16; ++r) {
+              const int hi = lane >> 5, l31 = lane & 31;
+              double acc[2];
+              for (int f = 0; f < 2; ++f) {
+                const int wrow = mid_weight_row(mid_acc_feature(fw, f, r, hi), n0, N, silu != 0);
+                const int xrow = m0 + mid_acc_token(tw, b, l31);
+                double sum = 0;
+                for (int k = 0; k < K; ++k) sum += (double)w[wrow * K + k] * x[xrow * K + k];
+                acc[f] = sum;
+              }
+              // the epilogue's output columns: plain col0 = n0 + fw * 64 + f * 32, SwiGLU col0 = n0 / 2 + fw * 32 (gate: f = 0)
+              const int within = (r & 3) + 8 * (r >> 2) + 4 * hi;
+              const int tok = m0 + mid_acc_token(tw, b, l31);
+              if (silu) {
+                const int col = (n0 >> 1) + fw * 32 + within;
+                double g = 0, u = 0;
+                for (int k = 0; k < K; ++k) {
+                  g += (double)x[tok * K + k] * w[col * K + k];
+                  u += (double)x[tok * K + k] * w[(N / 2 + col) * K + k];
+                }
+                CHECK(acc[0] == g && acc[1] == u, "mid silu pairing at (%d, %d)", tok, col);
+              } else {
+                for (int f = 0; f < 2; ++f) {
+                  const int col = n0 + fw * 64 + f * 32 + within;
+                  double ref = 0;
+                  for (int k = 0; k < K; ++k) ref += (double)x[tok * K + k] * w[col * K + k];
+                  CHECK(acc[f] == ref, "mid output (%d, %d)", tok, col);
+                }
+              }
+            }
+      }
+    }
   }
   if (fails) { std::printf("%d check(s) failed\n", fails); return 1; }
   std::printf("gemm_tile index replay: ok\n");
