@@ -396,6 +396,29 @@ def test_moe_model_builds_only_its_own_layers_and_flags_ignored_config_fields():
     assert _C.lib.mi_moe_shapes_supported(2048, 96) == -2  # Qwen3-30B-A3B experts at TP 8: no kernel, said at start-up
 
 
+def test_sequence_ids_array_tracks_the_token_list():
+    """Sequence.ids_array (the int64 copy the block hashes and the prefill staging read): the prompt part is converted
+    once, the completion part on every call - it must equal token_ids after appends, after a pending token was resolved
+    (lookahead) and for a sequence rebuilt from the rank wire format"""
+    from array import array
+
+    from nanovllm._C import xxh64_chain_blocks
+
+    s = Sequence(list(range(100, 140)), SamplingParams(max_tokens=8), block_size=16)
+    assert s.ids_array() is s.ids_array() and list(s.ids_array()) == s.token_ids  # cached, equal
+    s.append_token(7)
+    s.append_pending()
+    assert list(s.ids_array()) == s.token_ids and len(s.ids_array()) == 42
+    s.resolve_pending(9)
+    assert list(s.ids_array()) == s.token_ids and s.ids_array()[-1] == 9
+    assert xxh64_chain_blocks(s.ids_array(), 2, 16) == xxh64_chain_blocks(s.token_ids, 2, 16)
+    wire = np.asarray(s.to_wire(True), dtype=np.int64)
+    t, _ = Sequence.from_wire(wire)
+    assert list(t.ids_array()) == s.token_ids and isinstance(t.ids_array(), array)
+    m = batch_meta.prefill_meta([s], 16)  # no block table: slots -1, ids from the array
+    assert m.input_ids.tolist() == s.token_ids
+
+
 def test_chained_block_hashes_in_one_call_equal_the_per_block_chain():
     import random
     from array import array
