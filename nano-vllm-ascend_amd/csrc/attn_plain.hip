@@ -94,6 +94,22 @@ static __global__ __launch_bounds__(256) void rope_plain_kernel(
 // ---------------------------------------------------------------------------------------------------
 constexpr float kNegBig = -1.0e30f;  // "no score yet": finite, so that differences of maxima never produce NaN
 
+// Sum over an aligned group of 8 (or 16) lanes, every lane receiving the total, on the DPP path of the VALU (quad
+// permutes, then the half-row / row mirror: the partner holds the other half's sum already) - a __shfl_xor is a
+// ds_bpermute, ~100 cycles of LDS crossbar latency per step, three or four dependent steps per score.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int LANES>
+__device__ __forceinline__ float group_sum(float s) {
+  s += dpp_f<0xB1>(s);   // quad_perm [1, 0, 3, 2]
+  s += dpp_f<0x4E>(s);   // quad_perm [2, 3, 0, 1]
+  s += dpp_f<0x141>(s);  // row_half_mirror: lane i <-> 7 - i of each 8
+  if (LANES == 16) s += dpp_f<0x140>(s);  // row_mirror: lane i <-> 15 - i of each 16
+  return s;
+}
+
 // merge the online-softmax state (m, l, acc[8]) of two partners
 __device__ __forceinline__ void merge_state(float& m, float& l, float (&acc)[8], float m2, float l2, const float (&a2)[8]) {
   const float mn = fmaxf(m, m2);
@@ -183,8 +199,7 @@ __global__ __launch_bounds__(256) void attn_decode_plain_kernel(
           float s = 0.f;
 #pragma unroll
           for (int i = 0; i < 8; ++i) s += qf[g][i] * kf[i];
-#pragma unroll
-          for (int o = 1; o < LPT; o <<= 1) s += __shfl_xor(s, o, 64);  // the row's LPT lanes hold the full dot product
+          s = group_sum<LPT>(s);  // the row's LPT lanes hold the full dot product
           const float mn = valid[u] ? fmaxf(m[g], s) : m[g];
           const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
           const float p = valid[u] ? __builtin_amdgcn_exp2f(s - mn) : 0.f;
