@@ -228,8 +228,7 @@ __global__ __launch_bounds__(64) void allreduce_add_rmsnorm_kernel(
       for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  ss = wave_sum(ss);  // the butterfly 32 .. 1 of rmsnorm_kernel<64, ...>
   const float rs = 1.0f / sqrtf(ss / (float)cols + eps);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {

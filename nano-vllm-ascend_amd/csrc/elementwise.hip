@@ -80,8 +80,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
       for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
     }
   }
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  // the butterfly LPR / 2 .. 1 over the row's lanes (DPP / permlane partners, mi_common.hpp: the __shfl_xor bits)
+  if (LPR >= 64) ss = xor_sum<32>(ss);
+  if (LPR >= 32) ss = xor_sum<16>(ss);
+  if (LPR >= 16) ss = xor_sum<8>(ss);
+  if (LPR >= 8) ss = xor_sum<4>(ss);
+  if (LPR >= 4) ss = xor_sum<2>(ss);
+  if (LPR >= 2) ss = xor_sum<1>(ss);
   const float rs = 1.0f / sqrtf(ss / (float)cols + eps);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {

@@ -32,9 +32,9 @@ __device__ __forceinline__ void head_rmsnorm(float (&a)[8], float (&b)[8], const
   for (int i = 0; i < 8; ++i) ss += a[i] * a[i];
 #pragma unroll
   for (int i = 0; i < 8; ++i) ss += b[i] * b[i];
-  ss += __shfl_xor(ss, 1, 64);
-  ss += __shfl_xor(ss, 2, 64);
-  ss += __shfl_xor(ss, 4, 64);
+  ss = xor_sum<1>(ss);  // (DPP partners: the bits of the __shfl_xor butterfly 1, 2, 4 - mi_common.hpp)
+  ss = xor_sum<2>(ss);
+  ss = xor_sum<4>(ss);
   const float rs = 1.0f / sqrtf(ss / 128.0f + eps);
   float wa[8], wb[8];
   load16(w + 8 * j, wa);

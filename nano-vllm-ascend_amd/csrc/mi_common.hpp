@@ -33,15 +33,72 @@ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 // ---- wave-level reductions (64 lanes) --------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// xor_get<O>(v): the value of lane ^ O (O = 1, 2, 4, 8), on the DPP path of the VALU; xor_pair<O>(v, a, b) for O = 16,
+// 32: a and b = (own, partner) in some order (v_permlane16_swap / v_permlane32_swap) - enough for commutative
+// reductions.  The SAME partners in the SAME order as a `__shfl_xor` butterfly, so sums and maxima keep their bits
+// (x + y == y + x), at a few VALU cycles per step: a __shfl_xor is a ds_bpermute - ~100 cycles of LDS crossbar latency
+// per dependent step, six steps per wave reduction, on the critical path of every decode-sized norm launch.
+// All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int O>
+__device__ __forceinline__ float xor_get(float v) {
+  static_assert(O == 1 || O == 2 || O == 4 || O == 8, "in-row partners");
+  if (O == 1) return dpp_mov<0xB1>(v);                 // quad_perm [1, 0, 3, 2]
+  if (O == 2) return dpp_mov<0x4E>(v);                 // quad_perm [2, 3, 0, 1]
+  if (O == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror (i -> 7 - i), then quad_perm [3, 2, 1, 0]
+  return dpp_mov<0x128>(v);                            // row_ror:8
+}
+template <int O>
+__device__ __forceinline__ void xor_pair(float v, float& a, float& b) {
+  static_assert(O == 16 || O == 32, "cross-row partners");
+  if (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+  }
+}
+template <int O>
+__device__ __forceinline__ float xor_sum(float v) {  // v + (value of lane ^ O), the bits of v + __shfl_xor(v, O)
+  if constexpr (O >= 16) {
+    float a, b;
+    xor_pair<O>(v, a, b);
+    return a + b;
+  } else {
+    return v + xor_get<O>(v);
+  }
+}
+template <int O>
+__device__ __forceinline__ float xor_max(float v) {
+  if constexpr (O >= 16) {
+    float a, b;
+    xor_pair<O>(v, a, b);
+    return fmaxf(a, b);
+  } else {
+    return fmaxf(v, xor_get<O>(v));
+  }
+}
+__device__ __forceinline__ float wave_sum(float v) {  // the butterfly 32, 16, 8, 4, 2, 1
+  v = xor_sum<32>(v);
+  v = xor_sum<16>(v);
+  v = xor_sum<8>(v);
+  v = xor_sum<4>(v);
+  v = xor_sum<2>(v);
+  return xor_sum<1>(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = xor_max<32>(v);
+  v = xor_max<16>(v);
+  v = xor_max<8>(v);
+  v = xor_max<4>(v);
+  v = xor_max<2>(v);
+  return xor_max<1>(v);
 }
 
 // ---- counter-based random numbers of the sampler (mi_sample, and the pick epilogue of the head GEMM) ----
