@@ -66,6 +66,26 @@ const char* mi_version(void);
 /* hipGetLastError() text of the most recent MI_ELAUNCH on this thread. */
 const char* mi_last_launch_error(void);
 
+/* ---- process-wide tuning knobs ------------------------------------------------
+ * The entry points never read the process environment: a kernel choice that is not implied by the arguments is
+ * either an explicit parameter of an `_ex` entry point or one of these knobs.  mi_set_tuning() is host-side,
+ * takes effect for launches issued after it returns (a captured hipGraph keeps what it was captured with) and is
+ * the ONLY hidden state of the library; every default is the measured-best path.  Returns MI_EINVAL for an unknown
+ * knob or a value outside its range.  (The Python binding maps its MI355_* A/B environment switches onto these at
+ * import time: nanovllm/_C.py.) */
+enum mi_tuning_knob {
+  MI_TUNE_ATTN_PIPE = 0,          /* mi_paged_attn_decode: 1 (default) = 8 waves x two chunks in flight, 0 = round-1 16-wave form */
+  MI_TUNE_ATTN_RESOLVE = 1,       /* decode attention resolves its block-id run at kernel start (default 0: measured slower)    */
+  MI_TUNE_NORM_WPR = 2,           /* mi_add_rmsnorm_splitk: waves per row for <= 64 rows: 4 (default), 2, 1                     */
+  MI_TUNE_ROPE_BLOCK64 = 3,       /* mi_qknorm_rope_store: one-wave workgroups for <= 64 tokens (default 1)                     */
+  MI_TUNE_PLAIN_SPLIT_TARGET = 4, /* mi_paged_attn_decode_plain: workgroups aimed for when contexts are split (default 512)     */
+  MI_TUNE_PREFILL_P_SPLIT = 5,    /* prefill attention: probabilities as bf16 hi + lo (1) instead of one bf16 (default 0)       */
+  MI_TUNE_COUNT = 6
+};
+int mi_set_tuning(int knob, int value);
+/* current value, or INT32_MIN for an unknown knob */
+int mi_get_tuning(int knob);
+
 /* ---- KV cache: layout helpers ------------------------------------------- */
 /* Element offset of logical (slot_in_block, head, d) inside one block of the
  * K (is_v=0) or V (is_v=1) cache.  Host-side helper used by tests. */
@@ -141,6 +161,22 @@ int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_stride,
                                int batch, int n_q_heads, int n_kv_heads, int head_dim,
                                int block_size, float scale, mi_stream stream);
 
+/* Instrumented form of mi_paged_attn_decode_fused (tools/attn_timeline.py; n_q_heads / n_kv_heads == 2 only): the same
+ * results, and stamps[batch * n_kv_heads * splits][8 waves][8] (uint64, device memory) receives every wave's
+ * s_memtime at: 0 entry, 1 context length known, 2 its first two K/V chunks requested, 3 the step's q / k / v rows
+ * published (workgroup barrier), 4 first chunk consumed, 5 its run of the context attended, 6 all waves arrived,
+ * 7 merged and stored. */
+int mi_paged_attn_decode_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride,
+                                  const mi_bf16* q_w, const mi_bf16* k_w, float eps,
+                                  const int64_t* positions, const float* cos_sin,
+                                  const int32_t* slot_2d,
+                                  mi_bf16* k_cache, mi_bf16* v_cache,
+                                  const int32_t* block_table, int table_stride,
+                                  const int32_t* context_lens,
+                                  mi_bf16* out, void* workspace, size_t ws_bytes,
+                                  int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                                  int block_size, float scale, uint64_t* stamps, mi_stream stream);
+
 /* Tuning entry point (tools/attn_exp.py): mi_paged_attn_decode with an explicit number of context splits
  * per (sequence, kv head) (0 = automatic) and explicit element strides of the cache
  * (block, kv head, 16-token tile). */
@@ -184,8 +220,12 @@ int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_stride, cons
                                 const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs,
                                 int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
                                 int head_dim, int block_size, float scale, mi_stream stream);
-/* Tuning / stress-test form: variant 0 = mi_paged_attn_prefill_fused, variant 1 requests the first two K/V chunks
- * ahead of the Q preparation.  Same results bit for bit (tests). */
+/* Tuning / stress-test form of mi_paged_attn_prefill_fused.  variant 0 = the product kernel; 4 = probabilities
+ * as bf16 hi + lo (what MI_TUNE_PREFILL_P_SPLIT selects process-wide; every group size).  Schedule variants, for
+ * n_q_heads / n_kv_heads == 2 only (the bench model; MI_EUNSUPPORTED otherwise), same results as variant 0 bit for
+ * bit (tests): 1 = the first two K/V chunks requested ahead of the Q preparation; 2 = one workgroup barrier per two
+ * chunks; 8 = round 3's V operand reads (ds_read2st64_b64: LDS bank conflicts); 16 = round 3's request path (table
+ * read + divisions in front of every chunk request); 24 = 8 + 16; 28 = the round-3 kernel as a whole (4 + 8 + 16). */
 int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
                                    const int64_t* positions, const float* cos_sin, const mi_bf16* k_cache,
                                    const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
@@ -311,35 +351,6 @@ int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* resi
                           const mi_bf16* w, mi_bf16* y, mi_bf16* residual_out, int rows,
                           int cols, float eps, mi_stream stream);
 
-/* mi_add_rmsnorm_splitk for the decode chain (rows <= 64, cols <= 1024) with the CUs the norm leaves idle
- * (a launch of `rows` workgroups on a 256-CU part) pulling the packed weights of the launches BEHIND it - the
- * projections this norm feeds (linear.py:73,150 of the same layer) - into the L2 of the XCD that will read them.
- * warmN: mi_pack_weight output (or NULL), warmN_tile_bytes = 32 * K (one 16-row tile), a multiple of 4096.
- * Results are those of mi_add_rmsnorm_splitk bit for bit; only the timing of the following launches changes. */
-int mi_add_rmsnorm_splitk_warm(const float* partials, int nsplit, const mi_bf16* residual,
-                               const mi_bf16* w, mi_bf16* y, mi_bf16* residual_out, int rows,
-                               int cols, float eps, const void* warm0, size_t warm0_bytes,
-                               int warm0_tile_bytes, const void* warm1, size_t warm1_bytes,
-                               int warm1_tile_bytes, mi_stream stream);
-
-/* The warming workgroups of mi_add_rmsnorm_splitk_warm as a launch of their own: n_workgroups (a multiple of 8)
- * workgroups pull the given packed weights into L2.  The tensor-parallel decode path queues it on a forked stream
- * beside mi_allreduce_add_rmsnorm (MI355_SEAM_OVERLAP=1, SURVEY 8(f)1: the all-reduce overlapped with the next
- * projection's weight stream). */
-int mi_warm_l2(const void* warm0, size_t warm0_bytes, int warm0_tile_bytes, const void* warm1,
-               size_t warm1_bytes, int warm1_tile_bytes, int n_workgroups, mi_stream stream);
-
-/* EXPERIMENT, not on the product path (decode chain): the MLP half of a decode layer
- * (layernorm.py:27-38 -> linear.py:73 + activation.py:10-12 -> linear.py:150) as ONE persistent launch of 256
- * workgroups with in-launch hand-offs instead of three launches; bit-identical to
- * mi_add_rmsnorm_splitk + mi_gemm_bf16_packed(epilogue 1) + mi_gemm_bf16_packed_splitk(ksplit 4).
- * hidden 1024, intermediate 3072, 1 <= rows <= 32, partials_in / partials_out [4][rows][1024] fp32;
- * sync_words: 8 x uint32, zeroed once by the caller (word 6 != 0 afterwards: a hand-off timed out). */
-int mi_mlp_half_fused(const float* partials_in, const mi_bf16* residual, const mi_bf16* norm_w, float eps,
-                      const mi_bf16* w_gate_up_packed, const mi_bf16* w_down_packed,
-                      mi_bf16* residual_out, mi_bf16* xn_scratch, mi_bf16* act_scratch,
-                      float* partials_out, uint32_t* sync_words, int rows, int hidden, int intermediate,
-                      mi_stream stream);
 
 /* ---- plain-layout attention (csrc/attn_plain.hip) -------------------------
  * The same operators (attention.py:22-93, rotary_embedding.py:6-14) for the head geometries the fragment-native

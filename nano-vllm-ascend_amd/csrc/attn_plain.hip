@@ -281,10 +281,7 @@ __global__ __launch_bounds__(D) void attn_merge_plain_kernel(const float* __rest
 static int decode_plain_splits(int batch, int n_kv_heads, int max_blocks_hint) {
   (void)max_blocks_hint;
   const int wgs = batch * n_kv_heads;
-  static const int target = [] {
-    const char* e = getenv("MI355_PLAIN_SPLIT_TARGET");
-    return e ? atoi(e) : 512;
-  }();
+  const int target = tuning(MI_TUNE_PLAIN_SPLIT_TARGET);  // 512: measured best of 128 / 256 / 512
   int ns = 1;
   while (wgs * ns < target && ns < 16) ns *= 2;
   return ns;

@@ -1,13 +1,29 @@
 // Library-level entry points of libmi355_nanovllm.so: error reporting, layout
 // helper, and the host-side XXH64 used by the block manager's prefix hashing.
+#include <limits.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 
 #include "mi_common.hpp"
 
 namespace mi {
 static thread_local std::string g_last_launch_error;
+
+// process-wide tuning knobs (include/mi355_nanovllm.h: mi_tuning_knob): {default, min, max}
+static constexpr int kTuneSpec[MI_TUNE_COUNT][3] = {
+    {1, 0, 1},       // MI_TUNE_ATTN_PIPE
+    {0, 0, 1},       // MI_TUNE_ATTN_RESOLVE
+    {4, 1, 4},       // MI_TUNE_NORM_WPR
+    {1, 0, 1},       // MI_TUNE_ROPE_BLOCK64
+    {512, 1, 4096},  // MI_TUNE_PLAIN_SPLIT_TARGET
+    {0, 0, 1},       // MI_TUNE_PREFILL_P_SPLIT
+};
+static std::atomic<int> g_tuning[MI_TUNE_COUNT] = {
+    {kTuneSpec[0][0]}, {kTuneSpec[1][0]}, {kTuneSpec[2][0]}, {kTuneSpec[3][0]}, {kTuneSpec[4][0]}, {kTuneSpec[5][0]}};
+
+int tuning(int knob) { return g_tuning[knob].load(std::memory_order_relaxed); }
 
 int check_launch() {
   const hipError_t e = hipGetLastError();
@@ -27,6 +43,19 @@ extern "C" const char* mi_strerror(int code) {
     case MI_ERUNTIME: return "HIP runtime call failed (allocation / IPC)";
     default: return "unknown error code";
   }
+}
+
+extern "C" int mi_set_tuning(int knob, int value) {
+  if (knob < 0 || knob >= MI_TUNE_COUNT) return MI_EINVAL;
+  if (value < mi::kTuneSpec[knob][1] || value > mi::kTuneSpec[knob][2]) return MI_EINVAL;
+  if (knob == MI_TUNE_NORM_WPR && value == 3) return MI_EINVAL;
+  mi::g_tuning[knob].store(value, std::memory_order_relaxed);
+  return MI_OK;
+}
+
+extern "C" int mi_get_tuning(int knob) {
+  if (knob < 0 || knob >= MI_TUNE_COUNT) return INT_MIN;
+  return mi::tuning(knob);
 }
 
 extern "C" const char* mi_version(void) { return "mi355_nanovllm 0.1.0 gfx950"; }

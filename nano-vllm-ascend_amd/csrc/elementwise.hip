@@ -7,6 +7,9 @@
 #include "mi_common.hpp"
 #include "kv_store.hpp"
 #include "warm_l2.hpp"
+#ifdef MI_EXPERIMENTS
+#include "mi355_nanovllm_experiments.h"
+#endif
 
 namespace mi {
 
@@ -693,6 +696,7 @@ extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const m
                               S(stream));
 }
 
+#ifdef MI_EXPERIMENTS  // include/mi355_nanovllm_experiments.h: measured slower, not in the default build
 // the same as a launch of its own (a forked graph branch beside the tensor-parallel seam, models/qwen3.py)
 static __global__ __launch_bounds__(256) void warm_l2_kernel(const WarmArgs wa) {
   __shared__ __attribute__((aligned(1024))) char scratch[4096];
@@ -759,6 +763,7 @@ extern "C" int mi_add_rmsnorm_splitk_warm(const float* partials, int nsplit, con
   }
 #undef WARM_CASE
 }
+#endif  // MI_EXPERIMENTS
 
 extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* residual, const mi_bf16* w,
                                      mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
@@ -768,11 +773,8 @@ extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi
   if (!aligned16(partials) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
     return MI_EINVAL;
   if (rows == 0) return MI_OK;
-  // decode-sized: WPR waves per row (env MI355_NORM_WPR=1 keeps the one-wave-per-row kernel)
-  static const int wpr = [] {
-    const char* e = getenv("MI355_NORM_WPR");
-    return e ? atoi(e) : 4;
-  }();
+  // decode-sized: WPR waves per row (tuning knob MI_TUNE_NORM_WPR = 1 keeps the one-wave-per-row kernel)
+  const int wpr = tuning(MI_TUNE_NORM_WPR);
   constexpr bool narrow = true;  // four columns per thread when the row fits (24.2 vs 24.5 us per layer chain)
 #define SPLITK_CASE(NS)                                                                                       \
   case NS:                                                                                                    \
@@ -897,10 +899,7 @@ extern "C" int mi_qknorm_rope_store(const mi_bf16* qkv, int64_t qkv_row_stride, 
     return check_launch();
   }
   // decode-sized: one wave per workgroup, so the (token, head) groups spread over four times as many CUs
-  static const int small_blocks = [] {
-    const char* e = getenv("MI355_ROPE_BLOCK64");
-    return e ? atoi(e) : 1;
-  }();
+  const int small_blocks = tuning(MI_TUNE_ROPE_BLOCK64);
   const int threads = (n_tokens <= 64 && small_blocks) ? 64 : 256;
   hipLaunchKernelGGL((qk_rope_store_kernel<0>), dim3((unsigned)((hs * 8 + threads - 1) / threads)), dim3(threads), 0,
                      S(stream), qkv, qkv_row_stride, ksrc, qkv_row_stride, vsrc, qkv_row_stride, q_w, k_w, eps,

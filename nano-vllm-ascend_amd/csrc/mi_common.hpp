@@ -138,6 +138,7 @@ __host__ __device__ __forceinline__ int64_t kv_tile_base(int64_t blk, int h, int
 }
 
 // ---- host-side launch bookkeeping ------------------------------------------
+int tuning(int knob);        // current value of a mi_tuning_knob (c_api.hip; the library never reads the environment)
 int check_launch();          // returns MI_OK or MI_ELAUNCH (records hipGetLastError text)
 inline hipStream_t S(mi_stream s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

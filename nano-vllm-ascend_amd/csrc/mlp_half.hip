@@ -19,6 +19,7 @@
 // wave, waves summed in order): outputs are bit-identical to them, which tests/test_kernels_gpu.py checks.
 // Measured against them: tools/kbench.py KBENCH_ONLY=mlp_half, profiles/r03_mlp_half.txt.
 #include "gemm_skinny_kernel.hpp"
+#include "mi355_nanovllm_experiments.h"
 
 namespace mi {
 

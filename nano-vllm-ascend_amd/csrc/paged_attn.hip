@@ -19,7 +19,7 @@
 // Decode splits each sequence's context over `nsplit` workgroups (flash-decoding)
 // whose ranges are derived on the device from context_lens, so the launch
 // geometry is static and hipGraph-capturable; a second kernel merges the splits.
-#include <stdlib.h>
+#include <limits.h>
 
 #include "mi_common.hpp"
 #include "kv_store.hpp"
@@ -338,13 +338,23 @@ __device__ __forceinline__ void patch_new_token(u32x4 (&K)[4], u32x4 (&V)[4], co
 //   chunk i has been consumed, so every wave keeps 16-32 KiB of loads outstanding while it computes
 //   (the same 256 KiB per CU as the 16-wave form, but no wave ever sits with nothing requested), half
 //   the waves to merge, and register room for the fused step prologue.
-template <int G, int WAVES, bool FUSE, bool PIPE>
+// STAMP (mi_paged_attn_decode_fused_ex, tools/attn_timeline.py): every wave records s_memtime at eight points of its
+// life into stamps[workgroup][wave][8] - where a launch's microseconds go (ramp, steady state, merge tail).  The
+// instrumented instantiation is a separate kernel; the product kernels carry no stamp code.
+template <int G, int WAVES, bool FUSE, bool PIPE, bool STAMP = false>
 __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* kc,
     const uint16_t* vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ ctx_lens, float* __restrict__ part_o, float* __restrict__ part_ml,
-    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, int tpb_shift, int resolve_run, float scale_log2e, FusedStep fs) {
+    uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, int tpb_shift, int resolve_run, float scale_log2e, FusedStep fs,
+    unsigned long long* __restrict__ stamps = nullptr) {
   static_assert(!FUSE || PIPE, "the fused prologue needs the register room of the 8-wave form");
+  unsigned long long ts[8] = {};
+#define MI_STAMP(i)                                        \
+  do {                                                     \
+    if constexpr (STAMP) ts[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  MI_STAMP(0);  // entry
   __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
   __shared__ float sm_m[WAVES][16];
   __shared__ float sm_l[WAVES][16];
@@ -383,6 +393,8 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int32_t* table_row = block_table + (int64_t)b * table_stride;
   const int vw = split * WAVES + wave;
   const int t0 = 2 * deal(vw), t1 = min(n_tiles, 2 * deal(vw + 1));
+  if constexpr (STAMP) asm volatile("" ::"s"(t0), "s"(t1));  // the context length has arrived
+  MI_STAMP(1);
 
   // FUSE: the token of this step sits at position ctx - 1: row new_tok of tile new_tile.  The last wave of
   // the workgroup (never a long run, see deal()) produces the query heads and that token's K / V row in LDS
@@ -494,8 +506,21 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
       load_a();
       if (is_pro) finish_prologue();  // under the latency of buffer A
       load_b();
+      MI_STAMP(2);  // both buffers requested (the prologue wave: and its norm + RoPE done)
       __syncthreads();  // sm_q (sm_k, sm_v) complete; this wave's tile loads are in flight behind the barrier
+      MI_STAMP(3);  // the step's q / k / v rows are published
       load_q(Q);
+      if constexpr (STAMP) {  // the first chunk on its own, so that its end can be stamped
+        if (tb + 4 < t1) {
+          attend_a();
+          MI_STAMP(4);  // first chunk consumed: the first K/V bytes have arrived and been used
+          ta += 4;
+          load_a();
+          attend_b();
+          tb += 4;
+          load_b();
+        }
+      }
       while (tb + 4 < t1) {  // both buffers have a successor
         attend_a();
         ta += 4;
@@ -540,6 +565,8 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
       }
     }
   }
+  if constexpr (STAMP) asm volatile("" ::"v"(acc[0]), "v"(acc[7]));
+  MI_STAMP(5);  // this wave's run is attended
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
 
@@ -552,6 +579,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     }
   }
   __syncthreads();
+  MI_STAMP(6);  // every wave of the workgroup has arrived
   // merge the waves (at least one of them had a chunk, so M is finite; empty ones weigh exp2(-inf) = 0)
   for (int idx = threadIdx.x; idx < G * 128; idx += WAVES * 64) {
     const int hn = idx >> 7, d = idx & 127;
@@ -576,6 +604,15 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
       }
     }
   }
+  if constexpr (STAMP) {
+    MI_STAMP(7);  // merged and stored
+    if (stamps != nullptr && lane == 0) {
+      unsigned long long* dst = stamps + ((((int64_t)b * gridDim.y + h) * splits + split) * WAVES + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = ts[i];
+    }
+  }
+#undef MI_STAMP
 }
 
 // merge the splits (small batches only): one wave per (sequence, q head) row, lane = 2 dims
@@ -635,12 +672,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr float kDeferMax = 8.0f;  // prefill: rescale the running softmax only when a maximum grows by more than 2^8
 
-// P as bf16 hi + lo (two MFMAs per product, fp32-softmax accuracy as in decode).  -DMI_PREFILL_SPLIT_P=0
-// drops the lo part: 118 vs 144 us at 16 x 1024 tokens, output error up to ~1.5 bf16 ulp instead of 0.5.
-#ifndef MI_PREFILL_SPLIT_P
-#define MI_PREFILL_SPLIT_P 1
-#endif
-
+// Probabilities in the second product.  SPLIT_P = false (the default since round 4): P is ONE bf16 per key, as in
+// the reference's own CPU statement of this operator (attention_torch_native.py:80,127,139,188-189 keeps the scale, S
+// and P in bf16; the fp32 running sum l is taken from the un-rounded exponentials): 16 instead of 24 MFMAs and ~50
+// VALU instructions fewer per 32-key chunk in an issue-bound loop.  Bound: |out - fp32 oracle| <= 2^-7 |out| + 1e-4
+// (1 bf16 ulp of the output instead of 1/2; tests/test_kernels_gpu.py).  SPLIT_P = true (tuning knob
+// MI_TUNE_PREFILL_P_SPLIT, the round-1..3 form): P as bf16 hi + lo, two MFMAs per product, <= 1/2 ulp.
 // swap the upper half of `x` with the lower half of a copy: both halves then see (own, partner)
 __device__ __forceinline__ float xor32_max(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -649,6 +686,13 @@ __device__ __forceinline__ float xor32_max(float x) {
 __device__ __forceinline__ float xor32_sum(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// one hand-issued ds_read_b64 at LDS byte address `addr` + OFF (see PV_READ2 below).  NOT counted by hipcc: the caller
+// waits with its own asm s_waitcnt lgkmcnt naming the destination "+v" before the first use.
+template <int OFF>
+__device__ __forceinline__ void lds_read64_uncounted(uint64_t& dst, uint32_t addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
 
 // FUSE_Q: q points at the RAW q heads of the packed qkv rows; q-norm (if q_w) and RoPE are applied while the Q
@@ -660,15 +704,28 @@ struct QPrep {
   float eps;
 };
 
-// EARLY (tuning / stress-test variant, mi_paged_attn_prefill_fused_ex): the first two chunks are requested ahead of
-// the Q preparation instead of behind it.
-// PAIR (tuning variant 2): a ring of four buffers and ONE barrier per TWO chunks.
-template <int G, bool SPLIT_P, bool FUSE_Q, bool EARLY = false, bool PAIR = false>
+// Variant bits VAR (mi_paged_attn_prefill_fused_ex; the product entry points use 0, or PV_SPLIT_P under the tuning knob):
+//   PV_EARLY   the first two chunks are requested ahead of the Q preparation instead of behind it (stress test)
+//   PV_PAIR    a ring of four buffers and ONE barrier per TWO chunks (measured slower in round 3)
+//   PV_SPLIT_P P as bf16 hi + lo (see above)
+//   PV_READ2   round 3's V operand reads: the two 8-byte pieces of a fragment through ordinary loads, which hipcc
+//              merges into ONE ds_read2st64_b64 - an instruction served in 16-lane groups on 32 banks, where this
+//              layout (16-byte lane stride) is a 2-way conflict: 16 LDS cycles per fragment, 38.6 % of all LDS cycles
+//              of the kernel (profiles/r03_prefill_attention_pmc.txt: SQ_LDS_BANK_CONFLICT 8.65 M = 8 extra cycles x
+//              8 instructions x 16.5 chunks x 8192 waves, to the digit).  Default now: two un-merged ds_read_b64
+//              (32-lane groups on 64 banks: the same addresses are conflict-free, 2 cycles each).
+//   PV_NOPREF  round 3's block-table read: s_load + s_waitcnt right in front of every chunk request.  Default now: the
+//              block id of the NEXT request is read one chunk ahead, so the wait finds it landed.
+enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16 };
+
+template <int G, bool FUSE_Q, int VAR = 0>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ kv_lens, uint16_t* __restrict__ out,
     int n_q_heads, int n_kv_heads, int tpb, int tpb_shift, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
+  constexpr bool EARLY = (VAR & PV_EARLY) != 0, PAIR = (VAR & PV_PAIR) != 0, SPLIT_P = (VAR & PV_SPLIT_P) != 0;
+  constexpr bool READ2 = (VAR & PV_READ2) != 0, PREF = !(VAR & PV_NOPREF) && !PAIR;
   constexpr int TQ = 32 / G;        // query tokens per wave
   constexpr int TQ_WG = 4 * TQ;     // per workgroup
   constexpr int NBUF = PAIR ? 4 : 3;  // LDS ring: chunk c is computed while c+1 and c+2 are landing
@@ -743,19 +800,24 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   // away (tiles per block are a power of two for every block size but 48, 80, ...: shifts, not divisions - the
   // request of a chunk is ~40 scalar instructions shorter, and the loop is issue-bound)
   const uint16_t* const cache_h = ((piece & 2) ? vc : kc) + (int64_t)h * st.head + lane * 8;
-  auto issue = [&](int c) {
-    c = min(c, wg_chunks - 1);  // past the end: re-load the last chunk into a buffer nobody reads (keeps vmcnt uniform)
-    const int tile0 = 2 * c;
-    const int tile = (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
-    const int blk = table_row[tpb_shift >= 0 ? tile >> tpb_shift : tile / tpb];
+  // the cache tile this wave fetches for chunk c (past the end: the last chunk again, into a buffer nobody reads -
+  // keeps the vmcnt arithmetic uniform), and the block-table entry that holds it
+  auto tile_of = [&](int c) {
+    const int tile0 = 2 * min(c, wg_chunks - 1);
+    return (piece & 1) ? ((tile0 + 1 < wg_tiles) ? tile0 + 1 : tile0) : tile0;
+  };
+  auto block_of = [&](int tile) { return table_row[tpb_shift >= 0 ? tile >> tpb_shift : tile / tpb]; };
+  auto issue_from = [&](int c, int blk) {
+    const int tile = tile_of(c);
     const int in_block = tpb_shift >= 0 ? tile & (tpb - 1) : tile % tpb;
     const uint16_t* src = cache_h + (int64_t)blk * st.block + (int64_t)in_block * st.tile;
-    uint16_t* dst = &stage[c % NBUF][piece][0];
+    uint16_t* dst = &stage[min(c, wg_chunks - 1) % NBUF][piece][0];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
                                        (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
   };
+  auto issue = [&](int c) { issue_from(c, block_of(tile_of(c))); };
 
   // LDS element offsets of this lane's operand pieces inside a tile
   //   K (A of the first product): key n (tile n / 16, token n % 16), dims 16 kk + 8 hi .. +7
@@ -785,9 +847,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   // (Scores one chunk ahead of the softmax - the eight dependent score MFMAs of chunk c + 1 in the basic block of
   // chunk c's exponentials, a fourth ring buffer - was built and measured in round 3: 145-147 us against 137-139
   // for this form at 16 x 1024 tokens; removed.)
-  auto attend = [&](int c) __attribute__((always_inline)) {
+  auto attend = [&](int c, int buf) __attribute__((always_inline)) {  // buf = c % NBUF
     if (c < wave_chunks) {
-      const int buf = c % NBUF;
       const uint16_t* kt = &stage[buf][n >> 4][k_off];
       f32x16 s;
 #pragma unroll
@@ -837,17 +898,53 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         ph[i >> 2][i & 3] = hw;
         if (SPLIT_P) pl[i >> 2][i & 3] = pack_bf(p[2 * i] - lo_bf(hw), p[2 * i + 1] - hi_bf(hw));
       }
+      if (READ2) {
 #pragma unroll
-      for (int sgm = 0; sgm < 2; ++sgm) {
-        const uint16_t* vt = &stage[buf][2 + sgm][v_off];
+        for (int sgm = 0; sgm < 2; ++sgm) {
+          const uint16_t* vt = &stage[buf][2 + sgm][v_off];
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vt + db * 512);
-          const u32x2 a1 = *reinterpret_cast<const u32x2*>(vt + db * 512 + 256);
-          const u32x4 a = {a0[0], a0[1], a1[0], a1[1]};
-          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(ph[sgm]), acc[db], 0, 0, 0);
-          if (SPLIT_P)
-            acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(pl[sgm]), acc[db], 0, 0, 0);
+          for (int db = 0; db < 4; ++db) {
+            const u32x2 a0 = *reinterpret_cast<const u32x2*>(vt + db * 512);
+            const u32x2 a1 = *reinterpret_cast<const u32x2*>(vt + db * 512 + 256);
+            const u32x4 a = {a0[0], a0[1], a1[0], a1[1]};
+            acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(ph[sgm]), acc[db], 0, 0, 0);
+            if (SPLIT_P)
+              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(pl[sgm]), acc[db], 0, 0, 0);
+          }
+        }
+      } else {
+        // The V operand by hand-issued ds_read_b64 (hipcc would pair two ordinary loads into a ds_read2st64_b64, see
+        // PV_READ2; a volatile access loses the LDS address space).  hipcc does not count an asm load (guide 5.7): the
+        // data is waited for by the asm s_waitcnt below, which names every destination "+v" so that no consumer can
+        // be scheduled above it; LDS operations return in order, so the compiler's own lgkmcnt waits (its K reads of
+        // the next chunk) only become more conservative by these.  Both key segments are requested up front - 16
+        // reads in flight under the exponentials - and waited for segment by segment (lgkmcnt(8), then 0).
+        uint64_t va[2][4][2];
+        const uint32_t vaddr = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)&stage[buf][2][v_off];
+#define MI_V_READ(SG, DB)                                                          \
+  lds_read64_uncounted<(SG) * 4096 + (DB) * 1024>(va[SG][DB][0], vaddr);           \
+  lds_read64_uncounted<(SG) * 4096 + (DB) * 1024 + 512>(va[SG][DB][1], vaddr)
+        MI_V_READ(0, 0); MI_V_READ(0, 1); MI_V_READ(0, 2); MI_V_READ(0, 3);
+        MI_V_READ(1, 0); MI_V_READ(1, 1); MI_V_READ(1, 2); MI_V_READ(1, 3);
+#undef MI_V_READ
+#pragma unroll
+        for (int sgm = 0; sgm < 2; ++sgm) {
+          if (sgm == 0)
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]), "+v"(va[0][2][0]),
+                           "+v"(va[0][2][1]), "+v"(va[0][3][0]), "+v"(va[0][3][1]));
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(va[1][0][0]), "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1]), "+v"(va[1][2][0]),
+                           "+v"(va[1][2][1]), "+v"(va[1][3][0]), "+v"(va[1][3][1]));
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const u32x4 a = {(uint32_t)va[sgm][db][0], (uint32_t)(va[sgm][db][0] >> 32), (uint32_t)va[sgm][db][1],
+                             (uint32_t)(va[sgm][db][1] >> 32)};
+            acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(ph[sgm]), acc[db], 0, 0, 0);
+            if (SPLIT_P)
+              acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(pl[sgm]), acc[db], 0, 0, 0);
+          }
         }
       }
     }
@@ -859,16 +956,59 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       issue(c + 2);
       issue(c + 3);
-      attend(c);
-      if (c + 1 < wg_chunks) attend(c + 1);
+      attend(c, c % NBUF);
+      if (c + 1 < wg_chunks) attend(c + 1, (c + 1) % NBUF);
     }
-  } else {
+  } else if (!PREF) {
     for (int c = 0; c < wg_chunks; ++c) {
       // this wave's pieces of chunk c have landed (those of c+1 may still fly); after the barrier
       // everybody's have, and everybody is done reading chunk c-1, whose buffer chunk c+2 re-uses
       asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       issue(c + 2);
-      attend(c);
+      attend(c, c % NBUF);
+    }
+  } else {
+    // The same loop with the request side kept as running state - no division, no modulo, no table read in front
+    // of a request (the round-3 form spends ~90 scalar instructions per chunk and wave on them, and the scalar unit
+    // is shared by the CU's twelve waves).  Request r (= min(c + 2, wg_chunks - 1), i.e. saturating: past the end
+    // the last chunk is requested again into its own slot, which keeps the vmcnt arithmetic uniform) fetches tile
+    // rq_t = min(2 r + odd, t_max) = block-table entry rq_bi, tile rq_in of that block, into ring slot rq_slot;
+    // rq_blk is the block id, read one iteration AHEAD of its use (a scalar-cache read: lgkmcnt, not vmcnt).
+    const int odd = piece & 1, r_last = wg_chunks - 1;
+    const int t_max = min(2 * r_last + odd, wg_tiles - 1);
+    int rq = min(2, r_last), rq_slot = rq % NBUF, rq_t = min(2 * rq + odd, t_max);
+    int rq_bi = tpb_shift >= 0 ? rq_t >> tpb_shift : rq_t / tpb, rq_in = rq_t - rq_bi * tpb;
+    int rq_blk = table_row[rq_bi];
+    int rd_slot = 0;
+    for (int c = 0; c < wg_chunks; ++c) {
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      {
+        // (a block is n_kv_heads x tpb x 4 KiB: its element stride fits 32 bits, one s_mul_i32 + s_mul_hi_i32)
+        const uint16_t* src = cache_h + (int64_t)rq_blk * (int)st.block + rq_in * MI_KV_TILE_ELEMS;
+        uint16_t* dst = &stage[0][piece][0] + rq_slot * (4 * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
+                                           (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
+      }
+      if (rq < r_last) {  // advance the request state to chunk rq + 1 (wave-uniform)
+        ++rq;
+        rq_slot = rq_slot + 1 == NBUF ? 0 : rq_slot + 1;
+        const int t_new = min(rq_t + 2, t_max);
+        rq_in += t_new - rq_t;
+        rq_t = t_new;
+        if (rq_in >= tpb) {
+          rq_in -= tpb;
+          ++rq_bi;
+        }
+        if (rq_in >= tpb) {  // tpb == 1: two blocks further
+          rq_in -= tpb;
+          ++rq_bi;
+        }
+        rq_blk = table_row[rq_bi];  // used by the NEXT iteration: a whole chunk of compute to land in
+      }
+      attend(c, rd_slot);
+      rd_slot = rd_slot + 1 == NBUF ? 0 : rd_slot + 1;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two padding loads
@@ -941,7 +1081,7 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
                        const int32_t* block_table, int table_stride, const int32_t* context_lens, mi_bf16* out,
                        void* workspace, size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
                        int block_size, float scale, int num_splits, KvStrides kvs, mi_stream stream,
-                       const FusedStep* fused = nullptr) {
+                       const FusedStep* fused = nullptr, unsigned long long* stamps = nullptr) {
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -951,9 +1091,8 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   if (ws_bytes < mi_paged_attn_decode_workspace(batch, n_q_heads)) return MI_EWORKSPACE;
   const int G = n_q_heads / n_kv_heads;
   // geometry: 0 = 16 waves, one chunk per wave in flight; 1 = 8 waves, two chunks per wave in flight.
-  // The fused entry point always uses 1; MI355_ATTN_PIPE (0/1) selects it for the plain one.
-  const char* pipe_env = getenv("MI355_ATTN_PIPE");  // read per call (a host-side getenv; captured graphs keep their choice)
-  const bool pipe = fused != nullptr || !pipe_env || atoi(pipe_env) != 0;
+  // The fused entry point always uses 1; the tuning knob MI_TUNE_ATTN_PIPE (default 1) selects it for the plain one.
+  const bool pipe = fused != nullptr || tuning(MI_TUNE_ATTN_PIPE) != 0;
   const int waves = pipe ? 8 : decode_waves(G);
   int nsplit = num_splits > 0 ? num_splits : decode_splits(batch, n_kv_heads, pipe ? 16 : waves);
   if (nsplit > 16) nsplit = 16;
@@ -964,12 +1103,11 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   int tpb_shift = -1;  // log2 of the tiles per block, or -1 (division) for block sizes like 48
   for (int sft = 0; sft < 12; ++sft)
     if ((1 << sft) == tpb_host) tpb_shift = sft;
-  // A/B knob, read per call: 1 = a wave resolves its whole run of block ids once (vector load + v_readlane).  Measured
+  // MI_TUNE_ATTN_RESOLVE = 1: a wave resolves its whole run of block ids once (vector load + v_readlane).  Measured
   // SLOWER than reading the ids through the scalar cache per chunk (26.07 vs 25.70 us for the fused step at ctx 1100,
   // interleaved rounds, profiles/r03_kbench_attention.txt): the first tile loads then wait for a vector load instead
   // of a scalar one.  Default off.
-  const char* resolve_env = getenv("MI355_ATTN_RESOLVE");
-  const int resolve_run = resolve_env && atoi(resolve_env) != 0;
+  const int resolve_run = tuning(MI_TUNE_ATTN_RESOLVE) != 0;
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
   const FusedStep fs = fused ? *fused : FusedStep{};
@@ -981,6 +1119,17 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   if (fused) LAUNCH_DEC_AS(GG, 8, true, true);   \
   else if (pipe) LAUNCH_DEC_AS(GG, 8, false, true); \
   else LAUNCH_DEC_AS(GG, WW, false, false)
+  if (stamps != nullptr) {  // the instrumented kernel: the bench model's geometry only
+    if (!fused || G != 2) return MI_EUNSUPPORTED;
+    hipLaunchKernelGGL((paged_attn_decode_kernel<2, 8, true, true, true>), grid, dim3(8 * 64), 0, st, q, q_row_stride,
+                       k_cache, v_cache, block_table, table_stride, context_lens, part_o, part_ml, out, n_q_heads, kvs,
+                       block_size / 16, tpb_shift, resolve_run, sl2, fs, stamps);
+    rc = check_launch();
+    if (rc != MI_OK || nsplit == 1) return rc;
+    hipLaunchKernelGGL(paged_attn_merge_kernel, dim3((batch * n_q_heads + 3) / 4), dim3(256), 0, st, part_o, part_ml, out,
+                       batch * n_q_heads, nsplit);
+    return check_launch();
+  }
   switch (G) {
     case 1: LAUNCH_DEC(1, 16); break;
     case 2: LAUNCH_DEC(2, 16); break;
@@ -1024,6 +1173,26 @@ extern "C" int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_st
                      default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream, &fs);
 }
 
+// instrumented form of mi_paged_attn_decode_fused (tools/attn_timeline.py): stamps[batch * n_kv_heads * splits][8 waves][8]
+// receives every wave's s_memtime at entry / context length known / tile loads requested / step rows published /
+// first chunk consumed / run attended / workgroup arrived / merged and stored.  Same results as the product kernel.
+extern "C" int mi_paged_attn_decode_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w,
+                                             const mi_bf16* k_w, float eps, const int64_t* positions,
+                                             const float* cos_sin, const int32_t* slot_2d, mi_bf16* k_cache,
+                                             mi_bf16* v_cache, const int32_t* block_table, int table_stride,
+                                             const int32_t* context_lens, mi_bf16* out, void* workspace,
+                                             size_t ws_bytes, int batch, int n_q_heads, int n_kv_heads, int head_dim,
+                                             int block_size, float scale, uint64_t* stamps, mi_stream stream) {
+  if (!positions || !cos_sin || !slot_2d || !stamps) return MI_EINVAL;
+  if ((q_w == nullptr) != (k_w == nullptr)) return MI_EINVAL;
+  if (!aligned16(cos_sin) || (q_w && (!aligned16(q_w) || !aligned16(k_w)))) return MI_EINVAL;
+  const FusedStep fs{q_w, k_w, positions, cos_sin, slot_2d, eps};
+  return decode_impl(qkv, qkv_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out,
+                     workspace, ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, 0,
+                     default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream, &fs,
+                     reinterpret_cast<unsigned long long*>(stamps));
+}
+
 // tuning entry point: explicit split count and cache strides (tools/attn_exp.py)
 extern "C" int mi_paged_attn_decode_ex(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_cache,
                                        const mi_bf16* v_cache, const int32_t* block_table, int table_stride,
@@ -1041,7 +1210,9 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
                         const int32_t* cu_seqlens_q, const int32_t* kv_lens, int n_seqs, int max_seqlen_q,
                         mi_bf16* out, int n_q_heads, int n_kv_heads, int head_dim, int block_size, float scale,
                         mi_stream stream, int variant = 0) {
-  const bool early = variant == 1, pair = variant == 2;
+  if (variant < 0) return MI_EUNSUPPORTED;
+  // P as one bf16 (default) or as bf16 hi + lo (variant bit / process-wide tuning knob)
+  const bool split_p = (variant & PV_SPLIT_P) || tuning(MI_TUNE_PREFILL_P_SPLIT) != 0;
   int rc = check_attn_common(q, k_cache, v_cache, block_table, n_q_heads, n_kv_heads, head_dim, block_size,
                              q_row_stride);
   if (rc != MI_OK) return rc;
@@ -1050,6 +1221,7 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   if (!aligned16(out)) return MI_EINVAL;
   if (n_seqs == 0 || max_seqlen_q == 0) return MI_OK;
   const int G = n_q_heads / n_kv_heads;
+  if ((int64_t)n_kv_heads * (block_size / 16) * MI_KV_TILE_ELEMS > INT32_MAX) return MI_EUNSUPPORTED;  // 32-bit block stride
   const int tq_wg = 4 * (32 / G);  // query tokens per workgroup
   const int n_qblocks = (max_seqlen_q + tq_wg - 1) / tq_wg, n_pairs = n_seqs * n_kv_heads;
   const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8 * n_qblocks));
@@ -1058,27 +1230,32 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   for (int sft = 0; sft < 12; ++sft)
     if ((1 << sft) == block_size / 16) tpb_shift = sft;
   hipStream_t st = S(stream);
-  constexpr bool kSplitP = MI_PREFILL_SPLIT_P;
   const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
-#define LAUNCH_PRE(GG)                                                                                          \
-  do {                                                                                                          \
-    if (prep && pair)                                                                                           \
-      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true, false, true>), grid, dim3(256), 0, st, q, \
-                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
-                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
-    else if (prep && early)                                                                                     \
-      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true, true>), grid, dim3(256), 0, st, q,        \
-                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
-                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
-    else if (prep)                                                                                              \
-      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, true>), grid, dim3(256), 0, st, q, q_row_stride, \
-                         k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads,     \
-                         n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);                  \
-    else                                                                                                        \
-      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, kSplitP, false>), grid, dim3(256), 0, st, q,             \
-                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, \
-                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);       \
+#define LAUNCH_PRE_AS(GG, FQ, VV)                                                                                  \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, FQ, VV>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,   \
+                     v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads, n_kv_heads,       \
+                     block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp)
+  // every group size: {raw q rows, q prepared in the kernel} x {P as one bf16, P as hi + lo}
+#define LAUNCH_PRE(GG)                                                       \
+  do {                                                                       \
+    if (prep && split_p) LAUNCH_PRE_AS(GG, true, PV_SPLIT_P);                \
+    else if (prep) LAUNCH_PRE_AS(GG, true, 0);                               \
+    else if (split_p) LAUNCH_PRE_AS(GG, false, PV_SPLIT_P);                  \
+    else LAUNCH_PRE_AS(GG, false, 0);                                        \
   } while (0)
+  if (variant & ~PV_SPLIT_P) {  // schedule variants: the bench model's group size only (tools/kbench.py, the stress test)
+    if (!prep || G != 2) return MI_EUNSUPPORTED;
+    switch (variant) {
+      case PV_EARLY: LAUNCH_PRE_AS(2, true, PV_EARLY); break;
+      case PV_PAIR: LAUNCH_PRE_AS(2, true, PV_PAIR); break;
+      case PV_READ2: LAUNCH_PRE_AS(2, true, PV_READ2); break;
+      case PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_NOPREF); break;
+      case PV_READ2 | PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_READ2 | PV_NOPREF); break;
+      case PV_SPLIT_P | PV_READ2 | PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_SPLIT_P | PV_READ2 | PV_NOPREF); break;  // round 3
+      default: return MI_EUNSUPPORTED;
+    }
+    return check_launch();
+  }
   switch (G) {
     case 1: LAUNCH_PRE(1); break;
     case 2: LAUNCH_PRE(2); break;
@@ -1087,6 +1264,7 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
     default: LAUNCH_PRE(16); break;
   }
 #undef LAUNCH_PRE
+#undef LAUNCH_PRE_AS
   return check_launch();
 }
 
@@ -1120,7 +1298,6 @@ extern "C" int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_ro
                                               int max_seqlen_q, mi_bf16* out, int n_q_heads, int n_kv_heads,
                                               int head_dim, int block_size, float scale, int variant, mi_stream stream) {
   if (!positions || !cos_sin || !aligned16(cos_sin) || (q_w && !aligned16(q_w))) return MI_EINVAL;
-  if (variant < 0 || variant > 2) return MI_EUNSUPPORTED;
   const QPrep prep{q_w, positions, cos_sin, eps};
   return prefill_impl(qkv, qkv_row_stride, &prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
                       n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, head_dim, block_size, scale, stream, variant);

@@ -50,6 +50,8 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "mi_strerror": (c_char_p, [c_int]),
     "mi_version": (c_char_p, []),
+    "mi_set_tuning": (c_int, [c_int, c_int]),
+    "mi_get_tuning": (c_int, [c_int]),
     "mi_last_launch_error": (c_char_p, []),
     "mi_kv_elem_offset": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi_reshape_and_cache": (c_int, [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
@@ -64,6 +66,11 @@ _SIGNATURES = {
         c_int,
         [_p, c_int64, _p, _p, c_float, _p, _p, _p, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int,
          c_int, c_int, c_float, _p],
+    ),
+    "mi_paged_attn_decode_fused_ex": (
+        c_int,
+        [_p, c_int64, _p, _p, c_float, _p, _p, _p, _p, _p, _p, c_int, _p, _p, _p, c_size_t, c_int, c_int, c_int,
+         c_int, c_int, c_float, _p, _p],
     ),
     "mi_paged_attn_decode_ex": (
         c_int,
@@ -110,10 +117,6 @@ _SIGNATURES = {
                                            c_int, c_int, c_float, _p]),
     "mi_paged_attn_prefill_plain": (c_int, [_p, c_int64, _p, _p, _p, c_int, _p, _p, c_int, c_int, _p, c_int, c_int,
                                             c_int, c_int, c_float, _p]),
-    "mi_warm_l2": (c_int, [_p, c_size_t, c_int, _p, c_size_t, c_int, c_int, _p]),
-    "mi_mlp_half_fused": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
-    "mi_add_rmsnorm_splitk_warm": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, c_size_t, c_int, _p,
-                                           c_size_t, c_int, _p]),
     "mi_embedding": (c_int, [_p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
     "mi_embedding_from_prev": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
     "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),
@@ -156,6 +159,47 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch: fail loudly
     _fn.restype = _res
     _fn.argtypes = _args
+
+# measured-and-lost experiments (include/mi355_nanovllm_experiments.h): present only in a library built with
+# `make EXPERIMENTS=1`; the product path never calls them
+_EXPERIMENT_SIGNATURES = {
+    "mi_warm_l2": (c_int, [_p, c_size_t, c_int, _p, c_size_t, c_int, c_int, _p]),
+    "mi_mlp_half_fused": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_add_rmsnorm_splitk_warm": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, c_size_t, c_int, _p,
+                                           c_size_t, c_int, _p]),
+}
+HAS_EXPERIMENTS = all(hasattr(lib, _n) for _n in _EXPERIMENT_SIGNATURES)
+if HAS_EXPERIMENTS:
+    for _name, (_res, _args) in _EXPERIMENT_SIGNATURES.items():
+        _fn = getattr(lib, _name)
+        _fn.restype = _res
+        _fn.argtypes = _args
+
+# ---- tuning knobs (include/mi355_nanovllm.h: mi_tuning_knob).  The library never reads the environment; the A/B
+# switches documented in tools/README.md are mapped onto mi_set_tuning() here, once, at import.
+TUNE_ATTN_PIPE, TUNE_ATTN_RESOLVE, TUNE_NORM_WPR, TUNE_ROPE_BLOCK64, TUNE_PLAIN_SPLIT_TARGET, TUNE_PREFILL_P_SPLIT = range(6)
+_ENV_KNOBS = {
+    "MI355_ATTN_PIPE": TUNE_ATTN_PIPE,
+    "MI355_ATTN_RESOLVE": TUNE_ATTN_RESOLVE,
+    "MI355_NORM_WPR": TUNE_NORM_WPR,
+    "MI355_ROPE_BLOCK64": TUNE_ROPE_BLOCK64,
+    "MI355_PLAIN_SPLIT_TARGET": TUNE_PLAIN_SPLIT_TARGET,
+    "MI355_PREFILL_P_SPLIT": TUNE_PREFILL_P_SPLIT,
+}
+
+
+def set_tuning(knob: int, value: int) -> None:
+    if lib.mi_set_tuning(int(knob), int(value)) != MI_OK:
+        raise ValueError(f"mi_set_tuning({knob}, {value}): unknown knob or value out of range")
+
+
+def get_tuning(knob: int) -> int:
+    return lib.mi_get_tuning(int(knob))
+
+
+for _env, _knob in _ENV_KNOBS.items():
+    if os.environ.get(_env) is not None:
+        set_tuning(_knob, int(os.environ[_env]))
 
 
 if os.environ.get("MI355_TRACE"):  # debugging aid: name each launch, make faults synchronous

@@ -250,7 +250,8 @@ class Qwen3Model(nn.Module):
         return ks
 
     def _forward_streaming(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
-        """<= 64 tokens (every decode step): SEVEN launches per layer (the reference's eager decode layer
+        """<= ops.SKINNY_MAX_M (512) tokens - every decode step, and short prefills - in chunks of 64 rows inside the
+        kernels: SEVEN launches per layer (the reference's eager decode layer
         is ~13):
           add+RMSNorm (summing the previous projection's split-K partials)      (mi_add_rmsnorm_splitk)
           -> packed qkv GEMM                                                     (mi_gemm_bf16_packed)
@@ -302,10 +303,16 @@ class Qwen3Model(nn.Module):
                 y = all_reduce_sum(y)
             return y, ("ranks" if fused_seam else False)
 
-        # measured: 1.52-1.54 ms per decode step with the warming, 1.50-1.51 without (bench, same box, alternating):
-        # off unless asked for ("first": only the column-parallel projection's weights)
+        # EXPERIMENT (nanovllm/experiments.py, library built with EXPERIMENTS=1): the norm launch's idle CUs warm L2 with
+        # the next GEMMs' weights.  Measured: 1.52-1.54 ms per decode step with it, 1.50-1.51 without: off unless asked
+        # for ("first": only the column-parallel projection's weights)
         warm_l2 = os.environ.get("MI355_WARM_L2", "0") != "0"
         warm_n = 1 if os.environ.get("MI355_WARM_L2") == "first" else 2
+        overlap_env = os.environ.get("MI355_SEAM_OVERLAP", "0") != "0"
+        if warm_l2 or overlap_env:
+            from nanovllm import experiments
+
+            experiments.require()
 
         def add_norm(y, is_partials, res, ln, warm=()):
             """is_partials: True = fp32 split-K partials of this rank (TP 1); "ranks" = bf16 partial sums that
@@ -313,8 +320,10 @@ class Qwen3Model(nn.Module):
             warm: the linear layers this norm feeds - the norm launch (rows workgroups on 256 CUs) pulls their
             packed weights into L2 with its idle CUs."""
             if is_partials is True:
-                return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps,
-                                              warm=[m.weight_packed for m in warm][:warm_n] if warm_l2 else ())
+                if warm_l2:
+                    return experiments.add_rmsnorm_splitk_warm(y, res, ln.weight, ln.eps,
+                                                               [m.weight_packed for m in warm][:warm_n])
+                return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps)
             if is_partials == "ranks":  # all-reduce over xGMI + add + RMSNorm in one launch
                 return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
             return ops.add_rmsnorm(y, res, ln.weight, ln.eps)
@@ -335,7 +344,7 @@ class Qwen3Model(nn.Module):
         # weights beside mi_allreduce_add_rmsnorm and joins before the column-parallel GEMM.  Off by default: on one GPU
         # the same warming inside the norm launch measured slower (MI355_WARM_L2); whether the longer seam on links
         # changes that is for the 8-GPU box to say.
-        overlap = fused_seam and os.environ.get("MI355_SEAM_OVERLAP", "0") != "0"
+        overlap = fused_seam and overlap_env
         side = _seam_stream(h.device) if overlap else None
 
         def norm_linear(y, is_partials, res, ln, lin, silu_mul=False, then=None):
@@ -345,7 +354,7 @@ class Qwen3Model(nn.Module):
                 main = torch.cuda.current_stream()
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    ops.warm_l2([m.weight_packed for m in ((lin,) if then is None else (lin, then))])
+                    experiments.warm_l2([m.weight_packed for m in ((lin,) if then is None else (lin, then))])
             x, res = add_norm(y, is_partials, res, ln, warm=(lin,) if then is None else (lin, then))
             if forked:
                 main.wait_stream(side)

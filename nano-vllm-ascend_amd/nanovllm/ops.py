@@ -129,6 +129,30 @@ def paged_attn_decode_fused(qkv, q_w, k_w, eps: float, positions, cos_sin, slots
     return out
 
 
+def paged_attn_decode_fused_stamped(qkv, q_w, k_w, eps: float, positions, cos_sin, slots_2d, k_cache, v_cache,
+                                    block_tables, context_lens, n_q_heads: int, n_kv_heads: int, block_size: int,
+                                    scale: float, stamps, out=None, workspace=None) -> torch.Tensor:
+    """paged_attn_decode_fused through the instrumented kernel (mi_paged_attn_decode_fused_ex): `stamps`
+    [batch * n_kv_heads * splits, 8 waves, 8] int64 receives every wave's s_memtime at eight points of its life."""
+    require_gpu(qkv, positions, cos_sin, slots_2d, k_cache, v_cache, block_tables, context_lens, stamps)
+    _bf16(qkv, k_cache, v_cache, q_w, k_w)
+    batch = qkv.shape[0]
+    assert stamps.dtype == torch.int64 and stamps.is_contiguous() and stamps.numel() >= batch * n_kv_heads * 16 * 64
+    if out is None:
+        out = torch.empty((batch, n_q_heads * HEAD_DIM), dtype=_BF16, device=qkv.device)
+    if workspace is None:
+        workspace = attn_workspace(qkv.device, batch, n_q_heads)
+    check(
+        lib.mi_paged_attn_decode_fused_ex(ptr(qkv), qkv.stride(0), ptr(q_w), ptr(k_w), float(eps), ptr(positions),
+                                          ptr(cos_sin), ptr(slots_2d), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                          block_tables.stride(0), ptr(context_lens), ptr(out), ptr(workspace),
+                                          workspace.numel() * workspace.element_size(), batch, n_q_heads, n_kv_heads,
+                                          HEAD_DIM, block_size, float(scale), ptr(stamps), stream()),
+        "mi_paged_attn_decode_fused_ex",
+    )
+    return out
+
+
 def paged_attn_prefill(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens, max_seqlen_q: int,
                        n_q_heads: int, n_kv_heads: int, block_size: int, scale: float, out=None) -> torch.Tensor:
     require_gpu(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
@@ -564,41 +588,7 @@ def gemm_packed_splitk(x, w_packed, ksplit: int, out=None) -> torch.Tensor:
     return out
 
 
-def warm_l2(weights, n_workgroups: int = 64) -> None:
-    """queue a launch that pulls up to two packed bf16 weights ([N, K], mi_pack_weight) into L2 (mi_warm_l2)"""
-    ws = [t for t in weights if isinstance(t, torch.Tensor) and t.dtype == _BF16 and t.dim() == 2
-          and (32 * t.shape[1]) % 4096 == 0 and t.numel() * 2 < (1 << 32)][:2]
-    if not ws:
-        return
-    require_gpu(*ws)
-    w0, w1 = ws[0], (ws[1] if len(ws) > 1 else None)
-    check(lib.mi_warm_l2(ptr(w0), w0.numel() * 2, 32 * w0.shape[1], ptr(w1), w1.numel() * 2 if w1 is not None else 0,
-                         32 * w1.shape[1] if w1 is not None else 0, n_workgroups, stream()), "mi_warm_l2")
-
-
-def mlp_half_fused(partials, residual, norm_w, eps: float, w_gate_up_packed, w_down_packed, sync_words, scratch=None):
-    """EXPERIMENT (csrc/mlp_half.hip): add+RMSNorm -> gate_up+SwiGLU -> down split-K as one persistent launch.
-    -> (fp32 partials [4, rows, hidden], new residual); sync_words: 8 zeroed int32 on the device, kept across calls."""
-    require_gpu(partials, residual, norm_w, w_gate_up_packed, w_down_packed, sync_words)
-    _bf16(residual, norm_w, w_gate_up_packed, w_down_packed)
-    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[0] == 4
-    rows, hidden = residual.shape
-    inter = w_down_packed.shape[1]
-    assert sync_words.dtype == torch.int32 and sync_words.numel() >= 8
-    if scratch is None:
-        scratch = (torch.empty_like(residual), torch.empty(rows, hidden, dtype=_BF16, device=residual.device),
-                   torch.empty(rows, inter, dtype=_BF16, device=residual.device),
-                   torch.empty(4, rows, hidden, dtype=torch.float32, device=residual.device))
-    res_out, xn, act, out = scratch
-    check(lib.mi_mlp_half_fused(ptr(partials), ptr(residual), ptr(norm_w), float(eps), ptr(w_gate_up_packed),
-                                ptr(w_down_packed), ptr(res_out), ptr(xn), ptr(act), ptr(out), ptr(sync_words), rows,
-                                hidden, inter, stream()), "mi_mlp_half_fused")
-    return out, res_out
-
-
-def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out=None, warm=()):
-    """warm: up to two packed bf16 weights ([N, K], mi_pack_weight) of the GEMMs behind this norm; decode-sized
-    inputs then use the launch's idle CUs to pull them into L2 (mi_add_rmsnorm_splitk_warm)."""
+def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out=None):
     require_gpu(partials, residual, w)
     _bf16(residual, w)
     assert partials.dtype == torch.float32 and partials.is_contiguous() and residual.is_contiguous()
@@ -608,18 +598,6 @@ def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out
         out = torch.empty_like(residual)
     if residual_out is None:
         residual_out = torch.empty_like(residual)
-    warm = [t for t in warm if isinstance(t, torch.Tensor) and t.dtype == _BF16 and t.dim() == 2
-            and (32 * t.shape[1]) % 4096 == 0 and t.numel() * 2 < (1 << 32)]
-    if warm and rows <= 64 and cols <= 1024 and cols % 4 == 0:
-        w0, w1 = warm[0], (warm[1] if len(warm) > 1 else None)
-        check(
-            lib.mi_add_rmsnorm_splitk_warm(ptr(partials), nsplit, ptr(residual), ptr(w), ptr(out), ptr(residual_out),
-                                           rows, cols, float(eps), ptr(w0), w0.numel() * 2, 32 * w0.shape[1],
-                                           ptr(w1), w1.numel() * 2 if w1 is not None else 0,
-                                           32 * w1.shape[1] if w1 is not None else 0, stream()),
-            "mi_add_rmsnorm_splitk_warm",
-        )
-        return out, residual_out
     check(
         lib.mi_add_rmsnorm_splitk(ptr(partials), nsplit, ptr(residual), ptr(w), ptr(out), ptr(residual_out), rows,
                                   cols, float(eps), stream()),

@@ -10,6 +10,8 @@ import torch
 from conftest import bf16_from_bits as bf
 from model_configs import QWEN3_32B_2L, MID, MID_LLAMA_HD64, TINY, TINY_LLAMA, TINY_LLAMA_HD64, TINY_MOE, TINY_QWEN2_HD64, make_model_dir
 
+from nanovllm._C import HAS_EXPERIMENTS as _HAS_EXPERIMENTS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -336,6 +338,7 @@ def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, w
         assert (logits1 - logits2).abs().max().item() <= tol
 
 
+@pytest.mark.skipif(not _HAS_EXPERIMENTS, reason="library built without -DMI_EXPERIMENTS")
 def test_tp_seam_overlap_branch_keeps_the_tokens(monkeypatch):
     """MI355_SEAM_OVERLAP=1: a forked graph branch warms L2 with the next projections' weights beside
     the fused all-reduce + add + RMSNorm seam.  Two ranks on one GPU, hipGraph decode: the same tokens as without it."""
