@@ -13,7 +13,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nano-vllm-ascend_amd"))
-from nanovllm import ops  # noqa: E402
+from nanovllm import _C, ops  # noqa: E402
 
 DEV = torch.device("cuda:0")
 PEAK = 8.0e12
@@ -65,8 +65,8 @@ def prefill_attention():
 
 
 def prefill_attention_order():
-    """The fused-Q prefill attention (q-norm + RoPE in the Q-operand load) with the first two K/V chunks requested
-    behind the Q preparation (the default) and ahead of it (variant 1), alternating rounds."""
+    """The fused-Q prefill attention (q-norm + RoPE in the Q-operand load) in every variant of its _ex entry point,
+    alternating rounds (KBENCH_ONLY=prefill_order)."""
     n, T, bs, hq, hkv, L = 16, int(os.environ.get("CTX", 1024)), 16, 16, 8, 4
     nb = (T + bs - 1) // bs
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -82,22 +82,34 @@ def prefill_attention_order():
     out = torch.empty(n * T, hq * 128, device=DEV).bfloat16()
     cu = (torch.arange(n + 1, dtype=torch.int32) * T).to(DEV)
     kvl = torch.full((n,), T, dtype=torch.int32, device=DEV)
-    res = {"requests behind the Q preparation (default)": [], "requests ahead of it (variant 1)": [],
-           "one barrier per two chunks, ring of four (variant 2)": []}
-    for rnd in range(4):
-        for name, v in (("requests behind the Q preparation (default)", None), ("requests ahead of it (variant 1)", 1),
-                        ("one barrier per two chunks, ring of four (variant 2)", 2)):
+    # variant bits of mi_paged_attn_prefill_fused_ex (include/mi355_nanovllm.h)
+    variants = (("default (P bf16, un-merged V reads, running request state)", 0),
+                ("P as bf16 hi + lo (4)", 4),
+                ("round-3 V reads: ds_read2st64_b64 (8)", 8),
+                ("round-3 request path: table read + divisions per chunk (16)", 16),
+                ("both round-3 forms, P bf16 (24)", 24),
+                ("the round-3 kernel as a whole: P hi + lo (28)", 28),
+                ("requests ahead of the Q preparation (1)", 1),
+                ("one barrier per two chunks, ring of four (2)", 2))
+    res = {name: [] for name, _ in variants}
+    for rnd in range(int(os.environ.get("ROUNDS", 4))):
+        for name, v in variants:
             t = timeit(lambda l: ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[l], vc[l], tables, cu, kvl, T,
                                                               hq, hkv, bs, 128 ** -0.5, out=out, variant=v), L)
             res[name].append(round(t * 1e6, 1))
-    print(f"fused-Q prefill attention 16x{T}, us per launch, four alternating rounds:")
+    flops = n * hq * (T * (T + 1) / 2) * 128 * 2 * 2
+    print(f"fused-Q prefill attention 16x{T}, us per launch, alternating rounds ({flops / 1e9:.1f} GFLOP useful per launch):")
     for k, v in res.items():
-        print(f"  {k}: {v}")
+        best = min(v)
+        print(f"  {k}: {v}   best {flops / best / 1e6:.0f} TFLOP/s")
 
 
 def mlp_half():
     """the MLP half of a Qwen3-0.6B decode layer (bs 32) as three launches and as ONE persistent
     launch with in-launch hand-offs (csrc/mlp_half.hip), over 4 rotating layers' weights, alternating rounds."""
+    from nanovllm import experiments  # needs the library built with EXPERIMENTS=1
+
+    experiments.require()
     B, H, I, L = 32, 1024, 3072, 4
     gu = [ops.pack_weight((torch.randn(2 * I, H, device=DEV) * 0.02).bfloat16()) for _ in range(L)]
     dn = [ops.pack_weight((torch.randn(H, I, device=DEV) * 0.02).bfloat16()) for _ in range(L)]
@@ -114,7 +126,7 @@ def mlp_half():
         return ops.gemm_packed_splitk(a, dn[l], 4), r
 
     def fused(l):
-        return ops.mlp_half_fused(parts, res_, nw, 1e-6, gu[l], dn[l], sync, scratch)
+        return experiments.mlp_half_fused(parts, res_, nw, 1e-6, gu[l], dn[l], sync, scratch)
 
     p3, r3 = three(0)
     pf, rf = fused(0)
@@ -305,11 +317,11 @@ def main():
         byt2 = B * 2 * c2 * hkv * 128 * 2
         res[f"paged_attn_decode ctx={c2}"] = {"us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
 
-    # geometry A/B (MI355_ATTN_PIPE is read per call; a captured graph keeps its choice) and the fused step
-    os.environ["MI355_ATTN_PIPE"] = "0"
+    # geometry A/B (tuning knob; a captured graph keeps its choice) and the fused step
+    _C.set_tuning(_C.TUNE_ATTN_PIPE, 0)
     t = timeit(lambda l: ops.paged_attn_decode(q, kc[l], vc[l], perm, ctxl, hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
     res["paged_attn_decode 16 waves (r01)"] = {"us": t * 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
-    os.environ["MI355_ATTN_PIPE"] = "1"
+    _C.set_tuning(_C.TUNE_ATTN_PIPE, 1)
     qkv_ = torch.randn(B, (hq + 2 * hkv) * 128, device=DEV).bfloat16()
     w128 = torch.ones(128, device=DEV).bfloat16()
     rope_t = torch.randn(4096, 128, device=DEV)
@@ -338,12 +350,12 @@ def main():
     byt2 = B * 2 * c2 * hkv * 128 * 2
     for rnd in range(3):
         for mode in ("0", "1"):
-            os.environ["MI355_ATTN_RESOLVE"] = mode
+            _C.set_tuning(_C.TUNE_ATTN_RESOLVE, int(mode))
             t = timeit(lambda l: ops.paged_attn_decode_fused(qkv_, w128, w128, 1e-6, pos2, rope_t, sl2, kc[l], vc[l], perm2, ctx2,
                                                              hq, hkv, bs, 128 ** -0.5, out=out, workspace=ws), L)
             res[f"fused step ctx=1100 {'run resolved   ' if mode == '1' else 'table per chunk'} #{rnd}"] = {
                 "us": t * 1e6, "GB/s": byt2 / t / 1e9, "frac": byt2 / t / PEAK}
-    os.environ["MI355_ATTN_RESOLVE"] = "0"
+    _C.set_tuning(_C.TUNE_ATTN_RESOLVE, 0)
 
     if os.environ.get("KBENCH_ONLY") == "attn":
         for k, v in res.items():

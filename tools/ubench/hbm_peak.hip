@@ -76,5 +76,21 @@ int main() {
   const size_t part = (size_t)128 << 20;
   double t7 = timeit([&] { for (int l = 0; l < 16; ++l) hipLaunchKernelGGL((read_runs_kernel<false>), dim3((int)(part / 16 / 1024 / 4)), dim3(256), 0, 0, src + l * (part / 16), sink, part / 16); }, 5);
   printf("128 MiB launches back to back: %6.0f GB/s (%.1f us per launch)\n", 16.0 * part / t7 / 1e9, t7 / 16 * 1e6);
+  // the same 128 MiB region every launch: resident in the 256 MiB Infinity Cache after the first pass.  Can the cache
+  // feed a launch of this size faster than HBM does (is a K/V prefetch of layer L + 1 under layer
+  // L's latency-bound chain worth a second look)?
+  for (int nt = 0; nt < 2; ++nt) {
+    auto one = [&] {
+      if (nt) hipLaunchKernelGGL((read_runs_kernel<true>), dim3((int)(part / 16 / 1024 / 4)), dim3(256), 0, 0, src, sink, part / 16);
+      else hipLaunchKernelGGL((read_runs_kernel<false>), dim3((int)(part / 16 / 1024 / 4)), dim3(256), 0, 0, src, sink, part / 16);
+    };
+    double t8 = timeit([&] { for (int l = 0; l < 16; ++l) one(); }, 5);
+    printf("128 MiB launches, SAME region (Infinity-Cache resident), %s: %6.0f GB/s (%.1f us per launch)\n",
+           nt ? "nt   " : "plain", 16.0 * part / t8 / 1e9, t8 / 16 * 1e6);
+  }
+  // 32 MiB: resident in the eight 4 MiB L2s (each XCD sees 1/8 of the workgroups but any address: mostly NOT L2 hits)
+  const size_t small = (size_t)32 << 20;
+  double t9 = timeit([&] { for (int l = 0; l < 16; ++l) hipLaunchKernelGGL((read_runs_kernel<true>), dim3((int)(small / 16 / 1024 / 4)), dim3(256), 0, 0, src, sink, small / 16); }, 5);
+  printf("32 MiB launches, same region: %6.0f GB/s (%.1f us per launch)\n", 16.0 * small / t9 / 1e9, t9 / 16 * 1e6);
   return 0;
 }
