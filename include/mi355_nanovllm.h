@@ -163,7 +163,7 @@ int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_stride,
 
 /* Instrumented form of mi_paged_attn_decode_fused (tools/attn_timeline.py; n_q_heads / n_kv_heads == 2 only): the same
  * results, and stamps[batch * n_kv_heads * splits][8 waves][8] (uint64, device memory) receives every wave's
- * s_memtime at: 0 entry, 1 context length known, 2 its first two K/V chunks requested, 3 the step's q / k / v rows
+ * s_memrealtime (the chip-wide 100 MHz clock) at: 0 entry, 1 context length known, 2 its first two K/V chunks requested, 3 the step's q / k / v rows
  * published (workgroup barrier), 4 first chunk consumed, 5 its run of the context attended, 6 all waves arrived,
  * 7 merged and stored. */
 int mi_paged_attn_decode_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride,

@@ -338,8 +338,8 @@ __device__ __forceinline__ void patch_new_token(u32x4 (&K)[4], u32x4 (&V)[4], co
 //   chunk i has been consumed, so every wave keeps 16-32 KiB of loads outstanding while it computes
 //   (the same 256 KiB per CU as the 16-wave form, but no wave ever sits with nothing requested), half
 //   the waves to merge, and register room for the fused step prologue.
-// STAMP (mi_paged_attn_decode_fused_ex, tools/attn_timeline.py): every wave records s_memtime at eight points of its
-// life into stamps[workgroup][wave][8] - where a launch's microseconds go (ramp, steady state, merge tail).  The
+// STAMP (mi_paged_attn_decode_fused_ex, tools/attn_timeline.py): every wave records s_memrealtime (the chip-wide 100 MHz
+// reference clock: s_memtime's cycle counters are not aligned between compute units) at eight points of its life into stamps[workgroup][wave][8] - where a launch's microseconds go (ramp, steady state, merge tail).  The
 // instrumented instantiation is a separate kernel; the product kernels carry no stamp code.
 template <int G, int WAVES, bool FUSE, bool PIPE, bool STAMP = false>
 __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   unsigned long long ts[8] = {};
 #define MI_STAMP(i)                                        \
   do {                                                     \
-    if constexpr (STAMP) ts[i] = __builtin_amdgcn_s_memtime(); \
+    if constexpr (STAMP) ts[i] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
   MI_STAMP(0);  // entry
   __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
@@ -1174,7 +1174,7 @@ extern "C" int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_st
 }
 
 // instrumented form of mi_paged_attn_decode_fused (tools/attn_timeline.py): stamps[batch * n_kv_heads * splits][8 waves][8]
-// receives every wave's s_memtime at entry / context length known / tile loads requested / step rows published /
+// receives every wave's s_memrealtime (100 MHz) at entry / context length known / tile loads requested / step rows published /
 // first chunk consumed / run attended / workgroup arrived / merged and stored.  Same results as the product kernel.
 extern "C" int mi_paged_attn_decode_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w,
                                              const mi_bf16* k_w, float eps, const int64_t* positions,

@@ -133,7 +133,7 @@ def paged_attn_decode_fused_stamped(qkv, q_w, k_w, eps: float, positions, cos_si
                                     block_tables, context_lens, n_q_heads: int, n_kv_heads: int, block_size: int,
                                     scale: float, stamps, out=None, workspace=None) -> torch.Tensor:
     """paged_attn_decode_fused through the instrumented kernel (mi_paged_attn_decode_fused_ex): `stamps`
-    [batch * n_kv_heads * splits, 8 waves, 8] int64 receives every wave's s_memtime at eight points of its life."""
+    [batch * n_kv_heads * splits, 8 waves, 8] int64 receives every wave's s_memrealtime (100 MHz) at eight points of its life."""
     require_gpu(qkv, positions, cos_sin, slots_2d, k_cache, v_cache, block_tables, context_lens, stamps)
     _bf16(qkv, k_cache, v_cache, q_w, k_w)
     batch = qkv.shape[0]
@@ -451,19 +451,20 @@ def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | 
     return out
 
 
-_GEMM_WS: dict[torch.device, torch.Tensor] = {}
+_GEMM_WS: dict[tuple, torch.Tensor] = {}
 _GEMM_WS_RETIRED: list[torch.Tensor] = []
 
 
 def _gemm_workspace(device, nbytes: int) -> torch.Tensor:
-    """split-K partial sums of the tile GEMM (one buffer per device, grown on demand; launches on one stream are
-    ordered, so consecutive GEMMs may share it)"""
-    ws = _GEMM_WS.get(device)
+    """split-K partial sums of the tile GEMM (one buffer per device AND stream, grown on demand; launches on one
+    stream are ordered, so consecutive GEMMs may share it - the prefill micro-batches of ModelRunner run on two)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)  # per stream: two streams never share partial sums
+    ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:  # a captured graph may hold the old buffer's address: it stays allocated
             _GEMM_WS_RETIRED.append(ws)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _GEMM_WS[device] = ws
+        _GEMM_WS[key] = ws
     return ws
 
 

@@ -2,11 +2,10 @@
 """Where the microseconds of ONE decode attention launch go ("first measure").
 
 Runs the fused decode-attention step of the bench (Qwen3-0.6B heads, bs 32, block 16, ctx from the environment)
-through the instrumented kernel (mi_paged_attn_decode_fused_ex): every wave stamps s_memtime at eight points.  The
+through the instrumented kernel (mi_paged_attn_decode_fused_ex): every wave stamps s_memrealtime (the chip-wide 100 MHz clock) at eight points.  The
 launch is replayed over 28 distinct caches (nothing served from the Infinity Cache); the stamps of the LAST launch are
 reduced to, per phase, the distribution over the 2048 waves (256 workgroups x 8) of
     time since the EARLIEST wave's entry (the launch's own clock)  and  phase durations.
-s_memtime ticks at the shader clock; the kernel's duration from HIP events gives the tick length.
 
 usage: python tools/attn_timeline.py   [CTX=1100]"""
 import os
@@ -73,14 +72,16 @@ def main():
     launch(L - 1, False)
     torch.cuda.synchronize()
     ts = stamps[: B * hkv].cpu().numpy().astype(np.int64)  # [workgroup][wave][8] of the last stamped launch (layer L-1)
+    # the stamps are s_memrealtime: the chip-wide 100 MHz reference clock (10 ns per tick) - s_memtime's shader-cycle
+    # counters are not aligned between compute units, so only a common clock puts 2048 waves on one time axis
     t0 = ts[:, :, 0].min()
     rel = ts - t0
     span = rel[:, :, 7].max()
-    tick_us = us_stamped / span  # the launch's duration also holds dispatch and drain: an upper bound of the tick
+    tick_us = 0.01  # 100 MHz
     byt = B * 2 * ctx * hkv * 128 * 2
     print(f"decode attention fused step, bs {B} x ctx {ctx}, {byt / 1e6:.1f} MB of K/V per launch")
     print(f"  product kernel {us_plain:.2f} us per launch ({byt / us_plain / 1e6:.2f} TB/s), instrumented kernel {us_stamped:.2f} us")
-    print(f"  first entry -> last wave done: {span} ticks; at most {tick_us * 1e3:.3f} ns per tick (~{1e-3 / tick_us:.2f} GHz)")
+    print(f"  first wave's entry -> last wave done: {span * tick_us:.2f} us (stamps: s_memrealtime, 10 ns per tick)")
     print("  time since the earliest wave's entry [us]:   min     p10     p50     p90     max")
     for i, name in enumerate(NAMES):
         v = rel[:, :, i].reshape(-1) * tick_us
