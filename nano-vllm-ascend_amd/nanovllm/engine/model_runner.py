@@ -68,7 +68,13 @@ class ModelRunner:
         local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
         self.device = torch.device("cuda", local)
         torch.cuda.set_device(self.device)
-        if self.world_size > 1 and not dist.is_initialized():
+        from nanovllm.layers import parallel
+
+        # MI355_TP1_COLLECTIVES=1 (layers/parallel.py): a one-rank engine that takes every RCCL code path of a
+        # tensor-parallel rank - the bring-up check of the "nccl" branches on a single GPU
+        self.collective = self.world_size > 1 or os.environ.get("MI355_TP1_COLLECTIVES", "0") == "1"
+        self._own_group = False
+        if self.collective and not dist.is_initialized():
             # backend "nccl" is RCCL on ROCm; rendezvous on the loopback interface.
             # MI355_DIST_BACKEND=gloo lets several ranks share one GPU (functional TP tests on a
             # 1-GPU box; not capturable into graphs).
@@ -76,7 +82,8 @@ class ModelRunner:
             kw = {"device_id": self.device} if backend == "nccl" else {}
             dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{config.hccl_port}",
                                     world_size=self.world_size, rank=rank, **kw)
-        from nanovllm.layers import parallel
+            self._own_group = True
+        parallel.set_force_collectives(self.collective and self.world_size == 1)
 
         # the TP group is what Config says, not whatever process group happens to exist: independent replicas
         # (bench.py --mode replicas) share a default group only for their barrier
@@ -118,11 +125,12 @@ class ModelRunner:
             self.synthetic = True
         self.model.eval()
         self.sampler = Sampler(seed=config.sampling_seed)
-        if self.world_size > 1:
+        if self.collective:
             # every rank draws the sampler's noise for its vocabulary shard: one seed (rank 0's; a seed of None is
             # drawn from os.urandom per process) and one step counter, advanced in lockstep (run / launch_decode)
             seed = torch.tensor([self.sampler.seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64,
                                 device=self.device if dist.get_backend() == "nccl" else "cpu")
+            parallel.STATS["rccl_broadcast"] += dist.get_backend() == "nccl"
             dist.broadcast(seed, 0)
             self.sampler.seed = int(seed.item())
         # parity hook under tensor parallelism: gather the full logits to rank 0 although the graph already holds
@@ -137,9 +145,9 @@ class ModelRunner:
         self.graph_logits: dict[int, torch.Tensor] = {}
         # with TP the captured graph holds the xGMI exchange kernels; without them (RCCL all-reduce inside)
         # capture is only attempted on the nccl backend
-        if self.world_size > 1:
+        if self.collective:
             dist.barrier()  # weight loading can skew the ranks by more than the exchange kernels' patience
-        if config.use_graphs and (self.world_size == 1 or self.xgmi is not None or dist.get_backend() == "nccl"):
+        if config.use_graphs and (not self.collective or self.xgmi is not None or dist.get_backend() == "nccl"):
             try:
                 self.capture_decode_graphs()
             except Exception as e:  # e.g. a collective that refuses stream capture: run eagerly instead
@@ -149,7 +157,7 @@ class ModelRunner:
                 self.graphs.clear()
                 self.graph_logits.clear()
                 reset_context()
-        if self.world_size > 1:
+        if self.collective:
             dist.barrier()
 
     def _check_supported_shapes(self):
@@ -185,6 +193,7 @@ class ModelRunner:
         from nanovllm.layers import parallel
 
         parallel.reset_tp()
+        parallel.set_force_collectives(False)
         self.graphs.clear()
         self.graph_logits.clear()
         torch.cuda.synchronize()
@@ -200,7 +209,7 @@ class ModelRunner:
                 parallel.set_xgmi_comm(None)
             self.xgmi.close()
             self.xgmi = None
-        if self.world_size > 1 and dist.is_initialized():
+        if self.collective and dist.is_initialized() and (self.world_size > 1 or self._own_group):
             dist.destroy_process_group()
 
     def loop(self):
@@ -243,7 +252,7 @@ class ModelRunner:
         if cfg.num_kvcache_blocks <= 0:
             available = total * cfg.gpu_memory_utilization - used - peak + current
             cfg.num_kvcache_blocks = int(available) // block_bytes
-            if self.world_size > 1:
+            if self.collective:
                 # rank 0's scheduler hands out block ids to every rank: all ranks must allocate the same
                 # number of blocks, i.e. what the rank with the least free memory can hold (the reference
                 # sizes per rank, model_runner.py:195-214, and would index past the smaller caches)

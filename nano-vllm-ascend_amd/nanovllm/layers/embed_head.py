@@ -7,7 +7,8 @@ from torch import nn
 
 from nanovllm import ops
 from nanovllm.layers.linear import pack_for_decode, linear_forward
-from nanovllm.layers.parallel import all_reduce_sum, get_xgmi_comm, tp_rank, tp_size
+from nanovllm.layers import parallel
+from nanovllm.layers.parallel import all_reduce_sum, collectives_on, get_xgmi_comm, tp_rank, tp_size
 from nanovllm.utils.context import get_context
 
 
@@ -59,7 +60,9 @@ class ParallelLMHead(VocabParallelEmbedding):
         if self.weight_packed is None:
             return False
         # tensor parallelism: the ranks pick among themselves over the exchange region (bf16 shards only)
-        return self.tp_size == 1 or (get_xgmi_comm() is not None and not isinstance(self.weight_packed, ops.Fp8Weight))
+        if self.tp_size == 1:
+            return not collectives_on()  # (the one-rank bring-up hook behaves like ranks without the exchange region)
+        return get_xgmi_comm() is not None and not isinstance(self.weight_packed, ops.Fp8Weight)
 
     def local_logits_pick(self, x: torch.Tensor, temperatures: torch.Tensor, rng: torch.Tensor,
                           out_tokens: torch.Tensor) -> torch.Tensor:
@@ -84,10 +87,11 @@ class ParallelLMHead(VocabParallelEmbedding):
         """Vocabulary shards -> rank 0 (embed_head.py:62-65); None on the other ranks.  A collective of the
         process group (RCCL), kept outside captured graphs - as the reference keeps compute_logits
         outside its compiled graph (model_runner.py:394-396)."""
-        if self.tp_size == 1:
+        if not collectives_on():
             return logits
         if dist.get_backend() == "nccl":
             parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+            parallel.STATS["rccl_gather"] += 1
             dist.gather(logits, parts, 0)
             return torch.cat(parts, -1) if self.tp_rank == 0 else None
         # gloo has no device-side gather: place the shard in a zero buffer and sum (tests only)

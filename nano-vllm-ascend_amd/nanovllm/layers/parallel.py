@@ -43,6 +43,27 @@ def divide(numerator: int, denominator: int) -> int:
     return numerator // denominator
 
 
+# ---- collectives on a group of ONE rank (a hardware-bring-up hook) -------------------------
+# Every branch that calls RCCL (`dist.get_backend() == "nccl"`) is otherwise reachable only with several GPUs.  With
+# MI355_TP1_COLLECTIVES=1 a tensor_parallel_size == 1 engine creates an RCCL group of world size 1 and takes the
+# collective code paths it would take as one of n ranks whose xGMI exchange is unavailable: RCCL all-reduce behind the
+# embedding and every row-parallel projection (eager prefill AND inside the captured decode graphs), the logits
+# gather to rank 0, the device-side seed broadcast / MIN all-reduce of the start-up handshake.  On one rank every
+# collective is the identity, so the tokens are those of the plain engine - and the calls are real RCCL launches.
+_force_collectives = False
+STATS = {"rccl_all_reduce": 0, "rccl_gather": 0, "rccl_broadcast": 0}  # counted per CALL SITE execution (tests)
+
+
+def set_force_collectives(on: bool) -> None:
+    global _force_collectives
+    _force_collectives = bool(on)
+
+
+def collectives_on() -> bool:
+    """True when the layers must exchange partial results: several TP ranks, or the one-rank bring-up hook."""
+    return tp_size() > 1 or _force_collectives
+
+
 _xgmi = None  # layers/xgmi_comm.XgmiComm once the runner has set it up and its self-test passed
 
 
@@ -59,8 +80,9 @@ def all_reduce_sum(t):
     """C1/C2 of SURVEY.md §2.2: SUM over the TP ranks, in place.  Decode-sized bf16 vectors take
     the one-shot xGMI kernel (mi_allreduce_sum_bf16, hipGraph-capturable, one launch); everything
     else (prefill-sized activations) the RCCL all-reduce."""
-    if tp_size() > 1:
+    if collectives_on():
         if _xgmi is not None and _xgmi.fits(t):
             return _xgmi.all_reduce(t)
+        STATS["rccl_all_reduce"] += 1
         dist.all_reduce(t)
     return t

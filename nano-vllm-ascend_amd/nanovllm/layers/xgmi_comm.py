@@ -133,6 +133,9 @@ class XgmiComm:
             winner = (self.world - 1 - row) % self.world  # the rank whose key is world - 1
             ok = ok and bool(torch.equal(toks, 1000 * winner + row))
             ok = ok and not self.timed_out()
+            # fault injection for tests: "the self-test failed on rank k" must end with EVERY rank on the RCCL path
+            if os.environ.get("MI355_XGMI_SELFTEST_FAIL_RANK") == str(self.rank):
+                ok = False
             check(lib.mi_comm_set_spin_limit(self._comm, 1 << 26), "mi_comm_set_spin_limit")
         except Exception as e:  # noqa: BLE001 - any failure means "do not use this path"
             warnings.warn(f"xGMI all-reduce self-test raised {e!r}")

@@ -21,7 +21,7 @@ from nanovllm.layers.attention import Attention
 from nanovllm.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
 from nanovllm.layers.layernorm import RMSNorm
 from nanovllm.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
-from nanovllm.layers.parallel import all_reduce_sum, get_xgmi_comm, tp_size
+from nanovllm.layers.parallel import all_reduce_sum, collectives_on, get_xgmi_comm, tp_size
 from nanovllm.layers.rotary_embedding import get_rope
 from nanovllm.utils.context import get_context
 
@@ -264,6 +264,7 @@ class Qwen3Model(nn.Module):
         when that path is off.  Rounding points are those of the module-by-module path in every variant
         (tests require equal results up to fp32 summation order)."""
         tp = tp_size()
+        exchange = collectives_on()  # several ranks (or the one-rank bring-up hook, layers/parallel.py)
         ctx = get_context()
         h = self.embed_tokens(input_ids)
         rows = h.shape[0]
@@ -295,11 +296,11 @@ class Qwen3Model(nn.Module):
             """-> (tensor, is_partials): bf16 rows, or fp32 split-K partials for add_rmsnorm_splitk"""
             if rows4 and lin.weight_rows4 is not None:
                 y = ops.gemm_rows4(x, lin.weight_rows4)
-            elif tp == 1:
+            elif not exchange:
                 return ops.gemm_packed_splitk(x, lin.weight_packed, self._ksplit(lin.weight)), True
             else:
                 y = ops.gemm_packed(x, lin.weight_packed)  # this rank's bf16 partial sums
-            if tp > 1 and not fused_seam:
+            if exchange and not fused_seam:
                 y = all_reduce_sum(y)
             return y, ("ranks" if fused_seam else False)
 

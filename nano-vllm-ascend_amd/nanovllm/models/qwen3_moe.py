@@ -18,7 +18,7 @@ from torch import nn
 
 from nanovllm import ops
 from nanovllm.layers.linear import linear_forward
-from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
+from nanovllm.layers.parallel import all_reduce_sum, collectives_on, divide, tp_rank, tp_size
 from nanovllm.models.qwen3 import Qwen3DecoderLayer, Qwen3ForCausalLM
 
 
@@ -80,7 +80,7 @@ class Qwen3MoeSparseMoeBlock(nn.Module):
         x = x.reshape(-1, shape[-1])
         logits = linear_forward(x, self.gate.weight, None, self.gate_packed)  # bf16 router logits (:151)
         out, _, _ = ops.moe_forward(x.contiguous(), logits, self.gate_up_packed, self.down_packed, self.top_k,
-                                    all_reduce=all_reduce_sum if tp_size() > 1 else None)
+                                    all_reduce=all_reduce_sum if collectives_on() else None)
         return out.view(shape)
 
 

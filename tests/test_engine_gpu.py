@@ -638,3 +638,97 @@ def test_bench_ranks_on_one_gpu(mode, ranks):
         assert tp is not None and "error" not in tp, tp
         assert tp["value"] > 0 and tp["tp"]["world_seen"] == ranks and tp["tp"]["backend"] == "gloo"
         assert tp["roofline"]["bound"] == "hbm" and tp["roofline"].get("per_rank") and tp["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("model", ["MID", "TINY_MOE"])
+def test_rccl_code_paths_on_a_one_rank_group(monkeypatch, model):
+    """every `nccl`-only branch has so far been dead code on every box (the TP tests on one GPU
+    talk over gloo).  MI355_TP1_COLLECTIVES=1 makes a tensor_parallel_size == 1 engine create an RCCL group of world
+    size 1 and behave like a TP rank whose xGMI exchange is unavailable: device-side seed broadcast and MIN all-reduce
+    at start-up, RCCL all-reduce behind the embedding and every row-parallel projection in the eager prefill AND
+    inside the captured decode graphs (hipGraph capture of RCCL kernels), dist.gather + cat of the logits, sampler on
+    rank 0.  One rank's collectives are the identity: same greedy tokens as the plain engine."""
+    import socket
+
+    from nanovllm import LLM, SamplingParams
+    from nanovllm.layers import parallel
+
+    cfg = {"MID": MID, "TINY_MOE": TINY_MOE}[model]
+    gen = torch.Generator().manual_seed(17)
+    vocab = cfg["vocab_size"]
+    prompts = [torch.randint(0, vocab - 1, (n,), generator=gen).tolist() for n in (9, 33, 70, 600)]
+    sp = SamplingParams(max_tokens=6, ignore_eos=True, greedy=True)
+
+    def run(forced):
+        monkeypatch.setenv("MI355_TP1_COLLECTIVES", "1" if forced else "0")
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        before = dict(parallel.STATS)
+        llm = LLM(make_model_dir(cfg), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+                  max_model_len=1024, num_kvcache_blocks=128, enforce_eager=False, warmup=False, synthetic_seed=3,
+                  hccl_port=port)
+        try:
+            mr = llm.model_runner
+            assert mr.graphs, "decode graphs were not captured"
+            if forced:
+                import torch.distributed as dist
+
+                assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+                assert not mr.graph_samples  # the graphs end in the logits: gather + sampler outside, as under TP
+                captured = parallel.STATS["rccl_all_reduce"] - before["rccl_all_reduce"]
+                assert captured > 0, "no RCCL all-reduce was issued while the decode graphs were captured"
+            toks = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+            return toks, {k: parallel.STATS[k] - before[k] for k in before}
+        finally:
+            llm.exit()
+
+    plain, stats0 = run(False)
+    forced, stats1 = run(True)
+    assert stats0 == {"rccl_all_reduce": 0, "rccl_gather": 0, "rccl_broadcast": 0}
+    assert stats1["rccl_broadcast"] == 1 and stats1["rccl_gather"] >= 6 and stats1["rccl_all_reduce"] > 10, stats1
+    agree = sum(int(a == b) for x, y in zip(plain, forced) for a, b in zip(x, y))
+    total = sum(len(x) for x in plain)
+    # the row-parallel projections round their bf16 output before the add (split-K partials are summed in fp32 on the
+    # plain path): a near-tie may flip
+    assert agree >= total - 1, (plain, forced)
+    import torch.distributed as dist
+
+    assert not dist.is_initialized()  # the engine tore its group down
+
+
+def test_tp_xgmi_self_test_failure_on_one_rank_puts_every_rank_on_the_collective_path(monkeypatch):
+    """Fault injection (MI355_XGMI_SELFTEST_FAIL_RANK): rank 1's start-up self-test of the xGMI exchange "fails"; both
+    ranks must agree to drop the exchange region (no rank may wait in an exchange kernel for a peer that uses the
+    process-group all-reduce), decode eagerly over the process group, and still produce the TP = 1 tokens."""
+    import socket
+
+    from nanovllm import LLM, SamplingParams
+
+    gen = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in (9, 33, 70)]
+    sp = SamplingParams(max_tokens=6, ignore_eos=True, greedy=True)
+
+    def run(tp):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+                  max_model_len=512, num_kvcache_blocks=64, enforce_eager=False, warmup=False, synthetic_seed=3,
+                  tensor_parallel_size=tp, hccl_port=port)
+        try:
+            if tp > 1:
+                assert llm.model_runner.xgmi is None
+                assert llm.model_runner.xgmi_selftest == "self-test failed: RCCL all-reduce"
+                assert not llm.model_runner.graphs  # gloo collectives cannot be captured: eager decode
+            return [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+        finally:
+            llm.exit()
+
+    key = ("MID", False)
+    toks1 = _TP1_RUNS[key][0] if key in _TP1_RUNS else run(1)
+    monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("MI355_XGMI_SELFTEST_FAIL_RANK", "1")
+    toks2 = run(2)
+    agree = sum(int(a == b) for x, y in zip(toks1, toks2) for a, b in zip(x, y))
+    assert agree >= sum(len(x) for x in toks1) - 1, (toks1, toks2)
