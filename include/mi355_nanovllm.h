@@ -288,7 +288,7 @@ int mi_silu_mul(const mi_bf16* x, mi_bf16* out, int rows, int inter,
 /* ---- linear (reference: layers/linear.py:51,73,150; embed_head.py:61) ----- */
 /* y[M][N] = x[M][K] @ w[N][K]^T (+ bias[N]); bf16 in, fp32 accumulate, one
  * rounding to bf16.  Weight-streaming MFMA kernel for the decode regime:
- * 1 <= M <= 64, K % 32 == 0 (K % 256 == 0 fastest), N % 16 == 0.
+ * 1 <= M <= 512 (walked in chunks of 64 rows inside the launch), K % 32 == 0 (K % 256 == 0 fastest), N % 16 == 0.
  * x row stride = K, y row stride = N. */
 int mi_gemm_bf16_skinny(const mi_bf16* x, const mi_bf16* w, const mi_bf16* bias,
                         mi_bf16* y, int M, int N, int K, mi_stream stream);
@@ -333,7 +333,7 @@ int mi_gemm_bf16_packed(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16
  * quarter of the activation bytes through each CU and measured faster).  Weight layout
  * w_packed4[N/4][K/32][4][4][8]:
  *   w_packed4[((tn*K/32 + tk)*16 + g*4 + n)*8 + e] = w[(4 tn + n)*K + 32 tk + 8 g + e].
- * 1 <= M <= 64, N % 4 == 0, K % 32 == 0. */
+ * 1 <= M <= 512 (chunks of 64 rows), N % 4 == 0, K % 32 == 0. */
 int mi_pack_weight_rows4(const mi_bf16* w, mi_bf16* w_packed4, int N, int K, mi_stream stream);
 int mi_gemm_bf16_rows4(const mi_bf16* x, const mi_bf16* w_packed4, mi_bf16* y, int M, int N, int K,
                        mi_stream stream);

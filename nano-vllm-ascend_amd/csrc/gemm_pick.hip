@@ -64,7 +64,7 @@ using namespace mi;
 // head GEMM with the pick epilogue: the same workgroup geometry as mi_gemm_bf16_packed for this (M, N)
 extern "C" int mi_gemm_pick_groups(int M, int N, int K, int fp8_weights) {
   if (M <= 0 || N <= 0 || N % 16) return 0;
-  if (!fp8_weights && head_stream_fits(M, N, K)) return kHeadStreamGrid;
+  if (!fp8_weights && head_stream_fits(M, N, K)) return head_stream_grid(M);
   return pick_two_tiles(M, N) ? N / 32 : N / 16;
 }
 

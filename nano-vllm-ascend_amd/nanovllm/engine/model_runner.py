@@ -89,7 +89,13 @@ class ModelRunner:
         # (bench.py --mode replicas) share a default group only for their barrier
         parallel.set_tp(rank if self.world_size > 1 else 0, self.world_size)
         parallel.set_xgmi_comm(None)
-        self.channel = StepChannel(config.hccl_port, self.world_size, rank) if self.world_size > 1 else None
+        self.channel = None
+        if self.world_size > 1:
+            from nanovllm.engine.rpc import slot_words
+
+            self.channel = StepChannel(config.hccl_port, self.world_size, rank,
+                                       slot_words(config.max_num_batched_tokens, config.max_num_seqs,
+                                                  config.max_model_len, config.kvcache_block_size))
         self.xgmi = None
         self._steps_run = 0
         if self.world_size > 1:
@@ -117,6 +123,11 @@ class ModelRunner:
                 self.model = model_dict[arch](self.hf_config)
         finally:
             torch.set_default_dtype(prev)
+        from nanovllm.layers.linear import LinearBase, check_linear_shape
+
+        for name, module in self.model.named_modules():  # fail at start-up, not in the middle of a prefill step
+            if isinstance(module, LinearBase):
+                check_linear_shape(name, *module.weight.shape)
         if has_checkpoint(config.model):
             load_model(self.model, config.model)
             self.synthetic = False
@@ -189,7 +200,8 @@ class ModelRunner:
                     "grouped expert GEMMs (csrc/moe.hip) have no instantiation for these contraction lengths")
 
     # ------------------------------------------------------------------ lifecycle / RPC
-    def exit(self):
+    def exit(self, abort: bool = False):
+        """abort: a peer is known not to reach the exit barrier (rank 0 raised after an exchange time-out)."""
         from nanovllm.layers import parallel
 
         parallel.reset_tp()
@@ -198,7 +210,8 @@ class ModelRunner:
         self.graph_logits.clear()
         torch.cuda.synchronize()
         if self.channel is not None:
-            dist.barrier()
+            if not abort:
+                dist.barrier()
             self.channel.close()
         if self.xgmi is not None:
             from nanovllm.layers import parallel
@@ -218,6 +231,9 @@ class ModelRunner:
             method, seqs, is_prefill, extra = self.channel.recv()
             if method == "exit":
                 self.exit()
+                return
+            if method == "abort":  # rank 0 gave up on a step (an exchange timed out): leave without the exit barrier
+                self.exit(abort=True)
                 return
             if method == "launch_decode":  # a step rank 0 queued behind the running one: queue the same step here
                 self.launch_decode(seqs, extra if extra else None)
@@ -322,6 +338,7 @@ class ModelRunner:
         self.tokens_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
         self.tokens_hosts = [torch.zeros(B, dtype=torch.int64, pin_memory=True) for _ in range(2)]
         self.step_events = [torch.cuda.Event() for _ in range(2)]
+        self._events_recorded = [False, False]
         # prefill metadata staging: ids + positions (8 B) + slots (4 B) per token, per-sequence vectors, tables
         nbytes = cfg.max_num_batched_tokens * 20 + B * (W + 4) * 4 + 4096
         self.prefill_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
@@ -403,6 +420,9 @@ class ModelRunner:
         # (every rank then holds the step's tokens: no logits gather, no sampler on rank 0, no host in the loop)
         pick = os.environ.get("MI355_GRAPH_SAMPLER", "1") != "0" and self.model.lm_head.can_pick()
         self.graph_samples = {bs for bs in graph_buckets(cfg.max_num_seqs) if pick and bs <= ops.SKINNY_MAX_M}
+        # under TP a sampling graph ends in the candidate exchange over the xGMI region: that collective is what keeps
+        # the ranks' queued steps (engine lookahead) in lockstep
+        assert not (self.world_size > 1 and self.graph_samples) or self.xgmi is not None
         # neutral metadata: every row padded (context_len 0, dummy slot)
         self._fill_decode_stage([], cfg.max_num_seqs)
         pool = None
@@ -503,6 +523,10 @@ class ModelRunner:
         bucket = self._bucket_for(real)
         assert bucket in self.graph_samples
         self.lookahead_launches = getattr(self, "lookahead_launches", 0) + (src_rows is not None)
+        if self.rank != 0 and self._events_recorded[self._flip ^ 1]:
+            # a worker never waits for a step's tokens: before the pinned staging buffer of the step before last is
+            # overwritten, make sure its upload has executed (rank 0 gets the same guarantee from collect())
+            self.step_events[self._flip ^ 1].synchronize()
         b = self._fill_decode_stage(seqs, bucket, src_rows)
         self.graphs[bucket].replay()
         self.sampler.step += 1  # the graph sampled with this step (see _fill_decode_stage)
@@ -510,7 +534,8 @@ class ModelRunner:
             self.tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
             if self.xgmi is not None:  # the exchange's timeout flag travels with the tokens: no device sync here
                 self.xgmi.status_async(self._xgmi_flag)
-            self.step_events[b].record()
+        self.step_events[b].record()
+        self._events_recorded[b] = True
         self.last_logits = self.graph_logits[bucket]
         self._steps_run += 1
         return (b, real)
@@ -519,6 +544,7 @@ class ModelRunner:
         b, real = handle
         self.step_events[b].synchronize()
         if self._xgmi_flag is not None and int(self._xgmi_flag[0]):
+            self._abort_workers()
             raise RuntimeError("rank 0: xGMI exchange timed out waiting for a peer; results are invalid")
         return self.tokens_hosts[b][:real].tolist()
 
@@ -527,4 +553,11 @@ class ModelRunner:
         returned then is not a sum.  Surface that as an error (checked after every step - the stream has just
         been synchronised for the token copy - and at exit)."""
         if self.xgmi is not None and self.xgmi.timed_out():
+            self._abort_workers()
             raise RuntimeError(f"rank {self.rank}: xGMI all-reduce timed out waiting for a peer; results are invalid")
+
+    def _abort_workers(self):
+        """Rank 0 is about to raise: tell the workers to leave their receive loops (they kept spinning)."""
+        if self.channel is not None and self.rank == 0 and not getattr(self, "_aborted", False):
+            self._aborted = True
+            self.channel.send("abort")

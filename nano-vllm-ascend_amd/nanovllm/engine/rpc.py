@@ -28,11 +28,19 @@ import numpy as np
 
 from nanovllm.engine.sequence import Sequence
 
-_METHODS = ("run", "exit", "launch_decode")
+_METHODS = ("run", "exit", "launch_decode", "abort")
 _HEADER = 6
-_CAPACITY = 1 << 21  # int64 words per slot (16 MiB): > max_num_batched_tokens ids + tables
+_DEFAULT_CAPACITY = 1 << 18  # int64 words per slot (2 MiB) when the caller does not size the channel
 _SLOTS = 4
 _BASE = 8            # word 0: newest generation published
+
+
+def slot_words(max_num_batched_tokens: int, max_num_seqs: int, max_model_len: int, block_size: int) -> int:
+    """int64 words of the largest step message: a prefill step carries every scheduled token id once, every step up to
+    max_num_seqs records of 11 header words + a block table (Sequence.to_wire) - sized from the configuration
+    (four fixed 16 MiB slots were just over Docker's default 64 MB /dev/shm, which RCCL also uses)."""
+    table = -(-(max_model_len + 1) // block_size)
+    return _HEADER + max_num_batched_tokens + max_num_seqs * (12 + table + 1) + 1024
 
 
 def _name(port: int) -> str:
@@ -40,10 +48,11 @@ def _name(port: int) -> str:
 
 
 class StepChannel:
-    def __init__(self, port: int, world_size: int, rank: int):
+    def __init__(self, port: int, world_size: int, rank: int, capacity_words: int = _DEFAULT_CAPACITY):
         import torch.distributed as dist
 
         self.rank = rank
+        _CAPACITY = self.capacity = int(capacity_words)  # every rank derives it from the same configuration
         nbytes = (_BASE + _SLOTS * _CAPACITY) * 8
         if rank == 0:
             try:
@@ -70,6 +79,7 @@ class StepChannel:
         for s in seqs or ():
             payload.extend(s.to_wire(is_prefill))
         n, extra = len(payload), list(extra or ())
+        _CAPACITY = self.capacity
         assert _HEADER + n + len(extra) <= _CAPACITY, "step message exceeds the control channel"
         gen = self.generation + 1
         b = self.buf[_BASE + (gen % _SLOTS) * _CAPACITY:]
@@ -93,7 +103,7 @@ class StepChannel:
             spins += 1
             if spins > 2000:
                 time.sleep(0)  # yield, keep latency in the microsecond range
-        b = self.buf[_BASE + (want % _SLOTS) * _CAPACITY:]
+        b = self.buf[_BASE + (want % _SLOTS) * self.capacity:]
         method, is_prefill, n_seqs, n, n_extra = _METHODS[int(b[1])], bool(b[2]), int(b[3]), int(b[4]), int(b[5])
         data = b[_HEADER:_HEADER + n].copy()
         extra = [int(v) for v in b[_HEADER + n:_HEADER + n + n_extra]]

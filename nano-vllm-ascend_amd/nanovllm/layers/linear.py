@@ -15,21 +15,57 @@ from nanovllm import ops
 from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
 
 
+def tile_gemm_takes(rows: int, n: int, k: int) -> bool:
+    """mi_gemm_bf16's shape contract (csrc/gemm_tile.hip: K steps of 64, 16-byte output pieces, 32-bit DMA offsets)"""
+    return k % 64 == 0 and n % 4 == 0 and n * k * 2 < (1 << 32) and rows * k * 2 < (1 << 32)
+
+
+def streaming_gemm_takes(n: int, k: int) -> bool:
+    """the weight-streaming kernels' contract (16-feature row tiles, 32-deep MFMA steps)"""
+    return n % 16 == 0 and k % 32 == 0
+
+
+def check_linear_shape(name: str, n: int, k: int) -> None:
+    """Start-up validation (ModelRunner): a projection no kernel family takes must fail when the model is built, not
+    in the middle of a prefill step."""
+    if not (streaming_gemm_takes(n, k) or tile_gemm_takes(1, n, k)):
+        raise NotImplementedError(
+            f"{name}: a [{n} x {k}] projection fits neither the streaming GEMMs (N % 16, K % 32) nor the tile GEMM "
+            "(N % 4, K % 64); there is no library fallback in this build")
+
+
 def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None,
                    packed: torch.Tensor | None = None) -> torch.Tensor:
     rows = x.numel() // x.shape[-1]
-    tileable = weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0 and not isinstance(packed, ops.Fp8Weight)
-    if (rows <= ops.SKINNY_MAX_M and weight.shape[0] % 16 == 0 and weight.shape[1] % 32 == 0
-            and not (tileable and ops.prefers_tile(rows, weight.shape[0]))):
+    n, k = weight.shape
+    tile_ok = tile_gemm_takes(rows, n, k)
+    tileable = tile_ok and not isinstance(packed, ops.Fp8Weight)
+
+    def streamed(xr: torch.Tensor) -> torch.Tensor:
         if isinstance(packed, ops.Fp8Weight):  # the fp8 GEMM has no bias operand
-            y = ops.gemm_packed(x, packed)
+            y = ops.gemm_packed(xr, packed)
             return y if bias is None else y.add_(bias)
         if packed is not None:
-            return ops.gemm_packed(x, packed, bias)
-        return ops.gemm_skinny(x, weight, bias)
+            return ops.gemm_packed(xr, packed, bias)
+        return ops.gemm_skinny(xr, weight, bias)
+
+    if (rows <= ops.SKINNY_MAX_M and streaming_gemm_takes(n, k) and not (tileable and ops.prefers_tile(rows, n))):
+        return streamed(x)
     shape = x.shape
-    y = ops.gemm_tile(x.reshape(-1, shape[-1]), weight, bias)
-    return y.view(*shape[:-1], weight.shape[0])
+    if tile_ok:
+        y = ops.gemm_tile(x.reshape(-1, shape[-1]), weight, bias)
+        return y.view(*shape[:-1], n)
+    if streaming_gemm_takes(n, k):
+        # more rows than one streaming launch takes AND a shape the tile kernel cannot take (K % 64 == 32: e.g. an
+        # intermediate size of 11008 over 8 ranks = 1376; an operand of 4 GiB or more): the streaming kernels over the
+        # rows in pieces of SKINNY_MAX_M - every piece re-streams the weight, correct and slow, instead of an error in
+        # the middle of a prefill step (the reference's F.linear takes any shape; ADVICE r03)
+        x2 = x.reshape(-1, shape[-1])
+        y = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+        for r0 in range(0, rows, ops.SKINNY_MAX_M):
+            y[r0:r0 + ops.SKINNY_MAX_M] = streamed(x2[r0:r0 + ops.SKINNY_MAX_M].contiguous())
+        return y.view(*shape[:-1], n)
+    raise ops._C.MiError(f"no GEMM kernel takes a [{n} x {k}] projection (see layers/linear.check_linear_shape)")
 
 
 def can_pack(weight: torch.Tensor) -> bool:
@@ -48,7 +84,7 @@ def set_weight_quantization(mode: str | None) -> None:
 def pack_for_decode(weight: torch.Tensor, previous):
     """The decode-GEMM copy of a (sharded) weight: fragment-native bf16, or - Config.quantization == "fp8" -
     fragment-native e4m3 + per-row scale.  In fp8 mode the bf16 parameter itself is replaced by the
-    dequantised values, so the prefill (library GEMM) and anything tied to it see the same model."""
+    dequantised values, so the prefill (the bf16 tile GEMM) and anything tied to it see the same model."""
     if not can_pack(weight):
         return None
     if _QUANTIZATION == "fp8" and weight.shape[1] % 64 == 0:

@@ -108,7 +108,7 @@ def _engine_vs_oracle(cfg, lens, enforce_eager, seed, tol, max_tokens=6, quantiz
         for p in prompts:
             llm.add_request(p, SamplingParams(max_tokens=max_tokens, ignore_eos=True, greedy=True))
         bs = 16
-        worst, agree, total = 0.0, 0, 0
+        worst, agree, total, near_ties = 0.0, 0, 0, 0
         while not llm.is_finished():
             seqs, is_prefill = llm.scheduler.schedule()
             if is_prefill:
@@ -129,13 +129,18 @@ def _engine_vs_oracle(cfg, lens, enforce_eager, seed, tol, max_tokens=6, quantiz
             for row, (a, b) in enumerate(zip(toks, otoks)):
                 # greedy tokens agree wherever the oracle's own margin is wider than twice the logit tolerance,
                 # i.e. wherever an error within the tolerance cannot move the arg-max
-                if float(top2[row, 0] - top2[row, 1]) > 2 * tol:
-                    assert a == b, (row, a, b, float(top2[row, 0] - top2[row, 1]))
+                margin = float(top2[row, 0] - top2[row, 1])
+                if margin > 2 * tol:
+                    assert a == b, (row, a, b, margin)
+                else:
+                    near_ties += 1
                 agree += int(a == b)
             total += len(toks)
             llm.scheduler.postprocess(seqs, otoks)
         assert worst <= tol, worst
-        assert agree >= 0.8 * total, (agree, total)  # and near-ties stay the exception
+        # only genuine near-ties (oracle margin <= 2 tol, counted above) may flip, and at most about half of THOSE do in
+        # an honest run (a flat "80 % agree" floor could hide a small systematic bias)
+        assert total - agree <= max(1, (near_ties + 1) // 2), (agree, total, near_ties)
         return worst
     finally:
         llm.exit()
@@ -164,12 +169,22 @@ QWEN3_30B_A3B_2L = dict(MID, architectures=["Qwen3MoeForCausalLM"], model_type="
                         mlp_only_layers=[], norm_topk_prob=True, tie_word_embeddings=False)
 
 
-def test_engine_matches_oracle_qwen3_30b_a3b_widths():
+@pytest.mark.parametrize("p_split,tol", [(0, 2.2e-1), pytest.param(1, 1.3e-1, marks=pytest.mark.gpu_slow)])
+def test_engine_matches_oracle_qwen3_30b_a3b_widths(p_split, tol):
     """Engine (eager prefill through the grouped kernels, hipGraph decode) vs the oracle for the MoE widths.
     A routing decision is a discrete choice: where two experts' probabilities are within bf16 noise the two
     pipelines may pick differently, so - exactly as for greedy tokens - logits are compared per step on a
-    bound that allows for it (1.3e-1 at logits up to ~10)."""
-    _engine_vs_oracle(QWEN3_30B_A3B_2L, [5, 17, 64, 33], enforce_eager=False, seed=6, tol=1.3e-1, max_tokens=4)
+    bound that allows for it: 1.3e-1 at logits up to ~10 with the prefill attention's P as bf16 hi + lo (the
+    round-1..3 precision); with P as one bf16 per key (the default since round 4, the precision of the reference's
+    own CPU attention) one more near-tie of the router falls the other way on this seed - an expert swap moves a
+    logit by more than any rounding does (observed 1.8e-1 = 1.5 bf16 ulps at |logit| ~ 10)."""
+    from nanovllm import _C
+
+    _C.set_tuning(_C.TUNE_PREFILL_P_SPLIT, p_split)
+    try:
+        _engine_vs_oracle(QWEN3_30B_A3B_2L, [5, 17, 64, 33], enforce_eager=False, seed=6, tol=tol, max_tokens=4)
+    finally:
+        _C.set_tuning(_C.TUNE_PREFILL_P_SPLIT, 0)
 
 
 def test_engine_fp8_weights_match_oracle_on_dequantised_weights():
@@ -278,13 +293,16 @@ _TP1_RUNS: dict = {}
 
 
 @pytest.mark.parametrize("model,enforce_eager,tol,world", [
-    ("MID", True, 6e-2, 2), ("MID", False, 6e-2, 2), ("QWEN3_32B_2L", False, 1.3e-1, 2),
+    ("MID", True, 6e-2, 2), ("MID", False, 6e-2, 2),
+    # (two ranks at the widths that also run at their BASELINE.json world sizes below: gpu_slow)
+    pytest.param("QWEN3_32B_2L", False, 1.3e-1, 2, marks=pytest.mark.gpu_slow),
     # (sparse block: an expert's bf16 partial sums are rounded per rank before they are added - the widest spread)
-    ("QWEN3_30B_A3B_2L", False, 1.6e-1, 2),
+    pytest.param("QWEN3_30B_A3B_2L", False, 1.6e-1, 2, marks=pytest.mark.gpu_slow),
     # BASELINE.json configs[3] / configs[2] at their own world sizes: Qwen3-30B-A3B widths over FOUR ranks and
     # Qwen3-32B widths over EIGHT (one kv head per rank), hipGraph and eager - engine, exchange kernels and RPC
-    ("QWEN3_30B_A3B_2L", False, 2.2e-1, 4), ("QWEN3_30B_A3B_2L", True, 2.2e-1, 4),
-    ("QWEN3_32B_2L", False, 1.6e-1, 8), ("QWEN3_32B_2L", True, 1.6e-1, 8),
+    # (the eager twins of these two take 80 s and 30 s: gpu_slow, conftest.py)
+    ("QWEN3_30B_A3B_2L", False, 2.2e-1, 4), pytest.param("QWEN3_30B_A3B_2L", True, 2.2e-1, 4, marks=pytest.mark.gpu_slow),
+    ("QWEN3_32B_2L", False, 1.6e-1, 8), pytest.param("QWEN3_32B_2L", True, 1.6e-1, 8, marks=pytest.mark.gpu_slow),
     # the plain-layout attention family (head_dim 64) sharded: one kv head per rank
     ("MID_LLAMA_HD64", False, 6e-2, 2)])
 def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, world):
@@ -606,7 +624,9 @@ def test_full_size_properties_paging_invariance_and_decode_equals_reprefill():
         llm.exit()
 
 
-@pytest.mark.parametrize("mode,ranks", [("replicas", 2), ("tp", 2), ("both", 2), ("both", 4)])
+# ("both" runs the replicas line and the tp line of the same world size: the single-mode twins are gpu_slow)
+@pytest.mark.parametrize("mode,ranks", [pytest.param("replicas", 2, marks=pytest.mark.gpu_slow),
+                                        pytest.param("tp", 2, marks=pytest.mark.gpu_slow), ("both", 2), ("both", 4)])
 def test_bench_ranks_on_one_gpu(mode, ranks):
     """bench.py for N > 1 on a 1-GPU box (all ranks on cuda:0, gloo instead of RCCL).  `python bench.py --gpus N`
     starts its ranks itself - the command the driver uses for N = 1 must not die for N > 1 - and the default mode

@@ -170,3 +170,23 @@ def test_gemm_tile_captures_into_hipgraph(ops):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_linear_forward_takes_shapes_the_tile_kernel_cannot(ops, packed):
+    """a prefill-sized activation on a projection with K % 64 == 32 (an intermediate size of 11008 over 8
+    ranks = 1376: Llama-2-7B / Qwen1.5-7B down_proj shards) used to raise MI_EUNSUPPORTED in the middle of a prefill
+    step.  layers/linear.linear_forward now walks the rows through the streaming kernels in pieces of 512; shapes no
+    kernel family takes are refused when the model is built (check_linear_shape)."""
+    from nanovllm.layers import linear
+
+    M, N, K = 1100, 1024, 1376
+    g, x, w = _case(M, N, K, seed=4)
+    b = torch.randn(N, generator=g).bfloat16()
+    assert not linear.tile_gemm_takes(M, N, K) and linear.streaming_gemm_takes(N, K)
+    wd = w.to(DEV)
+    y = linear.linear_forward(x.to(DEV), wd, b.to(DEV), ops.pack_weight(wd) if packed else None)
+    assert_bf16_close(y, oracle.linear(x, w, b), max_ulp=1, max_frac=2e-2, atol=K * 2.0 ** -22)
+    with pytest.raises(NotImplementedError):
+        linear.check_linear_shape("odd", 1022, 1384)
+    linear.check_linear_shape("down_proj shard", N, K)

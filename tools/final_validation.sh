@@ -1,7 +1,7 @@
 set -x
 R=$PWD
 mkdir -p gpurun_out/final
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > gpurun_out/final/pytest_gpu.txt
+timeout 1500 python -m pytest tests -x -q -m "gpu or gpu_slow" 2>&1 | tail -4 > gpurun_out/final/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > gpurun_out/final/smoke.txt
 timeout 600 python bench.py 2>&1 | grep -v Warning | tail -1 > gpurun_out/final/bench.json
 cd /tmp && export TMPDIR=/tmp
