@@ -498,6 +498,103 @@ __global__ __launch_bounds__(128) void qkv_prefill_store_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// head_dim 64 (round 4: Llama-3.2-1B, Qwen2-0.5B on the fragment-native attention kernels): the same tile formulas
+// (k_tile_off / v_tile_off do not depend on the head width), a 16-token tile is the first 1024 elements = 2 KiB.
+// Pure copies of already rotated K rows and of V rows (the q/k-norm + RoPE fusions above are written for 128-wide
+// heads; models of this width have no q/k norm and take mi_rope_plain first).
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void kv_store_frag_kernel(const uint16_t* __restrict__ k, int64_t k_stride,
+                                                            const uint16_t* __restrict__ v, int64_t v_stride,
+                                                            uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
+                                                            const int32_t* __restrict__ slots, int slot_is_2d, int n_tokens,
+                                                            int n_kv_heads, int block_size, int skip_v) {
+  constexpr int GROUPS = D / 8;  // 16-byte groups of a head row
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_tokens * n_kv_heads * GROUPS) return;
+  const int j = (int)(idx % GROUPS), h = (int)((idx / GROUPS) % n_kv_heads), t = (int)(idx / ((int64_t)GROUPS * n_kv_heads));
+  int64_t blk;
+  int off;
+  if (!resolve_slot(slots, slot_is_2d, t, block_size, blk, off)) return;
+  const int64_t base = ((blk * n_kv_heads + h) * (block_size >> 4) + (off >> 4)) * (int64_t)(16 * D);
+  const int tk = off & 15;
+  *reinterpret_cast<u32x4*>(k_cache + base + k_tile_off(tk, 8 * j)) =
+      *reinterpret_cast<const u32x4*>(k + (int64_t)t * k_stride + h * D + 8 * j);
+  if (skip_v) return;
+  const u32x4 vv = *reinterpret_cast<const u32x4*>(v + (int64_t)t * v_stride + h * D + 8 * j);
+  uint16_t* vt = v_cache + base;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    vt[v_tile_off(tk, 8 * j + 2 * i)] = (uint16_t)(vv[i] & 0xffffu);
+    vt[v_tile_off(tk, 8 * j + 2 * i + 1)] = (uint16_t)(vv[i] >> 16);
+  }
+}
+
+// V rows of 16 consecutive tokens that fill one aligned cache tile: transposed through LDS, one coalesced 2 D x 16-byte
+// run; anything else: element scatter (v_store_tiles_kernel for any head width)
+template <int D>
+__global__ __launch_bounds__(128) void v_store_tiles_frag_kernel(const uint16_t* __restrict__ vsrc, int64_t v_stride,
+                                                                 uint16_t* __restrict__ v_cache,
+                                                                 const int32_t* __restrict__ slots, int n_tokens,
+                                                                 int n_kv_heads, int block_size) {
+  __shared__ uint16_t sm[16][D + 8];
+  __shared__ int sm_slot[16];
+  const int t0 = blockIdx.x * 16, h = blockIdx.y, tid = threadIdx.x;
+  const int n_here = min(16, n_tokens - t0);
+  if (tid < 16) sm_slot[tid] = tid < n_here ? slots[t0 + tid] : -2;
+  for (int c = tid; c < 16 * (D / 8); c += 128) {  // coalesced read of 16 rows x 2 D bytes
+    const int tk = c / (D / 8), ch = c % (D / 8);
+    u32x4 v = {0, 0, 0, 0};
+    if (tk < n_here) v = *reinterpret_cast<const u32x4*>(vsrc + (int64_t)(t0 + tk) * v_stride + h * D + ch * 8);
+    *reinterpret_cast<u32x4*>(&sm[tk][ch * 8]) = v;
+  }
+  __syncthreads();
+  const int s0 = sm_slot[0];
+  bool tile_ok = s0 >= 0 && (s0 & 15) == 0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) tile_ok = tile_ok && sm_slot[i] == s0 + i;
+  const int tpb = block_size >> 4;
+  if (tile_ok) {
+    uint16_t* tile = v_cache + (((int64_t)(s0 / block_size) * n_kv_heads + h) * tpb + ((s0 % block_size) >> 4)) * (16 * D);
+    for (int oc = tid; oc < 2 * D; oc += 128) {  // output chunk (jp, g4, n): 4 tokens x {d, d + 16}
+      const int jp = oc >> 6, g4 = (oc >> 4) & 3, nn = oc & 15;
+      const int d0 = jp * 32 + nn;
+      u32x4 o;
+      o[0] = (uint32_t)sm[4 * g4 + 0][d0] | ((uint32_t)sm[4 * g4 + 1][d0] << 16);
+      o[1] = (uint32_t)sm[4 * g4 + 2][d0] | ((uint32_t)sm[4 * g4 + 3][d0] << 16);
+      o[2] = (uint32_t)sm[4 * g4 + 0][d0 + 16] | ((uint32_t)sm[4 * g4 + 1][d0 + 16] << 16);
+      o[3] = (uint32_t)sm[4 * g4 + 2][d0 + 16] | ((uint32_t)sm[4 * g4 + 3][d0 + 16] << 16);
+      *reinterpret_cast<u32x4*>(tile + oc * 8) = o;
+    }
+  } else {
+    for (int e = tid; e < 16 * D; e += 128) {
+      const int tk = e / D, d = e % D;
+      const int sl = sm_slot[tk];
+      if (sl < 0) continue;
+      uint16_t* tile = v_cache + (((int64_t)(sl / block_size) * n_kv_heads + h) * tpb + ((sl % block_size) >> 4)) * (16 * D);
+      tile[v_tile_off(sl & 15, d)] = sm[tk][d];
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void kv_gather_frag_kernel(const uint16_t* __restrict__ cache, int is_v,
+                                                             const int32_t* __restrict__ slot_flat, int n,
+                                                             uint16_t* __restrict__ out, int n_kv_heads, int block_size) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * n_kv_heads * D) return;
+  const int d = (int)(idx % D), h = (int)((idx / D) % n_kv_heads), i = (int)(idx / ((int64_t)D * n_kv_heads));
+  const int32_t s = slot_flat[i];
+  if (s < 0) {
+    out[idx] = 0;
+    return;
+  }
+  const int off = s % block_size;
+  const uint16_t* tile = cache + (((int64_t)(s / block_size) * n_kv_heads + h) * (block_size >> 4) + (off >> 4)) * (16 * D);
+  out[idx] = tile[is_v ? v_tile_off(off & 15, d) : k_tile_off(off & 15, d)];
+}
+
 // inverse of the scatter, for content checks: out[i][h*128+d] = cache[slot_flat[i]][h][d]
 __global__ __launch_bounds__(256) void kv_gather_kernel(const uint16_t* __restrict__ cache, int is_v,
                                                         const int32_t* __restrict__ slot_flat, int n,
@@ -830,12 +927,22 @@ static int store_common(const mi_bf16* k, const mi_bf16* v, int64_t ks, int64_t 
                         mi_bf16* vc, const int32_t* slots, int is2d, int n, int n_kv_heads, int head_dim,
                         int block_size, mi_stream stream) {
   if (!k || !v || !kc || !vc || !slots || n < 0 || n_kv_heads <= 0) return MI_EINVAL;
-  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16 || ks % 8 || vs % 8)
+  if ((head_dim != MI_HEAD_DIM && head_dim != 64) || block_size <= 0 || block_size % 16 || ks % 8 || vs % 8)
     return MI_EUNSUPPORTED;
   if (!aligned16(k) || !aligned16(v) || !aligned16(kc) || !aligned16(vc)) return MI_EINVAL;
   if (n == 0) return MI_OK;
   const int64_t hs = (int64_t)n * 2 * n_kv_heads;
   const int tiled_v = (!is2d && n >= 64) ? 1 : 0;
+  if (head_dim == 64) {  // 2 KiB tiles
+    const int64_t items = (int64_t)n * n_kv_heads * 8;
+    hipLaunchKernelGGL(kv_store_frag_kernel<64>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, S(stream), k, ks, v,
+                       vs, kc, vc, slots, is2d, n, n_kv_heads, block_size, tiled_v);
+    int rc64 = check_launch();
+    if (rc64 != MI_OK || !tiled_v) return rc64;
+    hipLaunchKernelGGL(v_store_tiles_frag_kernel<64>, dim3((n + 15) / 16, n_kv_heads), dim3(128), 0, S(stream), v, vs, vc,
+                       slots, n, n_kv_heads, block_size);
+    return check_launch();
+  }
   hipLaunchKernelGGL((qk_rope_store_kernel<2>), dim3(heads_grid(hs)), dim3(256), 0, S(stream), nullptr,
                      (int64_t)0, k, ks, v, vs, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, kc,
                      vc, slots, is2d, n, 0, n_kv_heads, block_size, tiled_v);
@@ -866,8 +973,14 @@ extern "C" int mi_kv_cache_gather(const mi_bf16* cache, int is_v, const int32_t*
                                   mi_bf16* out, int n_kv_heads, int head_dim, int block_size,
                                   mi_stream stream) {
   if (!cache || !slot_flat || !out || n < 0 || n_kv_heads <= 0) return MI_EINVAL;
-  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16) return MI_EUNSUPPORTED;
+  if ((head_dim != MI_HEAD_DIM && head_dim != 64) || block_size <= 0 || block_size % 16) return MI_EUNSUPPORTED;
   if (n == 0) return MI_OK;
+  if (head_dim == 64) {
+    const int64_t total64 = (int64_t)n * n_kv_heads * 64;
+    hipLaunchKernelGGL(kv_gather_frag_kernel<64>, dim3((int)((total64 + 255) / 256)), dim3(256), 0, S(stream), cache, is_v,
+                       slot_flat, n, out, n_kv_heads, block_size);
+    return check_launch();
+  }
   const int64_t total = (int64_t)n * n_kv_heads * 128;
   hipLaunchKernelGGL(kv_gather_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, S(stream), cache, is_v,
                      slot_flat, n, out, n_kv_heads, block_size);

@@ -26,21 +26,25 @@
 
 namespace mi {
 
-__device__ __forceinline__ void load_tile(const uint16_t* __restrict__ tile, int lane, u32x4 (&f)[4]) {
+// DB = head_dim / 32: 4 for the 128-wide heads every kernel here was written around, 2 for head_dim 64 (round 4:
+// Llama-3.2-1B, Qwen2-0.5B - the first DB * 512 elements of the same tile formulas: a 2 KiB tile per 16 tokens)
+template <int DB>
+__device__ __forceinline__ void load_tile(const uint16_t* __restrict__ tile, int lane, u32x4 (&f)[DB]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)  // streamed once: non-temporal (measured +10-15 % HBM read bandwidth)
+  for (int i = 0; i < DB; ++i)  // streamed once: non-temporal (measured +10-15 % HBM read bandwidth)
     f[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tile + i * 512 + lane * 8));
 }
 
 // S^T = K . Q^T for one chunk, masked and scaled to the log2 domain.
 // `limit`: tokens with index < limit are visible to this lane's column.
 // `limit_all`: a wave-uniform lower bound of `limit` over the wave's columns.
-__device__ __forceinline__ void score_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4], const bf16x8 (&Q)[4],
+template <int DB>
+__device__ __forceinline__ void score_chunk(const u32x4 (&K0)[DB], const u32x4 (&K1)[DB], const bf16x8 (&Q)[DB],
                                             int tok0, int limit, int limit_all, float scale_log2e, int g,
                                             float (&p)[8]) {
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
+  for (int kk = 0; kk < DB; ++kk) {
     s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K0[kk]), Q[kk], s0, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(K1[kk]), Q[kk], s1, 0, 0, 0);
   }
@@ -68,9 +72,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;  // one MFMA 16x16x16 b
 // X16 = true: two 16-deep MFMAs (v_mfma_f32_16x16x16_bf16), one per tile, whose operands are aligned
 //   halves of the registers as loaded - no moves, so nothing touches a fragment between its load and its
 //   MFMA (the two-chunks-in-flight loop depends on that: a move right behind the load would wait for it).
-template <bool X16>
-__device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0)[4], const u32x4 (&V1)[4],
-                                                 float& m, float& l, f32x4 (&acc)[8]) {
+template <bool X16, int DB>
+__device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0)[DB], const u32x4 (&V1)[DB],
+                                                 float& m, float& l, f32x4 (&acc)[2 * DB]) {
   float mc = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
   mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
   mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
@@ -87,7 +91,7 @@ __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0
     const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m - mn);
     l *= alpha;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+    for (int j = 0; j < 2 * DB; ++j) acc[j] *= alpha;
     m = mn;
   }
   l += ps;
@@ -103,14 +107,14 @@ __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0
     for (int part = 0; part < 4; ++part) {  // (tile 0, hi), (tile 0, lo), (tile 1, hi), (tile 1, lo)
       const s16x4 pb = half((part & 1) ? pl : ph, (part >> 1) * 2);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)  // eight independent accumulators between two uses of the same one
+      for (int j = 0; j < 2 * DB; ++j)  // eight (DB = 4) independent accumulators between two uses of the same one
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(half((part >> 1) ? V1[j >> 1] : V0[j >> 1], (j & 1) * 2), pb,
                                                            acc[j], 0, 0, 0);
     }
   } else {
     const bf16x8 Ph = as_frag(ph), Pl = as_frag(pl);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 2 * DB; ++j) {
       const int jp = j >> 1, hf = (j & 1) * 2;
       const u32x4 a = {V0[jp][hf], V0[jp][hf + 1], V1[jp][hf], V1[jp][hf + 1]};
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a), Ph, acc[j], 0, 0, 0);
@@ -119,22 +123,22 @@ __device__ __forceinline__ void accumulate_chunk(float (&p)[8], const u32x4 (&V0
   }
 }
 
-template <bool X16 = false>
-__device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[4], const u32x4 (&K1)[4],
-                                             const u32x4 (&V0)[4], const u32x4 (&V1)[4],
-                                             const bf16x8 (&Q)[4], int tok0, int limit, int limit_all,
-                                             float scale_log2e, int g, float& m, float& l, f32x4 (&acc)[8]) {
+template <bool X16, int DB>
+__device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[DB], const u32x4 (&K1)[DB],
+                                             const u32x4 (&V0)[DB], const u32x4 (&V1)[DB],
+                                             const bf16x8 (&Q)[DB], int tok0, int limit, int limit_all,
+                                             float scale_log2e, int g, float& m, float& l, f32x4 (&acc)[2 * DB]) {
   float p[8];
-  score_chunk(K0, K1, Q, tok0, limit, limit_all, scale_log2e, g, p);
-  accumulate_chunk<X16>(p, V0, V1, m, l, acc);
+  score_chunk<DB>(K0, K1, Q, tok0, limit, limit_all, scale_log2e, g, p);
+  accumulate_chunk<X16, DB>(p, V0, V1, m, l, acc);
 }
 
 // element strides of the KV cache: block id, kv head, 16-token tile inside a block
 struct KvStrides {
   int64_t block, head, tile;
 };
-__host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb) {
-  return KvStrides{(int64_t)n_kv_heads * tpb * MI_KV_TILE_ELEMS, (int64_t)tpb * MI_KV_TILE_ELEMS, MI_KV_TILE_ELEMS};
+__host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb, int tile_elems = MI_KV_TILE_ELEMS) {
+  return KvStrides{(int64_t)n_kv_heads * tpb * tile_elems, (int64_t)tpb * tile_elems, tile_elems};
 }
 
 // ---------------------------------------------------------------------------
@@ -154,21 +158,23 @@ __host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb) {
 // ---------------------------------------------------------------------------
 // load one chunk = tiles (t, t2); for a single-tile tail t2 == t (a cache hit) and the caller masks
 // the second half through the token limit - no branch, no zero fill
+template <int DB>
 __device__ __forceinline__ void load_tiles(const uint16_t* __restrict__ cache, const int32_t* __restrict__ table_row,
                                            int t, int t2, int h, KvStrides st, int tpb, int lane,
-                                           u32x4 (&T0)[4], u32x4 (&T1)[4]) {
+                                           u32x4 (&T0)[DB], u32x4 (&T1)[DB]) {
   const int blk0 = table_row[t / tpb];
   const int blk1 = table_row[t2 / tpb];
-  load_tile(cache + (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(t % tpb) * st.tile, lane, T0);
-  load_tile(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(t2 % tpb) * st.tile, lane, T1);
+  load_tile<DB>(cache + (int64_t)blk0 * st.block + (int64_t)h * st.head + (int64_t)(t % tpb) * st.tile, lane, T0);
+  load_tile<DB>(cache + (int64_t)blk1 * st.block + (int64_t)h * st.head + (int64_t)(t2 % tpb) * st.tile, lane, T1);
 }
 
 // The same from resolved tile offsets (elements from the cache base of this kv head): no table read, no stride
 // arithmetic between the end of one chunk and the 16 loads of the next
+template <int DB>
 __device__ __forceinline__ void load_tiles_at(const uint16_t* __restrict__ cache_h, int64_t off0, int64_t off1, int lane,
-                                              u32x4 (&T0)[4], u32x4 (&T1)[4]) {
-  load_tile(cache_h + off0, lane, T0);
-  load_tile(cache_h + off1, lane, T1);
+                                              u32x4 (&T0)[DB], u32x4 (&T1)[DB]) {
+  load_tile<DB>(cache_h + off0, lane, T0);
+  load_tile<DB>(cache_h + off1, lane, T1);
 }
 
 // Operands of the fused step prologue (FUSE): the packed qkv row of QKVParallelLinear is consumed
@@ -341,7 +347,7 @@ __device__ __forceinline__ void patch_new_token(u32x4 (&K)[4], u32x4 (&V)[4], co
 // STAMP (mi_paged_attn_decode_fused_ex, tools/attn_timeline.py): every wave records s_memrealtime (the chip-wide 100 MHz
 // reference clock: s_memtime's cycle counters are not aligned between compute units) at eight points of its life into stamps[workgroup][wave][8] - where a launch's microseconds go (ramp, steady state, merge tail).  The
 // instrumented instantiation is a separate kernel; the product kernels carry no stamp code.
-template <int G, int WAVES, bool FUSE, bool PIPE, bool STAMP = false>
+template <int G, int WAVES, bool FUSE, bool PIPE, bool STAMP = false, int DB = 4>
 __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* kc,
     const uint16_t* vc, const int32_t* __restrict__ block_table, int table_stride,
@@ -349,17 +355,19 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     uint16_t* __restrict__ out, int n_q_heads, KvStrides kvs, int tpb, int tpb_shift, int resolve_run, float scale_log2e, FusedStep fs,
     unsigned long long* __restrict__ stamps = nullptr) {
   static_assert(!FUSE || PIPE, "the fused prologue needs the register room of the 8-wave form");
+  static_assert(!FUSE || DB == 4, "the fused step prologue is written for 128-wide heads");
+  constexpr int D = 32 * DB;  // head_dim
   unsigned long long ts[8] = {};
 #define MI_STAMP(i)                                        \
   do {                                                     \
     if constexpr (STAMP) ts[i] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
   MI_STAMP(0);  // entry
-  __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][128];
+  __shared__ __attribute__((aligned(16))) float sm_o[WAVES][G][D];
   __shared__ float sm_m[WAVES][16];
   __shared__ float sm_l[WAVES][16];
   // PIPE: the step's query heads, staged once per workgroup (FUSE: produced by the prologue wave)
-  __shared__ __attribute__((aligned(16))) uint16_t sm_q[PIPE ? G : 1][128];
+  __shared__ __attribute__((aligned(16))) uint16_t sm_q[PIPE ? G : 1][D];
   __shared__ __attribute__((aligned(16))) uint16_t sm_k[FUSE ? 128 : 8], sm_v[FUSE ? 128 : 8];  // the step's new K / V row
 
   const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
@@ -377,8 +385,8 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   const int64_t row0 = (int64_t)b * n_q_heads + h * G;  // first q head of this kv head
   if (wg_c0 >= wg_c1) {  // uniform for the workgroup: nothing to attend in this split
     if (splits == 1) {     // empty context (graph padding row): the output row is zero
-      for (int idx = threadIdx.x; idx < G * 64; idx += WAVES * 64)
-        *reinterpret_cast<uint32_t*>(out + row0 * 128 + 2 * idx) = 0u;
+      for (int idx = threadIdx.x; idx < G * (D / 2); idx += WAVES * 64)
+        *reinterpret_cast<uint32_t*>(out + row0 * D + 2 * idx) = 0u;
     } else {
       for (int hn = threadIdx.x; hn < G; hn += WAVES * 64) {
         part_ml[((row0 + hn) * 16 + split) * 2] = -INFINITY;
@@ -418,27 +426,27 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     step_prologue_issue<G>(pro, q + (int64_t)b * q_stride, n_q_heads, (int)gridDim.y, h, fs,
                            fs.cos_sin + fs.positions[b] * 128, lane);
 
-  if (PIPE && !FUSE && wave == 0) {  // stage the G query heads (contiguous G*256 bytes of the q row)
-    for (int c = lane; c < G * 16; c += 64)
+  if (PIPE && !FUSE && wave == 0) {  // stage the G query heads (contiguous G * 2 D bytes of the q row)
+    for (int c = lane; c < G * (D / 8); c += 64)
       *reinterpret_cast<u32x4*>(&sm_q[0][0] + 8 * c) =
-          *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)h * G * 128 + 8 * c);
+          *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)h * G * D + 8 * c);
   }
 
   float m = -INFINITY, l = 0.f;
-  f32x4 acc[8];
+  f32x4 acc[2 * DB];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < 2 * DB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // a single-tile chunk loads its tile twice (a cache hit) and masks the duplicate through the limit
   auto second = [&](int t) { return t + 1 < t1 ? t + 1 : t; };
   auto limit_of = [&](int t) { return t + 1 < t1 ? ctx : min(ctx, (t + 1) * 16); };
-  auto load_q = [&](bf16x8 (&Q)[4]) __attribute__((always_inline)) {
+  auto load_q = [&](bf16x8 (&Q)[DB]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < DB; ++kk) {
       u32x4 v;
       if (PIPE) v = *reinterpret_cast<const u32x4*>(&sm_q[PIPE && n < G ? n : 0][8 * g + 32 * kk]);
       else  // n >= G reads head 0 (valid memory)
-        v = *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * 128 +
+        v = *reinterpret_cast<const u32x4*>(q + (int64_t)b * q_stride + (int64_t)(h * G + (n < G ? n : 0)) * D +
                                             8 * g + 32 * kk);
       if (n >= G) v = u32x4{0, 0, 0, 0};
       Q[kk] = as_frag(v);
@@ -450,8 +458,8 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     // condition the following attend does not also sit under), so the compiler's vmcnt bookkeeping is
     // exact: an attend waits for ITS buffer only (s_waitcnt vmcnt(16)) while the other buffer's 16
     // fragment loads stay in flight behind it.
-    u32x4 AK0[4], AK1[4], AV0[4], AV1[4], BK0[4], BK1[4], BV0[4], BV1[4];
-    bf16x8 Q[4];
+    u32x4 AK0[DB], AK1[DB], AV0[DB], AV1[DB], BK0[DB], BK1[DB], BV0[DB], BV1[DB];
+    bf16x8 Q[DB];
     int ta = t0, tb = t0 + 2;
     // resolve_run (MI355_ATTN_RESOLVE=1, off by default - measured slower, see decode_impl): the wave's whole run of
     // block ids is read ONCE by one vector load issued ahead of everything else, lane i keeps the element offset of
@@ -480,27 +488,31 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     };
     auto load_a = [&]() __attribute__((always_inline)) {
       const int64_t o0 = tile_off(ta), o1 = tile_off(second(ta));
-      load_tiles_at(kc_h, o0, o1, lane, AK0, AK1);
-      load_tiles_at(vc_h, o0, o1, lane, AV0, AV1);
+      load_tiles_at<DB>(kc_h, o0, o1, lane, AK0, AK1);
+      load_tiles_at<DB>(vc_h, o0, o1, lane, AV0, AV1);
     };
     auto load_b = [&]() __attribute__((always_inline)) {
       const int64_t o0 = tile_off(tb), o1 = tile_off(second(tb));
-      load_tiles_at(kc_h, o0, o1, lane, BK0, BK1);
-      load_tiles_at(vc_h, o0, o1, lane, BV0, BV1);
+      load_tiles_at<DB>(kc_h, o0, o1, lane, BK0, BK1);
+      load_tiles_at<DB>(vc_h, o0, o1, lane, BV0, BV1);
     };
     auto attend_a = [&]() __attribute__((always_inline)) {
-      if (FUSE && (ta == new_tile || ta + 1 == new_tile)) {  // wave-uniform, true once per (sequence, kv head)
-        patch_new_token(AK0, AV0, sm_k, sm_v, new_tok, g, n, ta == new_tile);
-        patch_new_token(AK1, AV1, sm_k, sm_v, new_tok, g, n, ta + 1 == new_tile);
+      if constexpr (FUSE) {
+        if (ta == new_tile || ta + 1 == new_tile) {  // wave-uniform, true once per (sequence, kv head)
+          patch_new_token(AK0, AV0, sm_k, sm_v, new_tok, g, n, ta == new_tile);
+          patch_new_token(AK1, AV1, sm_k, sm_v, new_tok, g, n, ta + 1 == new_tile);
+        }
       }
-      attend_chunk<true>(AK0, AK1, AV0, AV1, Q, ta * 16, limit_of(ta), limit_of(ta), scale_log2e, g, m, l, acc);
+      attend_chunk<true, DB>(AK0, AK1, AV0, AV1, Q, ta * 16, limit_of(ta), limit_of(ta), scale_log2e, g, m, l, acc);
     };
     auto attend_b = [&]() __attribute__((always_inline)) {
-      if (FUSE && (tb == new_tile || tb + 1 == new_tile)) {
-        patch_new_token(BK0, BV0, sm_k, sm_v, new_tok, g, n, tb == new_tile);
-        patch_new_token(BK1, BV1, sm_k, sm_v, new_tok, g, n, tb + 1 == new_tile);
+      if constexpr (FUSE) {
+        if (tb == new_tile || tb + 1 == new_tile) {
+          patch_new_token(BK0, BV0, sm_k, sm_v, new_tok, g, n, tb == new_tile);
+          patch_new_token(BK1, BV1, sm_k, sm_v, new_tok, g, n, tb + 1 == new_tile);
+        }
       }
-      attend_chunk<true>(BK0, BK1, BV0, BV1, Q, tb * 16, limit_of(tb), limit_of(tb), scale_log2e, g, m, l, acc);
+      attend_chunk<true, DB>(BK0, BK1, BV0, BV1, Q, tb * 16, limit_of(tb), limit_of(tb), scale_log2e, g, m, l, acc);
     };
     if (tb < t1) {  // at least two chunks
       load_a();
@@ -550,29 +562,29 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
     }
   } else {
     int t = t0;
-    u32x4 K0[4], K1[4], V0[4], V1[4];
+    u32x4 K0[DB], K1[DB], V0[DB], V1[DB];
     if (t < t1) {
-      load_tiles(kc, table_row, t, second(t), h, kvs, tpb, lane, K0, K1);  // 16 fragment loads back to back
-      load_tiles(vc, table_row, t, second(t), h, kvs, tpb, lane, V0, V1);
-      bf16x8 Q[4];
+      load_tiles<DB>(kc, table_row, t, second(t), h, kvs, tpb, lane, K0, K1);  // 16 fragment loads back to back
+      load_tiles<DB>(vc, table_row, t, second(t), h, kvs, tpb, lane, V0, V1);
+      bf16x8 Q[DB];
       load_q(Q);
       while (true) {
-        attend_chunk(K0, K1, V0, V1, Q, t * 16, limit_of(t), limit_of(t), scale_log2e, g, m, l, acc);
+        attend_chunk<false, DB>(K0, K1, V0, V1, Q, t * 16, limit_of(t), limit_of(t), scale_log2e, g, m, l, acc);
         t += 2;
         if (t >= t1) break;
-        load_tiles(kc, table_row, t, second(t), h, kvs, tpb, lane, K0, K1);
-        load_tiles(vc, table_row, t, second(t), h, kvs, tpb, lane, V0, V1);
+        load_tiles<DB>(kc, table_row, t, second(t), h, kvs, tpb, lane, K0, K1);
+        load_tiles<DB>(vc, table_row, t, second(t), h, kvs, tpb, lane, V0, V1);
       }
     }
   }
-  if constexpr (STAMP) asm volatile("" ::"v"(acc[0]), "v"(acc[7]));
+  if constexpr (STAMP) asm volatile("" ::"v"(acc[0]), "v"(acc[2 * DB - 1]));
   MI_STAMP(5);  // this wave's run is attended
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
 
   if (n < G) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(&sm_o[wave][n][j * 16 + 4 * g]) = acc[j];
+    for (int j = 0; j < 2 * DB; ++j) *reinterpret_cast<f32x4*>(&sm_o[wave][n][j * 16 + 4 * g]) = acc[j];
     if (g == 0) {
       sm_m[wave][n] = m;
       sm_l[wave][n] = l;
@@ -581,8 +593,8 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
   __syncthreads();
   MI_STAMP(6);  // every wave of the workgroup has arrived
   // merge the waves (at least one of them had a chunk, so M is finite; empty ones weigh exp2(-inf) = 0)
-  for (int idx = threadIdx.x; idx < G * 128; idx += WAVES * 64) {
-    const int hn = idx >> 7, d = idx & 127;
+  for (int idx = threadIdx.x; idx < G * D; idx += WAVES * 64) {
+    const int hn = idx / D, d = idx % D;  // (D is a power of two: shifts)
     float M = sm_m[0][hn];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) M = fmaxf(M, sm_m[w][hn]);
@@ -594,10 +606,10 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
       L += e * sm_l[w][hn];
     }
     if (splits == 1) {
-      out[(row0 + hn) * 128 + d] = f2bf(o / L);
+      out[(row0 + hn) * D + d] = f2bf(o / L);
     } else {
       const int64_t slot = (row0 + hn) * 16 + split;
-      part_o[slot * 128 + d] = o;
+      part_o[slot * D + d] = o;
       if (d == 0) {
         part_ml[slot * 2] = M;
         part_ml[slot * 2 + 1] = L;
@@ -616,6 +628,7 @@ __global__ __launch_bounds__(WAVES * 64) void paged_attn_decode_kernel(
 }
 
 // merge the splits (small batches only): one wave per (sequence, q head) row, lane = 2 dims
+template <int D = 128>
 __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __restrict__ part_o,
                                                                const float* __restrict__ part_ml,
                                                                uint16_t* __restrict__ out, int n_rows, int splits) {
@@ -634,14 +647,14 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __re
   float2 acc = {0.f, 0.f};
   for (int s = 0; s < splits; ++s) {
     const float es = __shfl(e, s, 64);
-    if (es != 0.f) {  // wave-uniform; empty splits never wrote their partial rows
-      const float2 o = *reinterpret_cast<const float2*>(part_o + (row * 16 + s) * 128 + 2 * lane);
+    if (es != 0.f && 2 * lane < D) {  // (es: wave-uniform; empty splits never wrote their partial rows)
+      const float2 o = *reinterpret_cast<const float2*>(part_o + (row * 16 + s) * D + 2 * lane);
       acc.x += es * o.x;
       acc.y += es * o.y;
     }
   }
   const float inv = den > 0.f ? 1.0f / den : 0.f;
-  *reinterpret_cast<uint32_t*>(out + row * 128 + 2 * lane) = pack_bf(acc.x * inv, acc.y * inv);
+  if (2 * lane < D) *reinterpret_cast<uint32_t*>(out + row * D + 2 * lane) = pack_bf(acc.x * inv, acc.y * inv);
 }
 
 // ---------------------------------------------------------------------------
@@ -718,7 +731,9 @@ struct QPrep {
 //              block id of the NEXT request is read one chunk ahead, so the wait finds it landed.
 enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16 };
 
-template <int G, bool FUSE_Q, int VAR = 0>
+// DB = head_dim / 32 (4, or 2 for head_dim 64: plain q rows only).  G = 7 (Qwen2-0.5B, Qwen2.5-7B) runs as a group
+// of 8 columns per query token whose eighth column is masked out: 4 tokens x 7 heads per wave.
+template <int G, bool FUSE_Q, int VAR = 0, int DB = 4>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, const int32_t* __restrict__ block_table, int table_stride,
@@ -726,10 +741,13 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     int n_q_heads, int n_kv_heads, int tpb, int tpb_shift, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
   constexpr bool EARLY = (VAR & PV_EARLY) != 0, PAIR = (VAR & PV_PAIR) != 0, SPLIT_P = (VAR & PV_SPLIT_P) != 0;
   constexpr bool READ2 = (VAR & PV_READ2) != 0, PREF = !(VAR & PV_NOPREF) && !PAIR;
-  constexpr int TQ = 32 / G;        // query tokens per wave
+  static_assert(DB == 4 || (!FUSE_Q && VAR == 0), "head_dim 64: the default schedule over prepared q rows");
+  constexpr int D = 32 * DB, TILE = 512 * DB;  // head_dim; elements of a 16-token cache tile
+  constexpr int GP = G == 7 ? 8 : G;  // columns per query token (a power of two)
+  constexpr int TQ = 32 / GP;       // query tokens per wave
   constexpr int TQ_WG = 4 * TQ;     // per workgroup
   constexpr int NBUF = PAIR ? 4 : 3;  // LDS ring: chunk c is computed while c+1 and c+2 are landing
-  __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][4][2048];  // [buffer][K0,K1,V0,V1][tile]
+  __shared__ __attribute__((aligned(16))) uint16_t stage[NBUF][4][TILE];  // [buffer][K0,K1,V0,V1][tile]
 
   // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All query blocks of one
   // (sequence, kv head) re-read the same K/V tiles, so they are given ids that are equal mod 8:
@@ -753,17 +771,17 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
 
   const int qt0 = wg_qt0 + wave * TQ;
   const bool wave_on = qt0 < q_len;
-  const int my_qt = qt0 + n / G, hn = n % G;
-  const bool valid = wave_on && my_qt < q_len;
+  const int my_qt = qt0 + n / GP, hn = n % GP;
+  const bool valid = wave_on && my_qt < q_len && hn < G;
   const int limit = valid ? shift + my_qt + 1 : 1;  // keys [0, limit) are visible to this lane's column
   const int wave_chunks = wave_on ? (shift + min(qt0 + TQ, q_len) - 1 + 32) >> 5 : 0;
   const int limit_all = wave_on && qt0 + TQ <= q_len ? shift + qt0 + 1 : 0;  // earliest column of a full block
 
-  bf16x8 Q[8];  // B operand of S^T = K . Q^T: column n, dims 16 kk + 8 hi .. +7
+  bf16x8 Q[2 * DB];  // B operand of S^T = K . Q^T: column n, dims 16 kk + 8 hi .. +7
   auto prepare_q = [&]() __attribute__((always_inline)) {
     const int row = valid ? my_qt : wg_qt0;  // invalid columns read a valid row and are zeroed
-    const uint16_t* qrow = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * 128 + 8 * hi;
-    if (FUSE_Q) {
+    const uint16_t* qrow = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + (hn < G ? hn : 0)) * D + 8 * hi;
+    if constexpr (FUSE_Q) {
       float xq[8][8];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) load16(qrow + 16 * kk, xq[kk]);
@@ -776,7 +794,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
+      for (int kk = 0; kk < 2 * DB; ++kk) {
         u32x4 v = *reinterpret_cast<const u32x4*>(qrow + 16 * kk);
         if (!valid) v = u32x4{0, 0, 0, 0};
         Q[kk] = as_frag(v);
@@ -784,9 +802,9 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     }
   };
   float m = -INFINITY, l = 0.f;  // running max (log2 domain) and this lane's share of the running sum
-  f32x16 acc[4];
+  f32x16 acc[DB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < DB; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
@@ -794,7 +812,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   // 1 KiB rows of the 4 KiB cache tile per wave, each lane's 16 bytes landing at row + 16 * lane -
   // the cache tile is copied as it is stored, no registers and no ds_write involved
   const int32_t* table_row = block_table + (int64_t)seq * table_stride;
-  const KvStrides st = default_strides(n_kv_heads, tpb);
+  const KvStrides st = default_strides(n_kv_heads, tpb, 16 * D);
   const int piece = wave;
   // this wave's cache (K or V) at this kv head; the tile of a chunk is then one scalar load + one 64-bit multiply-add
   // away (tiles per block are a power of two for every block size but 48, 80, ...: shifts, not divisions - the
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* src = cache_h + (int64_t)blk * st.block + (int64_t)in_block * st.tile;
     uint16_t* dst = &stage[min(c, wg_chunks - 1) % NBUF][piece][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < DB; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
                                        (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
   };
@@ -854,7 +872,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
+      for (int kk = 0; kk < 2 * DB; ++kk) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(kt + (kk >> 1) * 512 + (kk & 1) * 256);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), Q[kk], s, 0, 0, 0);
       }
@@ -880,7 +898,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         l *= alpha;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < DB; ++j)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[j][i] *= alpha;
         m = mn;
@@ -898,7 +916,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         ph[i >> 2][i & 3] = hw;
         if (SPLIT_P) pl[i >> 2][i & 3] = pack_bf(p[2 * i] - lo_bf(hw), p[2 * i + 1] - hi_bf(hw));
       }
-      if (READ2) {
+      if constexpr (READ2) {
 #pragma unroll
         for (int sgm = 0; sgm < 2; ++sgm) {
           const uint16_t* vt = &stage[buf][2 + sgm][v_off];
@@ -919,26 +937,36 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         // be scheduled above it; LDS operations return in order, so the compiler's own lgkmcnt waits (its K reads of
         // the next chunk) only become more conservative by these.  Both key segments are requested up front - 16
         // reads in flight under the exponentials - and waited for segment by segment (lgkmcnt(8), then 0).
-        uint64_t va[2][4][2];
+        uint64_t va[2][DB][2];
         const uint32_t vaddr = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)&stage[buf][2][v_off];
-#define MI_V_READ(SG, DB)                                                          \
-  lds_read64_uncounted<(SG) * 4096 + (DB) * 1024>(va[SG][DB][0], vaddr);           \
-  lds_read64_uncounted<(SG) * 4096 + (DB) * 1024 + 512>(va[SG][DB][1], vaddr)
-        MI_V_READ(0, 0); MI_V_READ(0, 1); MI_V_READ(0, 2); MI_V_READ(0, 3);
-        MI_V_READ(1, 0); MI_V_READ(1, 1); MI_V_READ(1, 2); MI_V_READ(1, 3);
+        // (a key segment's V tile is TILE * 2 = DB KiB behind the other's; a 32-dim block 1 KiB behind the previous)
+#define MI_V_READ(SG, BLK)                                                               \
+  lds_read64_uncounted<(SG) * (2 * TILE) + (BLK) * 1024>(va[SG][BLK][0], vaddr);         \
+  lds_read64_uncounted<(SG) * (2 * TILE) + (BLK) * 1024 + 512>(va[SG][BLK][1], vaddr)
+        MI_V_READ(0, 0); MI_V_READ(0, 1);
+        if constexpr (DB == 4) { MI_V_READ(0, 2); MI_V_READ(0, 3); }
+        MI_V_READ(1, 0); MI_V_READ(1, 1);
+        if constexpr (DB == 4) { MI_V_READ(1, 2); MI_V_READ(1, 3); }
 #undef MI_V_READ
 #pragma unroll
         for (int sgm = 0; sgm < 2; ++sgm) {
-          if (sgm == 0)
-            asm volatile("s_waitcnt lgkmcnt(8)"
-                         : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]), "+v"(va[0][2][0]),
-                           "+v"(va[0][2][1]), "+v"(va[0][3][0]), "+v"(va[0][3][1]));
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(va[1][0][0]), "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1]), "+v"(va[1][2][0]),
-                           "+v"(va[1][2][1]), "+v"(va[1][3][0]), "+v"(va[1][3][1]));
+          if constexpr (DB == 4) {
+            if (sgm == 0)
+              asm volatile("s_waitcnt lgkmcnt(8)"
+                           : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]), "+v"(va[0][2][0]),
+                             "+v"(va[0][2][1]), "+v"(va[0][3][0]), "+v"(va[0][3][1]));
+            else
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(va[1][0][0]), "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1]), "+v"(va[1][2][0]),
+                             "+v"(va[1][2][1]), "+v"(va[1][3][0]), "+v"(va[1][3][1]));
+          } else {
+            if (sgm == 0)
+              asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]));
+            else
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[1][0][0]), "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1]));
+          }
 #pragma unroll
-          for (int db = 0; db < 4; ++db) {
+          for (int db = 0; db < DB; ++db) {
             const u32x4 a = {(uint32_t)va[sgm][db][0], (uint32_t)(va[sgm][db][0] >> 32), (uint32_t)va[sgm][db][1],
                              (uint32_t)(va[sgm][db][1] >> 32)};
             acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(ph[sgm]), acc[db], 0, 0, 0);
@@ -981,13 +1009,15 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     int rq_blk = table_row[rq_bi];
     int rd_slot = 0;
     for (int c = 0; c < wg_chunks; ++c) {
-      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      // (every wave requests DB pieces of 1 KiB per chunk: "all but my newest DB" = chunk c has landed)
+      if constexpr (DB == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
       {
-        // (a block is n_kv_heads x tpb x 4 KiB: its element stride fits 32 bits, one s_mul_i32 + s_mul_hi_i32)
-        const uint16_t* src = cache_h + (int64_t)rq_blk * (int)st.block + rq_in * MI_KV_TILE_ELEMS;
-        uint16_t* dst = &stage[0][piece][0] + rq_slot * (4 * 2048);
+        // (a block is n_kv_heads x tpb tiles: its element stride fits 32 bits, one s_mul_i32 + s_mul_hi_i32)
+        const uint16_t* src = cache_h + (int64_t)rq_blk * (int)st.block + rq_in * TILE;
+        uint16_t* dst = &stage[0][piece][0] + rq_slot * (4 * TILE);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < DB; ++i)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
                                            (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
       }
@@ -1014,30 +1044,33 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two padding loads
   __syncthreads();
   l = xor32_sum(l);
-  // O^T -> rows: each wave transposes its [128 dims][32 cols] tile through its 8 KiB quarter of the
-  // stage (all reads of the last chunk are behind the final barrier).  Column n's 256-byte row is
+  // O^T -> rows: each wave transposes its [D dims][32 cols] tile through its own D * 64 bytes of the
+  // stage (all reads of the last chunk are behind the final barrier).  Column n's 2 D-byte row is
   // XOR-swizzled in 8-byte pieces so that the 32 lanes of a write hit 32 different bank pairs.
-  uint16_t* tile = &stage[0][0][0] + wave * 4096;
+  uint16_t* tile = &stage[0][0][0] + wave * (32 * D);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
+  constexpr int PMASK = 8 * DB - 1;  // 8-byte pieces per row - 1
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int i4 = 0; i4 < 4; ++i4) {
       const int piece8 = db * 8 + i4 * 2 + hi;  // dims 4 piece8 .. +3  (= 32 db + 8 i4 + 4 hi)
       u32x2 o;
       o[0] = pack_bf(acc[db][4 * i4] * inv, acc[db][4 * i4 + 1] * inv);
       o[1] = pack_bf(acc[db][4 * i4 + 2] * inv, acc[db][4 * i4 + 3] * inv);
-      *reinterpret_cast<u32x2*>(tile + n * 128 + ((piece8 ^ n) & 31) * 4) = o;
+      *reinterpret_cast<u32x2*>(tile + n * D + ((piece8 ^ n) & PMASK) * 4) = o;
     }
   // same wave wrote and reads: LDS operations of a wave complete in order
+  constexpr int LPR = D / 8;        // lanes that store one row of 2 D bytes (16 bytes each)
+  constexpr int CPI = 64 / LPR;     // columns per iteration
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int col = it * 4 + (lane >> 4), d16 = lane & 15;  // 16 lanes store one 256-byte row
-    const int qt = qt0 + col / G;
-    const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + col * 128 + (((2 * d16) ^ col) & 31) * 4);
-    const u32x2 hh = *reinterpret_cast<const u32x2*>(tile + col * 128 + (((2 * d16 + 1) ^ col) & 31) * 4);
-    if (wave_on && qt < q_len) {
-      uint16_t* op = out + ((int64_t)(q_start + qt) * n_q_heads + h * G + col % G) * 128 + 8 * d16;
+  for (int it = 0; it < 32 / CPI; ++it) {
+    const int col = it * CPI + lane / LPR, dl = lane % LPR;
+    const int qt = qt0 + col / GP;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + col * D + (((2 * dl) ^ col) & PMASK) * 4);
+    const u32x2 hh = *reinterpret_cast<const u32x2*>(tile + col * D + (((2 * dl + 1) ^ col) & PMASK) * 4);
+    if (wave_on && qt < q_len && col % GP < G) {
+      uint16_t* op = out + ((int64_t)(q_start + qt) * n_q_heads + h * G + col % GP) * D + 8 * dl;
       *reinterpret_cast<u32x4*>(op) = u32x4{lo[0], lo[1], hh[0], hh[1]};
     }
   }
@@ -1069,10 +1102,11 @@ extern "C" size_t mi_paged_attn_decode_workspace(int batch, int n_q_heads) {
 static int check_attn_common(const void* q, const void* kc, const void* vc, const void* bt, int n_q_heads,
                              int n_kv_heads, int head_dim, int block_size, int64_t q_stride) {
   if (!q || !kc || !vc || !bt || n_q_heads <= 0 || n_kv_heads <= 0) return MI_EINVAL;
-  if (head_dim != MI_HEAD_DIM || block_size <= 0 || block_size % 16 || q_stride % 8) return MI_EUNSUPPORTED;
+  if ((head_dim != 128 && head_dim != 64) || block_size <= 0 || block_size % 16 || q_stride % 8) return MI_EUNSUPPORTED;
   if (n_q_heads % n_kv_heads) return MI_EUNSUPPORTED;
   const int G = n_q_heads / n_kv_heads;
-  if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) return MI_EUNSUPPORTED;
+  // (7 query heads per kv head: Qwen2-0.5B / Qwen2.5-7B - the plain entry points only, not the fused step forms)
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8 && G != 16) return MI_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(kc) || !aligned16(vc)) return MI_EINVAL;
   return MI_OK;
 }
@@ -1090,9 +1124,10 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   if (batch == 0) return MI_OK;
   if (ws_bytes < mi_paged_attn_decode_workspace(batch, n_q_heads)) return MI_EWORKSPACE;
   const int G = n_q_heads / n_kv_heads;
+  if (fused != nullptr && (head_dim != MI_HEAD_DIM || G == 7)) return MI_EUNSUPPORTED;
   // geometry: 0 = 16 waves, one chunk per wave in flight; 1 = 8 waves, two chunks per wave in flight.
   // The fused entry point always uses 1; the tuning knob MI_TUNE_ATTN_PIPE (default 1) selects it for the plain one.
-  const bool pipe = fused != nullptr || tuning(MI_TUNE_ATTN_PIPE) != 0;
+  const bool pipe = fused != nullptr || head_dim == 64 || G == 7 || tuning(MI_TUNE_ATTN_PIPE) != 0;
   const int waves = pipe ? 8 : decode_waves(G);
   int nsplit = num_splits > 0 ? num_splits : decode_splits(batch, n_kv_heads, pipe ? 16 : waves);
   if (nsplit > 16) nsplit = 16;
@@ -1111,14 +1146,14 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
   const dim3 grid(nsplit, n_kv_heads, batch);
   hipStream_t st = S(stream);
   const FusedStep fs = fused ? *fused : FusedStep{};
-#define LAUNCH_DEC_AS(GG, WW, FF, PP)                                                                          \
-  hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW, FF, PP>), grid, dim3(WW * 64), 0, st, q, q_row_stride, \
-                     k_cache, v_cache, block_table, table_stride, context_lens, part_o, part_ml, out,         \
+#define LAUNCH_DEC_AS(GG, WW, FF, PP, DD)                                                                            \
+  hipLaunchKernelGGL((paged_attn_decode_kernel<GG, WW, FF, PP, false, DD>), grid, dim3(WW * 64), 0, st, q,            \
+                     q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, part_o, part_ml, out, \
                      n_q_heads, kvs, block_size / 16, tpb_shift, resolve_run, sl2, fs)
-#define LAUNCH_DEC(GG, WW)                       \
-  if (fused) LAUNCH_DEC_AS(GG, 8, true, true);   \
-  else if (pipe) LAUNCH_DEC_AS(GG, 8, false, true); \
-  else LAUNCH_DEC_AS(GG, WW, false, false)
+#define LAUNCH_DEC(GG, WW)                              \
+  if (fused) LAUNCH_DEC_AS(GG, 8, true, true, 4);       \
+  else if (pipe) LAUNCH_DEC_AS(GG, 8, false, true, 4);  \
+  else LAUNCH_DEC_AS(GG, WW, false, false, 4)
   if (stamps != nullptr) {  // the instrumented kernel: the bench model's geometry only
     if (!fused || G != 2) return MI_EUNSUPPORTED;
     hipLaunchKernelGGL((paged_attn_decode_kernel<2, 8, true, true, true>), grid, dim3(8 * 64), 0, st, q, q_row_stride,
@@ -1126,24 +1161,40 @@ static int decode_impl(const mi_bf16* q, int64_t q_row_stride, const mi_bf16* k_
                        block_size / 16, tpb_shift, resolve_run, sl2, fs, stamps);
     rc = check_launch();
     if (rc != MI_OK || nsplit == 1) return rc;
-    hipLaunchKernelGGL(paged_attn_merge_kernel, dim3((batch * n_q_heads + 3) / 4), dim3(256), 0, st, part_o, part_ml, out,
-                       batch * n_q_heads, nsplit);
+    hipLaunchKernelGGL(paged_attn_merge_kernel<128>, dim3((batch * n_q_heads + 3) / 4), dim3(256), 0, st, part_o, part_ml,
+                       out, batch * n_q_heads, nsplit);
     return check_launch();
   }
-  switch (G) {
-    case 1: LAUNCH_DEC(1, 16); break;
-    case 2: LAUNCH_DEC(2, 16); break;
-    case 4: LAUNCH_DEC(4, 16); break;
-    case 8: LAUNCH_DEC(8, 8); break;
-    default: LAUNCH_DEC(16, 4); break;
+  if (head_dim == 64) {  // 2 KiB tiles (DB = 2): the 8-wave two-chunks-in-flight form for every group size
+    switch (G) {
+      case 1: LAUNCH_DEC_AS(1, 8, false, true, 2); break;
+      case 2: LAUNCH_DEC_AS(2, 8, false, true, 2); break;
+      case 4: LAUNCH_DEC_AS(4, 8, false, true, 2); break;
+      case 7: LAUNCH_DEC_AS(7, 8, false, true, 2); break;
+      case 8: LAUNCH_DEC_AS(8, 8, false, true, 2); break;
+      default: LAUNCH_DEC_AS(16, 8, false, true, 2); break;
+    }
+  } else {
+    switch (G) {
+      case 1: LAUNCH_DEC(1, 16); break;
+      case 2: LAUNCH_DEC(2, 16); break;
+      case 4: LAUNCH_DEC(4, 16); break;
+      case 7: LAUNCH_DEC_AS(7, 8, false, true, 4); break;
+      case 8: LAUNCH_DEC(8, 8); break;
+      default: LAUNCH_DEC(16, 4); break;
+    }
   }
 #undef LAUNCH_DEC
 #undef LAUNCH_DEC_AS
   rc = check_launch();
   if (rc != MI_OK || nsplit == 1) return rc;
   const int rows = batch * n_q_heads;
-  hipLaunchKernelGGL(paged_attn_merge_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, part_o, part_ml, out, rows,
-                     nsplit);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(paged_attn_merge_kernel<64>, dim3((rows + 3) / 4), dim3(256), 0, st, part_o, part_ml, out, rows,
+                       nsplit);
+  else
+    hipLaunchKernelGGL(paged_attn_merge_kernel<128>, dim3((rows + 3) / 4), dim3(256), 0, st, part_o, part_ml, out, rows,
+                       nsplit);
   return check_launch();
 }
 
@@ -1154,7 +1205,7 @@ extern "C" int mi_paged_attn_decode(const mi_bf16* q, int64_t q_row_stride, cons
                                     int block_size, float scale, mi_stream stream) {
   return decode_impl(q, q_row_stride, k_cache, v_cache, block_table, table_stride, context_lens, out,
                      workspace, ws_bytes, batch, n_q_heads, n_kv_heads, head_dim, block_size, scale, 0,
-                     default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1), stream);
+                     default_strides(n_kv_heads, block_size > 0 ? block_size / 16 : 1, 16 * head_dim), stream);
 }
 
 extern "C" int mi_paged_attn_decode_fused(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w,
@@ -1222,7 +1273,8 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   if (n_seqs == 0 || max_seqlen_q == 0) return MI_OK;
   const int G = n_q_heads / n_kv_heads;
   if ((int64_t)n_kv_heads * (block_size / 16) * MI_KV_TILE_ELEMS > INT32_MAX) return MI_EUNSUPPORTED;  // 32-bit block stride
-  const int tq_wg = 4 * (32 / G);  // query tokens per workgroup
+  if (prep != nullptr && (head_dim != MI_HEAD_DIM || G == 7)) return MI_EUNSUPPORTED;  // fused-Q form: 128-wide, 2^n groups
+  const int tq_wg = 4 * (32 / (G == 7 ? 8 : G));  // query tokens per workgroup
   const int n_qblocks = (max_seqlen_q + tq_wg - 1) / tq_wg, n_pairs = n_seqs * n_kv_heads;
   const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8 * n_qblocks));
   const float sl2 = scale * 1.4426950408889634f;
@@ -1256,13 +1308,37 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
     }
     return check_launch();
   }
-  switch (G) {
-    case 1: LAUNCH_PRE(1); break;
-    case 2: LAUNCH_PRE(2); break;
-    case 4: LAUNCH_PRE(4); break;
-    case 8: LAUNCH_PRE(8); break;
-    default: LAUNCH_PRE(16); break;
+#define LAUNCH_PRE_Q(GG, DD)                                                                                      \
+  do {                                                                                                            \
+    if (split_p)                                                                                                  \
+      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, false, PV_SPLIT_P * (DD == 4), DD>), grid, dim3(256), 0, st, q, \
+                         q_row_stride, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out,   \
+                         n_q_heads, n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);         \
+    else                                                                                                          \
+      hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, false, 0, DD>), grid, dim3(256), 0, st, q, q_row_stride,   \
+                         k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens, out, n_q_heads,      \
+                         n_kv_heads, block_size / 16, tpb_shift, sl2, n_qblocks, n_pairs, qp);                    \
+  } while (0)
+  if (head_dim == 64) {  // 2 KiB tiles, prepared q rows; P as one bf16 (the hi + lo form exists for 128-wide heads)
+    switch (G) {
+      case 1: LAUNCH_PRE_Q(1, 2); break;
+      case 2: LAUNCH_PRE_Q(2, 2); break;
+      case 4: LAUNCH_PRE_Q(4, 2); break;
+      case 7: LAUNCH_PRE_Q(7, 2); break;
+      case 8: LAUNCH_PRE_Q(8, 2); break;
+      default: LAUNCH_PRE_Q(16, 2); break;
+    }
+  } else {
+    switch (G) {
+      case 1: LAUNCH_PRE(1); break;
+      case 2: LAUNCH_PRE(2); break;
+      case 4: LAUNCH_PRE(4); break;
+      case 7: LAUNCH_PRE_Q(7, 4); break;
+      case 8: LAUNCH_PRE(8); break;
+      default: LAUNCH_PRE(16); break;
+    }
   }
+#undef LAUNCH_PRE_Q
 #undef LAUNCH_PRE
 #undef LAUNCH_PRE_AS
   return check_launch();

@@ -184,8 +184,8 @@ class ModelRunner:
         if ops.attention_is_plain(hq, hkv, head_dim) and not ops.attention_plain_supported(hq, hkv, head_dim):
             raise NotImplementedError(
                 f"head_dim {head_dim} with {hq} query heads over {hkv} kv heads: the fragment-native attention kernels "
-                "take head_dim 128 with GQA groups 1, 2, 4, 8, 16; the plain-layout kernels head_dim 64 or 128 with "
-                "groups up to 8")
+                "take head_dim 64 or 128 with GQA groups 1, 2, 4, 7, 8, 16; the plain-layout kernels head_dim 64 or 128 "
+                "with any group up to 8")
         if hq % self.world_size or hkv % self.world_size:
             raise ValueError(f"tensor_parallel_size {self.world_size} does not divide {hq} query / {hkv} kv heads")
         if getattr(hf, "num_experts", 0) and getattr(hf, "moe_intermediate_size", 0):
@@ -287,7 +287,7 @@ class ModelRunner:
         if ops.attention_is_plain(hq, n_kv, head_dim):  # head_dim 64 / odd GQA groups: [blocks, kv heads, block, head_dim]
             shape = ops.kv_cache_shape_plain(alloc_blocks, n_kv, self.block_size, head_dim)
         else:
-            shape = ops.kv_cache_shape(alloc_blocks, n_kv, self.block_size)
+            shape = ops.kv_cache_shape(alloc_blocks, n_kv, self.block_size, head_dim)
         self.kv_cache = torch.zeros((2, layers, *shape), dtype=torch.bfloat16, device=self.device)
         layer_id = 0
         for module in self.model.modules():

@@ -4,8 +4,8 @@ mi_reshape_and_cache / mi_scatter_update_kv / mi_paged_attn_prefill / mi_paged_a
 Same constructor and forward signature as the reference class; the runner injects
 `k_cache` / `v_cache` into every module that has both attributes
 (model_runner.py:222-229) and the per-step metadata arrives through get_context().
-The caches use the fragment-native layout of include/mi355_nanovllm.h - or, for the head geometries those kernels
-are not built for (head_dim 64, GQA groups that are not a power of two: `self.plain`), the plain
+The caches use the fragment-native layout of include/mi355_nanovllm.h (head_dim 128 or 64; 1, 2, 4, 7, 8 or 16 query
+heads per kv head) - or, for the head geometries those kernels are not built for (`self.plain`), the plain
 [blocks, kv heads, block, head_dim] layout and the mi_*_plain kernels (csrc/attn_plain.hip).
 """
 from __future__ import annotations
@@ -28,6 +28,9 @@ class Attention(nn.Module):
         self.k_cache = torch.tensor([])
         self.v_cache = torch.tensor([])
         self.plain = ops.attention_is_plain(num_heads, num_kv_heads, head_dim)
+        # the fused launches (models/qwen3.py) are written for 128-wide heads and power-of-two groups; head_dim 64 and
+        # groups of 7 take the module-by-module sequence RoPE -> store -> attention on the same fragment-native kernels
+        self.fusable = ops.attention_is_fusable(num_heads, num_kv_heads, head_dim)
 
     def _store_kvcache(self, k: torch.Tensor, v: torch.Tensor, context) -> None:
         """attention.py:22-35: flat slots in prefill, [block, offset] pairs in decode."""

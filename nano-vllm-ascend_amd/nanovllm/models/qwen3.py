@@ -81,7 +81,7 @@ class Qwen3Attention(nn.Module):
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
-        if self.fused and self.attn.k_cache.numel() > 0 and not self.attn.plain:
+        if self.fused and self.attn.k_cache.numel() > 0 and self.attn.fusable:
             o = self._attend_fused(positions, qkv)
         else:
             o = self._attend_unfused(positions, qkv)
@@ -277,7 +277,7 @@ class Qwen3Model(nn.Module):
                       and os.environ.get("MI355_XGMI_FUSED", "1") != "0")
 
         def attend(attn, qkv):
-            if attn.attn.plain:
+            if not attn.attn.fusable:  # head_dim 64 / groups of 7 / the plain-layout family: one launch per operator
                 return attn._attend_unfused(positions, qkv).flatten(1, -1)
             if not fuse_attn:
                 return attn._attend_fused(positions, qkv)

@@ -20,10 +20,16 @@ def _bf16(*ts: torch.Tensor) -> None:
 
 
 # --------------------------------------------------------------------------- KV cache
-def kv_cache_shape(num_blocks: int, n_kv_heads: int, block_size: int) -> tuple[int, int, int, int]:
-    """Shape of one layer's K (or V) cache in the fragment-native layout."""
-    assert block_size % _C.KV_TILE_TOKENS == 0
-    return (num_blocks, n_kv_heads, block_size // _C.KV_TILE_TOKENS, KV_TILE_ELEMS)
+def kv_cache_shape(num_blocks: int, n_kv_heads: int, block_size: int, head_dim: int = HEAD_DIM) -> tuple[int, int, int, int]:
+    """Shape of one layer's K (or V) cache in the fragment-native layout: one tile of 16 tokens x head_dim (4 KiB at
+    head_dim 128, 2 KiB at 64) per (16 slots, kv head)."""
+    assert block_size % _C.KV_TILE_TOKENS == 0 and head_dim in (64, HEAD_DIM)
+    return (num_blocks, n_kv_heads, block_size // _C.KV_TILE_TOKENS, _C.KV_TILE_TOKENS * head_dim)
+
+
+def _head_dim_of(cache: torch.Tensor) -> int:
+    """head_dim of a fragment-native cache tensor [..., 16 * head_dim]"""
+    return cache.shape[-1] // _C.KV_TILE_TOKENS
 
 
 def reshape_and_cache(k, v, k_cache, v_cache, slot_flat, n_kv_heads: int, block_size: int) -> None:
@@ -34,7 +40,7 @@ def reshape_and_cache(k, v, k_cache, v_cache, slot_flat, n_kv_heads: int, block_
     assert slot_flat.dtype == torch.int32 and slot_flat.is_contiguous() and slot_flat.numel() == n
     check(
         lib.mi_reshape_and_cache(ptr(k), ptr(v), k.stride(0), v.stride(0), ptr(k_cache), ptr(v_cache),
-                                 ptr(slot_flat), n, n_kv_heads, HEAD_DIM, block_size, stream()),
+                                 ptr(slot_flat), n, n_kv_heads, _head_dim_of(k_cache), block_size, stream()),
         "mi_reshape_and_cache",
     )
 
@@ -46,7 +52,7 @@ def scatter_update_kv(k, v, k_cache, v_cache, slot_2d, n_kv_heads: int, block_si
     assert slot_2d.dtype == torch.int32 and slot_2d.is_contiguous() and slot_2d.shape == (n, 2)
     check(
         lib.mi_scatter_update_kv(ptr(k), ptr(v), k.stride(0), v.stride(0), ptr(k_cache), ptr(v_cache),
-                                 ptr(slot_2d), n, n_kv_heads, HEAD_DIM, block_size, stream()),
+                                 ptr(slot_2d), n, n_kv_heads, _head_dim_of(k_cache), block_size, stream()),
         "mi_scatter_update_kv",
     )
 
@@ -54,10 +60,10 @@ def scatter_update_kv(k, v, k_cache, v_cache, slot_2d, n_kv_heads: int, block_si
 def kv_cache_gather(cache, is_v: bool, slot_flat, n_kv_heads: int, block_size: int) -> torch.Tensor:
     """Rows of the cache in the reference's logical layout [n, n_kv_heads*128]."""
     require_gpu(cache, slot_flat)
-    n = slot_flat.numel()
-    out = torch.empty((n, n_kv_heads * HEAD_DIM), dtype=_BF16, device=cache.device)
+    n, D = slot_flat.numel(), _head_dim_of(cache)
+    out = torch.empty((n, n_kv_heads * D), dtype=_BF16, device=cache.device)
     check(
-        lib.mi_kv_cache_gather(ptr(cache), int(is_v), ptr(slot_flat), n, ptr(out), n_kv_heads, HEAD_DIM,
+        lib.mi_kv_cache_gather(ptr(cache), int(is_v), ptr(slot_flat), n, ptr(out), n_kv_heads, D,
                                block_size, stream()),
         "mi_kv_cache_gather",
     )
@@ -81,20 +87,20 @@ def paged_attn_decode(q, k_cache, v_cache, block_tables, context_lens, n_q_heads
                       block_size: int, scale: float, out=None, workspace=None) -> torch.Tensor:
     require_gpu(q, k_cache, v_cache, block_tables, context_lens)
     _bf16(q, k_cache, v_cache)
-    batch = q.shape[0]
+    batch, D = q.shape[0], _head_dim_of(k_cache)
     q2 = q.view(batch, -1) if q.dim() == 3 else q
-    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * HEAD_DIM
+    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * D
     assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
     assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
     if out is None:
-        out = torch.empty((batch, n_q_heads * HEAD_DIM), dtype=_BF16, device=q.device)
+        out = torch.empty((batch, n_q_heads * D), dtype=_BF16, device=q.device)
     if workspace is None:
         workspace = attn_workspace(q.device, batch, n_q_heads)
     check(
         lib.mi_paged_attn_decode(ptr(q2), q2.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
                                  block_tables.stride(0), ptr(context_lens), ptr(out), ptr(workspace),
                                  workspace.numel() * workspace.element_size(), batch, n_q_heads, n_kv_heads,
-                                 HEAD_DIM, block_size, float(scale), stream()),
+                                 D, block_size, float(scale), stream()),
         "mi_paged_attn_decode",
     )
     return out
@@ -157,19 +163,19 @@ def paged_attn_prefill(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens,
                        n_q_heads: int, n_kv_heads: int, block_size: int, scale: float, out=None) -> torch.Tensor:
     require_gpu(q, k_cache, v_cache, block_tables, cu_seqlens_q, kv_lens)
     _bf16(q, k_cache, v_cache)
-    T = q.shape[0]
+    T, D = q.shape[0], _head_dim_of(k_cache)
     q2 = q.view(T, -1) if q.dim() == 3 else q
-    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * HEAD_DIM
+    assert q2.stride(1) == 1 and q2.shape[1] == n_q_heads * D
     assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
     assert cu_seqlens_q.dtype == torch.int32 and kv_lens.dtype == torch.int32
     n_seqs = cu_seqlens_q.numel() - 1
     assert kv_lens.numel() == n_seqs and block_tables.shape[0] >= n_seqs
     if out is None:
-        out = torch.empty((T, n_q_heads * HEAD_DIM), dtype=_BF16, device=q.device)
+        out = torch.empty((T, n_q_heads * D), dtype=_BF16, device=q.device)
     check(
         lib.mi_paged_attn_prefill(ptr(q2), q2.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
                                   block_tables.stride(0), ptr(cu_seqlens_q), ptr(kv_lens), n_seqs,
-                                  int(max_seqlen_q), ptr(out), n_q_heads, n_kv_heads, HEAD_DIM, block_size,
+                                  int(max_seqlen_q), ptr(out), n_q_heads, n_kv_heads, D, block_size,
                                   float(scale), stream()),
         "mi_paged_attn_prefill",
     )
@@ -254,8 +260,18 @@ def add_rmsnorm(x, residual, w, eps: float, out=None, residual_out=None):
 # --------------------------------------------------------------------------- rope (+ fused)
 # ---- plain-layout attention family (csrc/attn_plain.hip): head_dim 64, GQA groups that are not a power of two ----
 def attention_is_plain(n_q_heads: int, n_kv_heads: int, head_dim: int) -> bool:
-    """True: this head geometry runs on the mi_*_plain kernels and the [blocks, kv heads, block, head_dim] cache."""
-    return head_dim != HEAD_DIM or n_q_heads % n_kv_heads != 0 or (n_q_heads // n_kv_heads) not in (1, 2, 4, 8, 16)
+    """True: this head geometry runs on the mi_*_plain kernels and the [blocks, kv heads, block, head_dim] cache.
+    Round 4: head_dim 64 and 7 query heads per kv head (Llama-3.2-1B, Qwen2-0.5B, Qwen2.5-7B - the reference's README
+    models) run on the fragment-native MFMA kernels; the plain family remains for what is left (e.g. groups of 3, 5, 6)."""
+    if n_q_heads % n_kv_heads != 0:
+        return True
+    return not (head_dim in (64, HEAD_DIM) and (n_q_heads // n_kv_heads) in (1, 2, 4, 7, 8, 16))
+
+
+def attention_is_fusable(n_q_heads: int, n_kv_heads: int, head_dim: int) -> bool:
+    """True: the fused forms apply (q/k-norm + RoPE + KV store inside the decode attention launch, q prepared in the
+    prefill attention's operand load): written for 128-wide heads and power-of-two groups."""
+    return head_dim == HEAD_DIM and n_q_heads % n_kv_heads == 0 and (n_q_heads // n_kv_heads) in (1, 2, 4, 8, 16)
 
 
 def attention_plain_supported(n_q_heads: int, n_kv_heads: int, head_dim: int) -> bool:

@@ -26,6 +26,8 @@ TINY_MOE = dict(TINY, architectures=["Qwen3MoeForCausalLM"], model_type="qwen3_m
 TINY_QWEN2_HD64 = dict(TINY, architectures=["Qwen2ForCausalLM"], model_type="qwen2", hidden_size=128, head_dim=64,
                        num_attention_heads=7, num_key_value_heads=1, attention_bias=True)
 TINY_LLAMA_HD64 = dict(TINY_LLAMA, hidden_size=256, head_dim=64, num_attention_heads=4, num_key_value_heads=1)
+# a head geometry that still belongs to the plain-layout family after round 4 (three query heads per kv head)
+TINY_LLAMA_HD64_G3 = dict(TINY_LLAMA, hidden_size=384, head_dim=64, num_attention_heads=6, num_key_value_heads=2)
 
 # the two small models the reference's README benchmarks next to Qwen3-0.6B (README.md:316-318), full shapes
 QWEN2_0_5B = dict(

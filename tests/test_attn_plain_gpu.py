@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from model_configs import TINY_LLAMA_HD64, TINY_QWEN2_HD64
+from model_configs import TINY_LLAMA_HD64, TINY_LLAMA_HD64_G3, TINY_QWEN2_HD64
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -135,16 +135,23 @@ def test_plain_attention_rejects_what_it_cannot_do(ops):
     ctx = torch.ones(2, dtype=torch.int32, device=DEV)
     with pytest.raises(MiError):  # nine query heads per kv head
         ops.paged_attn_decode_plain(q, kc, kc, bt, ctx, 9, 1, 16, 0.125)
-    assert ops.attention_is_plain(14, 2, 64) and ops.attention_is_plain(28, 4, 128) and not ops.attention_is_plain(16, 8, 128)
+    # (since round 4 the README models' geometries run on the fragment-native kernels: tests/test_attn_hd64_gpu.py)
+    assert ops.attention_is_plain(6, 2, 64) and ops.attention_is_plain(12, 4, 128) and not ops.attention_is_plain(16, 8, 128)
     assert not ops.attention_plain_supported(16, 1, 64) and not ops.attention_plain_supported(8, 1, 96)
 
 
-@pytest.mark.parametrize("cfg_name", ["qwen2_hd64_gqa7", "llama_hd64_gqa4"])
+@pytest.mark.parametrize("cfg_name", ["qwen2_hd64_gqa7", "llama_hd64_gqa4", "llama_hd64_gqa3"])
 @pytest.mark.parametrize("enforce_eager", [True, False])
-def test_engine_with_plain_attention_matches_oracle(cfg_name, enforce_eager):
-    """tiny models with Qwen2-0.5B's and Llama-3.2-1B's head geometry through the whole engine (eager prefill,
-    eager and hipGraph decode incl. the in-graph sampler) against the oracle model on the same weights"""
+def test_engine_with_small_head_geometries_matches_oracle(cfg_name, enforce_eager):
+    """tiny models with Qwen2-0.5B's and Llama-3.2-1B's head geometry (fragment-native MFMA kernels on 2 KiB tiles since
+    round 4: RoPE -> store -> attention, one launch each) and with three query heads per kv head (the plain-layout
+    family) through the whole engine (eager prefill, eager and hipGraph decode incl. the in-graph sampler) against the
+    oracle model on the same weights"""
     from test_engine_gpu import _engine_vs_oracle
 
-    cfg = {"qwen2_hd64_gqa7": TINY_QWEN2_HD64, "llama_hd64_gqa4": TINY_LLAMA_HD64}[cfg_name]
+    cfg = {"qwen2_hd64_gqa7": TINY_QWEN2_HD64, "llama_hd64_gqa4": TINY_LLAMA_HD64, "llama_hd64_gqa3": TINY_LLAMA_HD64_G3}[cfg_name]
+    from nanovllm import ops
+
+    hq, hkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    assert ops.attention_is_plain(hq, hkv, 64) == (cfg_name == "llama_hd64_gqa3")
     _engine_vs_oracle(cfg, lens=[5, 33, 64, 17, 100], enforce_eager=enforce_eager, seed=11, tol=4e-2, max_tokens=6)

@@ -144,31 +144,42 @@ def mlp_half():
 
 
 def plain_attention():
-    """The plain-layout attention kernels (csrc/attn_plain.hip) at the reference README's small-model geometries:
-    decode bs 32 x ctx 1024 (HBM bytes = K + V rows of every context token) and prefill 16 x 1024 tokens."""
+    """The reference README's small-model head geometries (KBENCH_ONLY=plain): decode bs 32 x ctx 1024 (HBM bytes = K + V
+    rows of every context token) and prefill 16 x 1024 tokens, on the plain-layout family (csrc/attn_plain.hip, the
+    round-3 path) and on the fragment-native MFMA kernels over 2 KiB tiles / groups of 7 (round 4)."""
     B, T, bs, L = 32, 1024, 16, 4
     nb = (T + bs - 1) // bs
     g = torch.Generator(device="cpu").manual_seed(0)
     for name, hq, hkv, d in (("Qwen2-0.5B 14/2 x 64", 14, 2, 64), ("Llama-3.2-1B 32/8 x 64", 32, 8, 64),
                              ("Qwen2.5-7B 28/4 x 128", 28, 4, 128)):
-        kc = [torch.randn(ops.kv_cache_shape_plain(B * nb, hkv, bs, d), device=DEV).bfloat16() for _ in range(L)]
-        vc = [torch.randn(ops.kv_cache_shape_plain(B * nb, hkv, bs, d), device=DEV).bfloat16() for _ in range(L)]
         tables = torch.randperm(B * nb, generator=g).to(torch.int32).view(B, nb).to(DEV)
         q = torch.randn(B, hq * d, device=DEV).bfloat16()
         out = torch.empty_like(q)
         ctx = torch.full((B,), T, dtype=torch.int32, device=DEV)
-        t = timeit(lambda l: ops.paged_attn_decode_plain(q, kc[l], vc[l], tables, ctx, hq, hkv, bs, d ** -0.5, out=out), L)
-        byt = B * 2 * T * hkv * d * 2
         n = 16
         qp = torch.randn(n * T, hq * d, device=DEV).bfloat16()
         op = torch.empty_like(qp)
         cu = (torch.arange(n + 1, dtype=torch.int32) * T).to(DEV)
         kvl = torch.full((n,), T, dtype=torch.int32, device=DEV)
-        tp = timeit(lambda l: ops.paged_attn_prefill_plain(qp, kc[l], vc[l], tables[:n], cu, kvl, T, hq, hkv, bs, d ** -0.5,
-                                                           out=op), L)
+        byt = B * 2 * T * hkv * d * 2
         flops = n * hq * (T * (T + 1) / 2) * d * 2 * 2
-        print(f"{name}: decode bs {B} ctx {T} {t * 1e6:7.1f} us = {byt / t / 1e9:6.0f} GB/s ({byt / t / PEAK:.2f} of 8 TB/s); "
-              f"prefill 16x{T} {tp * 1e6:8.1f} us = {flops / tp / 1e12:5.1f} TFLOP/s useful")
+        for family in ("plain layout", "fragment-native"):
+            shape = ops.kv_cache_shape_plain(B * nb, hkv, bs, d) if family == "plain layout" else ops.kv_cache_shape(B * nb, hkv, bs, d)
+            kc = [torch.randn(shape, device=DEV).bfloat16() for _ in range(L)]
+            vc = [torch.randn(shape, device=DEV).bfloat16() for _ in range(L)]
+            if family == "plain layout":
+                t = timeit(lambda l: ops.paged_attn_decode_plain(q, kc[l], vc[l], tables, ctx, hq, hkv, bs, d ** -0.5, out=out), L)
+                tp = timeit(lambda l: ops.paged_attn_prefill_plain(qp, kc[l], vc[l], tables[:n], cu, kvl, T, hq, hkv, bs,
+                                                                   d ** -0.5, out=op), L)
+            else:
+                ws = ops.attn_workspace(DEV, B, hq)
+                t = timeit(lambda l: ops.paged_attn_decode(q, kc[l], vc[l], tables, ctx, hq, hkv, bs, d ** -0.5, out=out,
+                                                           workspace=ws), L)
+                tp = timeit(lambda l: ops.paged_attn_prefill(qp, kc[l], vc[l], tables[:n], cu, kvl, T, hq, hkv, bs, d ** -0.5,
+                                                             out=op), L)
+            print(f"{name} [{family:15s}]: decode bs {B} ctx {T} {t * 1e6:7.1f} us = {byt / t / 1e9:6.0f} GB/s "
+                  f"({byt / t / PEAK:.2f} of 8 TB/s); prefill 16x{T} {tp * 1e6:8.1f} us = {flops / tp / 1e12:5.1f} TFLOP/s useful",
+                  flush=True)
 
 
 def head_and_sampler():

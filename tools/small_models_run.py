@@ -1,6 +1,7 @@
 """Qwen2-0.5B and Llama-3.2-1B at their full shapes (synthetic weights) through the engine: the models the reference's
-README benchmarks beside Qwen3-0.6B, on the plain-layout attention family (csrc/attn_plain.hip).  Prints one JSON line
-per model: prefill rate of 16 x 1024-token prompts, decode step time and rate at bs 32 and bs 256 (hipGraph, greedy).
+README benchmarks beside Qwen3-0.6B.  Since round 4 both run on the fragment-native attention kernels (head_dim 64 tiles,
+7 and 4 query heads per kv head); `plain_attention` in the output says which family the engine picked.  Prints one JSON
+line per model: prefill rate of 16 x 1024-token prompts, decode step time and rate at bs 32 and bs 256 (hipGraph, greedy).
 usage: python tools/small_models_run.py"""
 import json
 import os
