@@ -453,6 +453,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
   if (!(V & 2) && fh == 0) MI_GT_BARRIER();         // barrier counts match again
 }
 
+#include "gemm_w4_kernel.hpp"
+
 // ---------------------------------------------------------------------------
 // The same GEMM on 128 x 128 tiles, for shapes whose 256 x 256 tiles cannot fill the chip (64 < M <= ~2048 rows:
 // large decode batches, short prompts).  Four waves, each 64 features x 64 tokens (2 x 2 accumulators); one K step of
@@ -642,13 +644,17 @@ static int tile_ksplit(int M, int N, int K) {
   return ks;
 }
 
+// V & kEightWaves: the eight-wave ping-pong kernel of rounds 2-3 (tuning / comparison only); otherwise the
+// four-wave kernel (gemm_w4_kernel.hpp)
+constexpr int kEightWaves = 1 << 20;
 template <int EPI, bool BIAS, int V = kDefaultV>
 static int launch_tile(const TileArgs& a, hipStream_t st, int ksplit = 1) {
   // persistent workgroups: one per CU; the grid is a multiple of 8, so a workgroup stays in one XCD class
   const int ntiles = a.tiles_f * a.tiles_t;
   const bool persistent = !(V & 16) && ntiles > kPersistentGrid;
-  hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, V>), dim3(persistent ? kPersistentGrid : ntiles, ksplit), dim3(512), 0,
-                     st, a);
+  const dim3 grid(persistent ? kPersistentGrid : ntiles, ksplit);
+  if (V & kEightWaves) hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, V & ~kEightWaves>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V>), grid, dim3(256), 0, st, a);
   return check_launch();
 }
 
@@ -710,7 +716,7 @@ static int check_tile_gemm(const void* x, int64_t ldx, const void* w, const void
   if (epilogue == 1 && (bias || (N / 2) % 128)) return MI_EUNSUPPORTED;  // (the 128-tile kernel alone would take % 64)
   if (ldy < (epilogue == 1 ? N / 2 : N)) return MI_EINVAL;
   // the DMA sources are 32-bit byte offsets from the operand bases
-  if ((int64_t)N * K * 2 >= (int64_t)1 << 32 || (int64_t)M * ldx * 2 >= (int64_t)1 << 32) return MI_EUNSUPPORTED;
+  if (((int64_t)N + 256) * K * 2 >= (int64_t)1 << 32 || ((int64_t)M + 256) * ldx * 2 >= (int64_t)1 << 32) return MI_EUNSUPPORTED;
   return MI_OK;
 }
 
@@ -756,20 +762,31 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
   const TileArgs a{x, w, nullptr, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T, nullptr};
   hipStream_t st = S(stream);
   switch (variant) {
+    // the four-wave product kernel and its variants
     case 0: return launch_tile<TEPI_NONE, false, 0>(a, st);
-    case 2: return launch_tile<TEPI_NONE, false, 2>(a, st);
     case 4: return launch_tile<TEPI_NONE, false, 4>(a, st);
     case 8: return launch_tile<TEPI_NONE, false, 8>(a, st);
     case 16: return launch_tile<TEPI_NONE, false, 16>(a, st);
+    case 20: return launch_tile<TEPI_NONE, false, 20>(a, st);
     case 32: return launch_tile<TEPI_NONE, false, 32>(a, st);
     case 64: return launch_tile<TEPI_NONE, false, 64>(a, st);
     case 96: return launch_tile<TEPI_NONE, false, 96>(a, st);
     case 224: return launch_tile<TEPI_NONE, false, 224>(a, st);
     case 256: return launch_tile<TEPI_NONE, false, 256>(a, st);
     case 512: return launch_tile<TEPI_NONE, false, 512>(a, st);
+    case 768: return launch_tile<TEPI_NONE, false, 768>(a, st);
     case 1024: return launch_tile<TEPI_NONE, false, 1024>(a, st);
-    case 8192: return launch_tile<TEPI_NONE, false, 8192>(a, st);
-    case 9216: return launch_tile<TEPI_NONE, false, 9216>(a, st);
+    case 1536: return launch_tile<TEPI_NONE, false, 1536>(a, st);
+    // the eight-wave kernel of rounds 2-3 and its variants
+    case kEightWaves: return launch_tile<TEPI_NONE, false, kEightWaves>(a, st);
+    case kEightWaves + 2: return launch_tile<TEPI_NONE, false, kEightWaves + 2>(a, st);
+    case kEightWaves + 4: return launch_tile<TEPI_NONE, false, kEightWaves + 4>(a, st);
+    case kEightWaves + 8: return launch_tile<TEPI_NONE, false, kEightWaves + 8>(a, st);
+    case kEightWaves + 16: return launch_tile<TEPI_NONE, false, kEightWaves + 16>(a, st);
+    case kEightWaves + 512: return launch_tile<TEPI_NONE, false, kEightWaves + 512>(a, st);
+    case kEightWaves + 1024: return launch_tile<TEPI_NONE, false, kEightWaves + 1024>(a, st);
+    case kEightWaves + 8192: return launch_tile<TEPI_NONE, false, kEightWaves + 8192>(a, st);
+    case kEightWaves + 9216: return launch_tile<TEPI_NONE, false, kEightWaves + 9216>(a, st);
     case 65536: return launch_mid<TEPI_NONE, false, 4>(a, st);  // the 128-tile kernel, no K slices, four-stage ring
     case 65538: return launch_mid<TEPI_NONE, false, 2>(a, st);  // ... with a two-stage ring, two workgroups per CU
     case 65539: return launch_mid<TEPI_NONE, false, 3>(a, st);

@@ -86,5 +86,32 @@ MI_HD constexpr int mid_b_local_row(int tw, int b, int l31) { return tw * 64 + b
 MI_HD constexpr int mid_acc_feature(int fw, int f, int r, int hi) { return fw * 64 + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 MI_HD constexpr int mid_acc_token(int tw, int b, int l31) { return tw * 64 + b * 32 + l31; }
 
+// ---- the four-wave 256 x 256 x 64 kernel (gemm_w4_kernel, the product kernel for large M since round 4) ----
+// One wave per SIMD: fw = wave >> 1 (128 features), tw = wave & 1 (128 tokens), wave tile 128 x 128 = 4 x 4 accumulators.
+// One K step of the tile in LDS is ONE 64 KiB image: A region (256 feature rows x 128 bytes) then B region (256 token
+// rows); row r of a region at (r >> 3) * 1024 + (r & 7) * 128, 16-byte chunks XOR-swizzled by swizzle(r) as above.  Two
+// images (steps t and t + 1) = 128 KiB.  The image is fed by 64 `buffer_load_dwordx4 ... lds` pieces of 1 KiB
+// (8 rows): wave w moves pieces 16 w .. 16 w + 15, i.e. waves 0, 1 the A region's rows 0..127 / 128..255, waves 2, 3
+// the B region's.
+constexpr int W4_STEP_BYTES = 65536, W4_REGION = 32768, W4_PIECES = 16;
+MI_HD constexpr int w4_row_off(int r, int c) { return (r >> 3) * 1024 + (r & 7) * 128 + ((c ^ swizzle(r)) << 4); }
+MI_HD constexpr bool w4_wave_is_weight(int wave) { return wave < 2; }
+// row (inside its region) and K chunk fetched by lane `lane` of piece i of wave `wave`; it lands at byte 16 * lane of
+// the piece = where w4_row_off() expects (row, chunk)
+MI_HD constexpr int w4_dma_row(int wave, int i, int lane) { return (wave & 1) * 128 + i * 8 + (lane >> 3); }
+MI_HD constexpr int w4_dma_chunk(int i, int lane) { return (lane & 7) ^ (((i & 1) << 2) + (lane >> 4)); }  // = ^ swizzle(row)
+MI_HD constexpr int w4_piece_off(int wave, int i) { return (wave & 1) * 16384 + i * 1024; }  // inside the region
+// weight row of A-region row r for the tile at feature n0: plain, or SwiGLU (each wave's 128 rows = 64 gate rows, then
+// the 64 up rows that pair with them; n0 counts gate + up rows, n0 / 2 output columns)
+MI_HD constexpr int w4_weight_row(int r, int n0, int N, bool silu) {
+  return silu ? ((r >> 6) & 1) * (N >> 1) + (n0 >> 1) + (r >> 7) * 64 + (r & 63) : n0 + r;
+}
+// fragment i (0..3) of wave half fw / tw, k group kk: region row, chunk frag_chunk(kk, hi)
+MI_HD constexpr int w4_a_row(int fw, int i, int l31) { return fw * 128 + i * 32 + l31; }
+MI_HD constexpr int w4_b_row(int tw, int j, int l31) { return tw * 128 + j * 32 + l31; }
+// accumulator acc[i][j], register r of lane (hi, l31)
+MI_HD constexpr int w4_acc_feature(int fw, int i, int r, int hi) { return fw * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+MI_HD constexpr int w4_acc_token(int tw, int j, int l31) { return tw * 128 + j * 32 + l31; }
+
 }  // namespace gt
 }  // namespace mi

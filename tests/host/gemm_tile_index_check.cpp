@@ -6,6 +6,7 @@
 //   4. a whole 256 x 256 tile computed the way the kernel does it (DMA image -> fragments -> 32x32x16 MFMA
 //      semantics -> accumulator layout -> output columns, plain and SwiGLU row pairing) equals x @ w^T
 //   5. the same for the 128 x 128 kernel (gemm_mid_kernel)
+//   6. the same for the four-wave 256 x 256 kernel (gemm_w4_kernel)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -240,6 +241,97 @@ int main() {
                   double ref = 0;
                   for (int k = 0; k < K; ++k) ref += (double)x[tok * K + k] * w[col * K + k];
                   CHECK(acc[f] == ref, "mid output (%d, %d)", tok, col);
+                }
+              }
+            }
+      }
+    }
+  }
+  // ---- 6: the four-wave 256 x 256 kernel (gemm_w4_kernel): DMA image of a K step, fragment reads, one tile end to end ----
+  {
+    std::vector<std::vector<Cell>> wimg(2, std::vector<Cell>(W4_REGION / 16));  // [A region | B region]
+    for (int wave = 0; wave < 4; ++wave)
+      for (int i = 0; i < W4_PIECES; ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int region = w4_wave_is_weight(wave) ? 0 : 1;
+          const int byte = w4_piece_off(wave, i) + lane * 16;  // lane-linear inside the piece
+          const int r = w4_dma_row(wave, i, lane), c = w4_dma_chunk(i, lane);
+          CHECK(c == ((lane & 7) ^ swizzle(r)), "w4 chunk form wave %d i %d lane %d", wave, i, lane);
+          CHECK(byte == w4_row_off(r, c), "w4 DMA wave %d i %d lane %d lands at %d, layout says %d", wave, i, lane, byte, w4_row_off(r, c));
+          Cell& cell = wimg[region][byte / 16];
+          cell.row = r;
+          cell.chunk = c;
+          cell.writers++;
+        }
+    for (int h = 0; h < 2; ++h) {
+      std::vector<int> seen(256 * 8, 0);
+      for (const Cell& c : wimg[h]) {
+        CHECK(c.writers == 1 && c.row >= 0 && c.row < 256, "w4 region %d: cell writers %d row %d", h, c.writers, c.row);
+        if (c.row >= 0) seen[c.row * 8 + c.chunk]++;
+      }
+      for (int v : seen) CHECK(v == 1, "w4 region %d: a (row, chunk) is held %d times", h, v);
+    }
+    for (int wave = 0; wave < 4; ++wave) {
+      const int fw = wave >> 1, tw = wave & 1;
+      for (int kk = 0; kk < 4; ++kk)
+        for (int op = 0; op < 2; ++op)
+          for (int f = 0; f < 4; ++f) {
+            int addr[64];
+            for (int lane = 0; lane < 64; ++lane) {
+              const int hi = lane >> 5, l31 = lane & 31;
+              // the kernel's form: (fw | tw) * 16384 + f * 4096 + row offset of l31 + swizzled chunk
+              addr[lane] = (op ? tw : fw) * 16384 + f * 4096 + (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
+              const int r = op ? w4_b_row(tw, f, l31) : w4_a_row(fw, f, l31);
+              CHECK(addr[lane] == w4_row_off(r, frag_chunk(kk, hi)), "w4 fragment address form");
+              const Cell& c = wimg[op][addr[lane] / 16];
+              CHECK(c.row == r && c.chunk == frag_chunk(kk, hi), "w4 fragment lane %d: row %d chunk %d", lane, c.row, c.chunk);
+            }
+            for (const auto& g : groups) {
+              int used[16] = {0};
+              for (int l : g) used[(addr[l] / 16) % 16]++;
+              for (int sl = 0; sl < 16; ++sl) CHECK(used[sl] <= 1, "w4: bank slot %d used %d times in one lane group", sl, used[sl]);
+            }
+          }
+    }
+    for (int silu = 0; silu < 2; ++silu) {
+      const int K = 64, N = silu ? 1024 : 512, M = 256, n0 = 256, m0 = 0;  // the second feature tile
+      std::vector<float> x(M * K), w(N * K);
+      unsigned sd = 4242u + silu;
+      auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)((int)(sd >> 24) - 128) / 64.0f; };
+      for (auto& v : x) v = rnd();
+      for (auto& v : w) v = rnd();
+      for (int wave = 0; wave < 4; ++wave) {
+        const int fw = wave >> 1, tw = wave & 1;
+        for (int j = 0; j < 4; ++j)
+          for (int lane = 0; lane < 64; lane += 7)
+            for (int r = 0; r < 16; ++r) {
+              const int hi = lane >> 5, l31 = lane & 31;
+              double acc[4];
+              for (int i = 0; i < 4; ++i) {
+                const int wrow = w4_weight_row(w4_acc_feature(fw, i, r, hi), n0, N, silu != 0);
+                const int xrow = m0 + w4_acc_token(tw, j, l31);
+                double sum = 0;
+                for (int k = 0; k < K; ++k) sum += (double)w[wrow * K + k] * x[xrow * K + k];
+                acc[i] = sum;
+              }
+              // the epilogue's output columns: plain col0 = n0 + fw * 128 + i * 32; SwiGLU col0 = n0 / 2 + fw * 64 + i * 32
+              // (gate = acc[i], up = acc[i + 2], i = 0, 1)
+              const int within = (r & 3) + 8 * (r >> 2) + 4 * hi;
+              const int tok = m0 + w4_acc_token(tw, j, l31);
+              for (int i = 0; i < (silu ? 2 : 4); ++i) {
+                if (silu) {
+                  const int col = (n0 >> 1) + fw * 64 + i * 32 + within;
+                  double g = 0, u = 0;
+                  for (int k = 0; k < K; ++k) {
+                    g += (double)x[tok * K + k] * w[col * K + k];
+                    u += (double)x[tok * K + k] * w[(N / 2 + col) * K + k];
+                  }
+                  CHECK(acc[i] == g && acc[i + 2] == u, "w4 silu pairing at (%d, %d)", tok, col);
+                } else {
+                  const int col = n0 + fw * 128 + i * 32 + within;
+                  double ref = 0;
+                  for (int k = 0; k < K; ++k) ref += (double)x[tok * K + k] * w[col * K + k];
+                  CHECK(acc[i] == ref, "w4 output (%d, %d)", tok, col);
                 }
               }
             }

@@ -43,15 +43,18 @@ def main():
         (1024, 1024, 3072, "down@1k"), (2048, 1024, 3072, "down@2k"), (512, 4096, 1024, "qkv@512"),
         (256, 4096, 1024, "qkv@256"), (128, 4096, 1024, "qkv@128"), (128, 1024, 3072, "down@128"), (8192, 8192, 8192, "8k^3"),
     ]
-    variants = {"tile": 0, "lockstep": 2, "narrow_stores": 8, "one_tile_per_wg": 16, "staggered": 1024, "staged_line_stores": 8192,
-                "staged+staggered": 9216}
+    E8 = 1 << 20  # the eight-wave ping-pong kernel of rounds 2-3 (kept for comparison)
+    variants = {"tile": 0, "xcd_rect": 4, "one_tile_per_wg": 16, "no_stores(timing only)": 512, "eight_wave_r03": E8}
+    if os.environ.get("GEMM_QUICK"):  # the four prefill projections only
+        shapes = shapes[:4]
     if os.environ.get("GEMM_MID"):  # the two kernels side by side over the mid-size shapes
         variants = {"tile": 0, "mid128": 65536, "mid128_2stage": 65538, "mid128_3stage": 65539}
         shapes = [(M, N, K, f"{name}@{M}") for M in ((16384,) if os.environ.get("GEMM_MID") == "big" else (128, 256, 512, 1024, 2048, 4096))
                   for N, K, name in ((4096, 1024, "qkv"), (1024, 2048, "o_proj"), (6144, 1024, "gate_up"), (1024, 3072, "down"))]
     if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
-        variants = {"tile": 0, "no_dma": 32, "no_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
-                    "dma_never_waited": 256, "no_stores": 512}
+        variants = {"tile": 0, "no_dma": 32, "no_next_step_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
+                    "pieces_never_waited": 256, "no_stores": 512, "never_waited_no_stores": 768,
+                    "l2_resident_feed": 1024, "l2_resident_feed_no_stores": 1536}
     rows = []
     for M, N, K, label in shapes:
         g = torch.Generator().manual_seed(M + N + K)

@@ -105,6 +105,242 @@ __global__ __launch_bounds__(256, 1) void feed_kernel(const char* __restrict__ s
   if (s == 12345.678f) sink[threadIdx.x] = s;
 }
 
+
+// MODE 5 / 6: the software pipeline a one-wave-per-SIMD kernel needs (the vendor's MT256x256x64 assembly kernel has the
+// same shape): fragments double-buffered in REGISTERS - the reads of k group kk + 1 are issued between the MFMAs of
+// group kk - and the feed issued as `buffer_load_dwordx4 ... lds` (SGPR offsets, M0 destinations: two SALU per piece,
+// no VALU address arithmetic) between the MFMAs of the last group.  One wait + barrier per K step: "my fragment reads
+// of this buffer are back, my pieces of the next step have landed" -> the buffer is re-filled two steps ahead.
+//   PIPE 0: 16 pieces all in group 3;  PIPE 1: pieces spread 1 per 4 MFMAs over groups 3, 0, 1, 2 is not legal (the
+//   buffer is being read) - instead 8 in group 3 and 8 in the next step's group 0 (its reads touch the OTHER buffer...
+//   no: group 0 reads k group 1 of the SAME step).  So PIPE 1 = pieces 2 per 2 MFMAs (front-loaded), PIPE 0 = 1 per MFMA.
+template <int PIPE>
+__global__ __launch_bounds__(256, 1) void pipe_kernel(const char* __restrict__ src, float* __restrict__ sink, int ksteps) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * KSTEP_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const char* stream = src + (size_t)(blockIdx.x & 7) * ((size_t)ksteps * KSTEP_BYTES);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, ksteps * KSTEP_BYTES, 0x00020000);
+  const int voff = wave * 16384 + lane * 16;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int offa[4], offb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int o = (l31 >> 3) * 1024 + (l31 & 7) * 128 + (((2 * kk + hi) ^ ((l31 >> 1) & 7)) << 4);
+    offa[kk] = o + (wave >> 1) * 16384;
+    offb[kk] = o + 32768 + (wave & 1) * 16384;
+  }
+  u32x4 Ra[2][4], Rb[2][4];
+  auto dma = [&](int t, int i, int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * KSTEP_BYTES + wave * 16384 + i * 1024),
+                                             16, voff, t * KSTEP_BYTES + i * 1024, 0, 0);
+  };
+  auto reads = [&](int kk, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Ra[set][i] = *reinterpret_cast<const u32x4*>(lds + i * 4096 + offa[kk]);
+      Rb[set][i] = *reinterpret_cast<const u32x4*>(lds + i * 4096 + offb[kk]);
+    }
+  };
+  auto mma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra[set][i]), __builtin_bit_cast(bf16x8, Rb[set][j]), acc[i][j], 0, 0, 0);
+  };
+  auto flip = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { offa[kk] ^= KSTEP_BYTES; offb[kk] ^= KSTEP_BYTES; }
+  };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(0, i, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(1, i, 1);
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+  reads(0, 0);
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int t = 0; t < ksteps; ++t) {
+    const int p = t & 1;
+    // group 0: MFMAs of k group 0, reads of k group 1 - one read behind each of the first eight MFMAs
+    reads(1, 1);
+    mma(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    reads(2, 0);
+    mma(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    reads(3, 1);
+    mma(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // every read of this buffer is back (lgkmcnt), my pieces of step t + 1 have landed (vmcnt) -> barrier -> the buffer
+    // is free for step t + 2 and the other one readable
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    flip();
+    // group 3 in pinned chunks (the scheduler does not move LDS-DMA under sched_group_barrier: they are chained through M0)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i0 = (2 * q) >> 2, j0 = (2 * q) & 3;
+      acc[i0][j0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra[1][i0]), __builtin_bit_cast(bf16x8, Rb[1][j0]), acc[i0][j0], 0, 0, 0);
+      if (q < 4) Ra[0][q] = *reinterpret_cast<const u32x4*>(lds + q * 4096 + offa[0]);
+      else Rb[0][q - 4] = *reinterpret_cast<const u32x4*>(lds + (q - 4) * 4096 + offb[0]);
+      if (PIPE == 0 || PIPE == 3) { dma(t + 2, 2 * q, p); }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i0][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra[1][i0]), __builtin_bit_cast(bf16x8, Rb[1][j0 + 1]), acc[i0][j0 + 1], 0, 0, 0);
+      if (PIPE == 0) { dma(t + 2, 2 * q + 1, p); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 8; q < 16; ++q) {
+      const int i0 = q >> 2, j0 = q & 3;
+      acc[i0][j0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra[1][i0]), __builtin_bit_cast(bf16x8, Rb[1][j0]), acc[i0][j0], 0, 0, 0);
+      if (PIPE == 1) { dma(t + 2, 2 * (q - 8), p); dma(t + 2, 2 * (q - 8) + 1, p); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { sink[1024 + 2 * blockIdx.x] = (float)(c1 - c0); sink[1025 + 2 * blockIdx.x] = (float)(r1 - r0); }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+
+// pipe2: fragment reads TWO k groups ahead (four register sets, one per k group): the buffer of step t has been read
+// completely by the end of group 1, so ONE wait + barrier at the start of group 2 ("my reads of this buffer are back,
+// my pieces of step t + 1 have landed") both frees it for step t + 2 and opens the other buffer; the sixteen pieces go
+// one behind every second MFMA of groups 2 and 3 (a piece blocks its wave ~60 cycles, an MFMA runs 32) and have a
+// whole K step to land.
+//   FEED 0: no pieces in the loop;  FEED 1: 16 pieces, 1 per 2 MFMAs over groups 2 and 3;  FEED 2: 16 pieces, 1 per MFMA over group 2
+template <int FEED>
+__global__ __launch_bounds__(256, 1) void pipe2_kernel(const char* __restrict__ src, float* __restrict__ sink, int ksteps) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * KSTEP_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const char* stream = src + (size_t)(blockIdx.x & 7) * ((size_t)ksteps * KSTEP_BYTES);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, ksteps * KSTEP_BYTES, 0x00020000);
+  const int voff = wave * 16384 + lane * 16;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int offa[4], offb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int o = (l31 >> 3) * 1024 + (l31 & 7) * 128 + (((2 * kk + hi) ^ ((l31 >> 1) & 7)) << 4);
+    offa[kk] = o + (wave >> 1) * 16384;
+    offb[kk] = o + 32768 + (wave & 1) * 16384;
+  }
+  u32x4 Ra[4][4], Rb[4][4];
+  auto dma = [&](int t, int i, int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * KSTEP_BYTES + wave * 16384 + i * 1024),
+                                             16, voff, t * KSTEP_BYTES + i * 1024, 0, 0);
+  };
+  auto read1 = [&](int kk, int q) __attribute__((always_inline)) {  // q-th of the eight fragment reads of k group kk
+    if (q < 4) Ra[kk][q] = *reinterpret_cast<const u32x4*>(lds + q * 4096 + offa[kk]);
+    else Rb[kk][q - 4] = *reinterpret_cast<const u32x4*>(lds + (q - 4) * 4096 + offb[kk]);
+  };
+  auto mma1 = [&](int kk, int m) __attribute__((always_inline)) {
+    const int i = m >> 2, j = m & 3;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra[kk][i]), __builtin_bit_cast(bf16x8, Rb[kk][j]), acc[i][j], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(0, i, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(1, i, 1);
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { read1(0, q); read1(1, q); }
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int t = 0; t < ksteps; ++t) {
+    const int p = t & 1;
+    // groups 0, 1: MFMAs of k group g, reads of k group g + 2 of the same buffer
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        mma1(g, 2 * q);
+        read1(g + 2, q);
+        mma1(g, 2 * q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the other buffer from here on
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { offa[kk] ^= KSTEP_BYTES; offb[kk] ^= KSTEP_BYTES; }
+#pragma unroll
+    for (int g = 2; g < 4; ++g) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        mma1(g, 2 * q);
+        read1(g - 2, q);
+        if (FEED == 2 && g == 2) dma(t + 2, 2 * q, p);
+        __builtin_amdgcn_sched_barrier(0);
+        mma1(g, 2 * q + 1);
+        if (FEED == 1) dma(t + 2, (g - 2) * 8 + q, p);
+        if (FEED == 2 && g == 2) dma(t + 2, 2 * q + 1, p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { sink[1024 + 2 * blockIdx.x] = (float)(c1 - c0); sink[1025 + 2 * blockIdx.x] = (float)(r1 - r0); }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+static double g_cycles_per_step, g_mhz;
+typedef void (*pipe_fn)(const char*, float*, int);
+static double run_fn(pipe_fn fn, const char* src, float* sink, int ksteps);
+template <int PIPE>
+static double run_pipe(const char* src, float* sink, int ksteps) { return run_fn(pipe_kernel<PIPE>, src, sink, ksteps); }
+static double run_fn(pipe_fn fn, const char* src, float* sink, int ksteps) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL(fn, dim3(256), dim3(256), 0, 0, src, sink, ksteps);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(fn, dim3(256), dim3(256), 0, 0, src, sink, ksteps);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  float h[2 * 256]; CK(hipMemcpy(h, sink + 1024, sizeof h, hipMemcpyDeviceToHost));
+  double cyc = 0, rt = 0;
+  for (int i = 0; i < 256; ++i) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
+  g_cycles_per_step = cyc / 256 / ksteps; g_mhz = cyc / rt * 100.0;
+  return ms * 1e3 / 5;
+}
+
 template <int MODE>
 static double run(const char* src, float* sink, int ksteps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -121,7 +357,7 @@ int main() {
   const int ksteps = 64;
   const size_t bytes = (size_t)8 * ksteps * KSTEP_BYTES;
   char* src; float* sink;
-  CK(hipMalloc(&src, bytes)); CK(hipMalloc(&sink, 4096));
+  CK(hipMalloc(&src, bytes)); CK(hipMalloc(&sink, 8192));
   // random bf16-ish data (DVFS: zero operands clock higher)
   uint32_t* h = (uint32_t*)malloc(bytes);
   uint32_t x = 12345;
@@ -136,5 +372,15 @@ int main() {
   printf("  + reads + LDS-DMA feed             %8.1f  %6.3f  %7.0f\n", t2, t2 / ksteps, flop / t2 / 1e6);
   printf("  + reads + register-staged feed     %8.1f  %6.3f  %7.0f\n", t3, t3 / ksteps, flop / t3 / 1e6);
   printf("  + reads + LDS-DMA, 1 per 4 MFMAs   %8.1f  %6.3f  %7.0f\n", t4, t4 / ksteps, flop / t4 / 1e6);
+  printf("software-pipelined loop (fragments double-buffered in registers, buffer_load ... lds feed); cycles per K step of the loop itself, shader clock\n");
+  double t;
+  t = run_pipe<2>(src, sink, ksteps); printf("  reads only, no feed                         %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_pipe<3>(src, sink, ksteps); printf("  + 8 pieces per K step (half the feed)       %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_pipe<0>(src, sink, ksteps); printf("  + 16 pieces, 1 per MFMA over group 3        %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_pipe<1>(src, sink, ksteps); printf("  + 16 pieces, 2 per MFMA behind the reads    %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  printf("reads two k groups ahead (four fragment register sets), one wait + barrier per K step\n");
+  t = run_fn(pipe2_kernel<0>, src, sink, ksteps); printf("  reads only, no feed                         %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<1>, src, sink, ksteps); printf("  + 16 pieces, 1 per 2 MFMAs, groups 2 and 3  %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<2>, src, sink, ksteps); printf("  + 16 pieces, 1 per MFMA, group 2            %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
   return 0;
 }
