@@ -645,16 +645,25 @@ static int tile_ksplit(int M, int N, int K) {
 }
 
 // V & kEightWaves: the eight-wave ping-pong kernel of rounds 2-3 (tuning / comparison only); otherwise the
-// four-wave kernel (gemm_w4_kernel.hpp)
-constexpr int kEightWaves = 1 << 20;
+// four-wave kernel (gemm_w4_kernel.hpp), with whole-line output stores (kLineStores) wherever the output allows it:
+// full feature tiles, 16-byte aligned rows, 32-bit byte offsets.  V & kDirectStores keeps the direct form (tuning).
+constexpr int kEightWaves = 1 << 20, kLineStores = 32768, kDirectStores = 1 << 18;
 template <int EPI, bool BIAS, int V = kDefaultV>
 static int launch_tile(const TileArgs& a, hipStream_t st, int ksplit = 1) {
   // persistent workgroups: one per CU; the grid is a multiple of 8, so a workgroup stays in one XCD class
   const int ntiles = a.tiles_f * a.tiles_t;
   const bool persistent = !(V & 16) && ntiles > kPersistentGrid;
   const dim3 grid(persistent ? kPersistentGrid : ntiles, ksplit);
-  if (V & kEightWaves) hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, V & ~kEightWaves>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V>), grid, dim3(256), 0, st, a);
+  if constexpr ((V & kEightWaves) != 0) {
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, V & ~kEightWaves>), grid, dim3(512), 0, st, a);
+  } else if constexpr (EPI == TEPI_PARTIAL || (V & (kDirectStores | 8 | 512)) != 0) {
+    hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V & ~kDirectStores>), grid, dim3(256), 0, st, a);
+  } else {
+    const bool lines = a.N % TILE_F == 0 && a.ldy % 8 == 0 && (int64_t)a.M * a.ldy * 2 < ((int64_t)1 << 32) &&
+                       (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+    if (lines) hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V | kLineStores>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V>), grid, dim3(256), 0, st, a);
+  }
   return check_launch();
 }
 
@@ -777,6 +786,9 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
     case 768: return launch_tile<TEPI_NONE, false, 768>(a, st);
     case 1024: return launch_tile<TEPI_NONE, false, 1024>(a, st);
     case 1536: return launch_tile<TEPI_NONE, false, 1536>(a, st);
+    case 2048: return launch_tile<TEPI_NONE, false, 2048>(a, st);
+    case 2560: return launch_tile<TEPI_NONE, false, 2560>(a, st);
+    case kDirectStores: return launch_tile<TEPI_NONE, false, kDirectStores>(a, st);
     // the eight-wave kernel of rounds 2-3 and its variants
     case kEightWaves: return launch_tile<TEPI_NONE, false, kEightWaves>(a, st);
     case kEightWaves + 2: return launch_tile<TEPI_NONE, false, kEightWaves + 2>(a, st);

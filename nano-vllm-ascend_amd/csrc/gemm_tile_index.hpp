@@ -94,6 +94,7 @@ MI_HD constexpr int mid_acc_token(int tw, int b, int l31) { return tw * 64 + b *
 // (8 rows): wave w moves pieces 16 w .. 16 w + 15, i.e. waves 0, 1 the A region's rows 0..127 / 128..255, waves 2, 3
 // the B region's.
 constexpr int W4_STEP_BYTES = 65536, W4_REGION = 32768, W4_PIECES = 16;
+constexpr int W4_STAGE_BYTES = 8192;  // per wave: a 32-token slab of its output on the way to memory as whole lines
 MI_HD constexpr int w4_row_off(int r, int c) { return (r >> 3) * 1024 + (r & 7) * 128 + ((c ^ swizzle(r)) << 4); }
 MI_HD constexpr bool w4_wave_is_weight(int wave) { return wave < 2; }
 // row (inside its region) and K chunk fetched by lane `lane` of piece i of wave `wave`; it lands at byte 16 * lane of

@@ -23,7 +23,7 @@
 
 template <int EPI, bool BIAS, int V>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
-  __shared__ __attribute__((aligned(1024))) char lds[2 * W4_STEP_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[2 * W4_STEP_BYTES + ((V & 32768) ? 4 * W4_STAGE_BYTES : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fw = wave >> 1, tw = wave & 1, hi = lane >> 5, l31 = lane & 31;
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
   // the swizzle of row 8 i + (lane >> 3) depends on i only through its parity
   uint32_t voff[2];
 #pragma unroll
-  for (int par = 0; par < 2; ++par) voff[par] = (uint32_t)(lane >> 3) * ld2 + (uint32_t)w4_dma_chunk(par, lane) * 16;
+  for (int par = 0; par < 2; ++par)  // (V & 2048, ablation, wrong results: the lanes of a row fetch its chunks in ascending order)
+    voff[par] = (uint32_t)(lane >> 3) * ld2 + (uint32_t)((V & 2048) ? (lane & 7) : w4_dma_chunk(par, lane)) * 16;
   // scalar part: first source row (as a byte offset) of pieces 0..7 and of pieces 8..15 of this wave's 128 region rows
   // for the tile being FETCHED, and the K offset of the step being fetched.  Plain: 128 consecutive rows.  SwiGLU
   // weights: 64 gate rows, then the 64 up rows N / 2 further on.
@@ -242,6 +243,100 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     }
   };
 
+
+  // ---- the same epilogue with the rows leaving as WHOLE cache lines (V & 32768; the host guarantees full feature
+  // tiles and 16-byte aligned rows).  Straight from the accumulator layout a store instruction writes 32 bytes of each
+  // of 32 rows, and the CU's store path handles one line per cycle: 32 cycles for 1 KiB.  Through a per-wave LDS stage
+  // (a 32-token slab of the wave's 128 - SwiGLU 64 - output features, rows XOR-swizzled in 16-byte chunks) an
+  // instruction covers CPR lanes per row = 8 (4) full lines.  The stage is written and read with inline assembly: for
+  // a C++ access to LDS the compiler first drains the VMEM queue (the pieces in flight might alias it, for all it
+  // knows), and with it every earlier store of the epilogue.  LDS operations of one wave execute in order: no barrier;
+  // the reads of slab j are in flight while slab j + 1 is converted.
+  constexpr int ROWB = EPI == TEPI_SILU ? 128 : 256, CPR = ROWB / 16, RPI = 64 / CPR, NCH = EPI == TEPI_SILU ? 4 : 8;
+  const uint32_t stg_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + 2 * W4_STEP_BYTES) + wave * W4_STAGE_BYTES;
+  const uint32_t stg_w = stg_base + (uint32_t)l31 * ROWB + (uint32_t)(((l31 & 7) ^ hi) << 4);  // ^ (4 i + 2 p2) << 4 per chunk
+  uint32_t stg_r[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int r = lane / CPR, c = lane % CPR;
+    stg_r[par] = stg_base + (uint32_t)r * ROWB + (uint32_t)((c ^ ((par * RPI + r) & 7)) << 4);  // + it * RPI * ROWB as an immediate
+  }
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (uint32_t)a.M * (uint32_t)a.ldy * 2, 0x00020000);
+  const uint32_t y_lane = (uint32_t)(lane / CPR) * (uint32_t)a.ldy * 2 + (uint32_t)(lane % CPR) * 16;
+  auto epilogue_lines = [&](int m0, int n0) __attribute__((always_inline)) {
+    u32x4 out[NCH], back[NCH];
+    // (opaque per tile: otherwise the eight chunk addresses are hoisted out of the tile loop and live - spilled -
+    // through the whole K loop)
+    uint32_t w_addr = stg_w;
+    asm volatile("" : "+v"(w_addr));
+    auto convert = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < (EPI == TEPI_SILU ? 2 : 4); ++i) {
+        u32x2 pk[4];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float o[4];
+          if (EPI == TEPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float gb = rbf(acc[i][j][4 * rq + e]);
+              const float sb = rbf(gb * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gb * -1.4426950408889634f)));
+              o[e] = sb * rbf(acc[i + 2][j][4 * rq + e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * rq + e];
+            if (BIAS) {
+              const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + n0 + fw * 128 + i * 32 + 8 * rq + 4 * hi);
+              o[0] += lo_bf(bw[0]);
+              o[1] += hi_bf(bw[0]);
+              o[2] += lo_bf(bw[1]);
+              o[3] += hi_bf(bw[1]);
+            }
+          }
+          pk[rq] = u32x2{pack_bf(o[0], o[1]), pack_bf(o[2], o[3])};
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+          out[2 * i + p2] = u32x4{sx[0], sy[0], sx[1], sy[1]};  // features 32 i + 16 p2 + 8 hi .. + 7 of token l31
+        }
+      }
+    };
+    auto stage_in = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)  // chunk 2 ch + hi of row l31
+        asm volatile("ds_write_b128 %0, %1" ::"v"(w_addr ^ (uint32_t)(ch << 5)), "v"(out[ch]) : "memory");
+    };
+    auto stage_out = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < NCH; ++it)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(back[it]) : "v"(stg_r[(it * RPI >> 2) & 1]), "n"(it * RPI * ROWB) : "memory");
+    };
+    auto store_lines = [&](int j) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint32_t colb = (uint32_t)(EPI == TEPI_SILU ? (n0 >> 1) + fw * 64 : n0 + fw * 128) * 2;
+#pragma unroll
+      for (int it = 0; it < NCH; ++it) {
+        const uint32_t rowb = (uint32_t)(m0 + tw * 128 + j * 32 + it * RPI) * (uint32_t)a.ldy * 2 + colb;
+        // (rows past M are beyond the descriptor's range: dropped)
+        __builtin_amdgcn_raw_buffer_store_b128(back[it], yrsrc, y_lane + rowb, 0, 0);
+      }
+    };
+    convert(0);
+    stage_in();
+    stage_out();
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      convert(j);
+      store_lines(j - 1);
+      stage_in();
+      stage_out();
+    }
+    store_lines(3);
+  };
+
   // ---- prologue: steps 0 and 1 of the stream into images 0 and 1; step 0 landed and published; its k groups 0, 1 read ----
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -264,7 +359,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     kstep(std::true_type{});
     for (int kt = 1; kt < KT; ++kt) kstep(std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
-    epilogue(m0, n0);
+    if ((V & 32768) && EPI != TEPI_PARTIAL) epilogue_lines(m0, n0);
+    else epilogue(m0, n0);
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the past-the-end pieces must not outlive the workgroup's LDS

@@ -44,7 +44,7 @@ def main():
         (256, 4096, 1024, "qkv@256"), (128, 4096, 1024, "qkv@128"), (128, 1024, 3072, "down@128"), (8192, 8192, 8192, "8k^3"),
     ]
     E8 = 1 << 20  # the eight-wave ping-pong kernel of rounds 2-3 (kept for comparison)
-    variants = {"tile": 0, "xcd_rect": 4, "one_tile_per_wg": 16, "no_stores(timing only)": 512, "eight_wave_r03": E8}
+    variants = {"tile": 0, "direct_stores": 1 << 18, "one_tile_per_wg": 16, "no_stores(timing only)": 512, "eight_wave_r03": E8}
     if os.environ.get("GEMM_QUICK"):  # the four prefill projections only
         shapes = shapes[:4]
     if os.environ.get("GEMM_MID"):  # the two kernels side by side over the mid-size shapes
@@ -54,7 +54,7 @@ def main():
     if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
         variants = {"tile": 0, "no_dma": 32, "no_next_step_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
                     "pieces_never_waited": 256, "no_stores": 512, "never_waited_no_stores": 768,
-                    "l2_resident_feed": 1024, "l2_resident_feed_no_stores": 1536}
+                    "l2_resident_feed": 1024, "l2_resident_feed_no_stores": 1536, "l2_resident_stores": 2048}
     rows = []
     for M, N, K, label in shapes:
         g = torch.Generator().manual_seed(M + N + K)
@@ -80,6 +80,10 @@ def main():
         ref = F.linear(x, w)
         ops.gemm_tile(x, w, out=y, variant=0)
         row["max_abs_diff_vs_library"] = float((y.float() - ref.float()).abs().max())
+        if "direct_stores" in variants:
+            y.zero_()
+            ops.gemm_tile(x, w, out=y, variant=variants["direct_stores"])
+            row["direct_stores_max_abs_diff"] = float((y.float() - ref.float()).abs().max())
         if N % 256 == 0 and label in ("gate_up",):
             ya = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
             t = timed(lambda: ops.gemm_tile(x, w, out=ya, silu_mul=True))
