@@ -725,7 +725,8 @@ static int check_tile_gemm(const void* x, int64_t ldx, const void* w, const void
   if (epilogue == 1 && (bias || (N / 2) % 128)) return MI_EUNSUPPORTED;  // (the 128-tile kernel alone would take % 64)
   if (ldy < (epilogue == 1 ? N / 2 : N)) return MI_EINVAL;
   // the DMA sources are 32-bit byte offsets from the operand bases
-  if (((int64_t)N + 256) * K * 2 >= (int64_t)1 << 32 || ((int64_t)M + 256) * ldx * 2 >= (int64_t)1 << 32) return MI_EUNSUPPORTED;
+  // (and 0xF0000000 must lie beyond both: the four-wave kernel's "fetch nothing" offset)
+  if (((int64_t)N + 256) * K * 2 >= (int64_t)1 << 31 || ((int64_t)M + 256) * ldx * 2 >= (int64_t)1 << 31) return MI_EUNSUPPORTED;
   return MI_OK;
 }
 

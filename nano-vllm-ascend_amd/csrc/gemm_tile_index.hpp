@@ -88,28 +88,47 @@ MI_HD constexpr int mid_acc_token(int tw, int b, int l31) { return tw * 64 + b *
 
 // ---- the four-wave 256 x 256 x 64 kernel (gemm_w4_kernel, the product kernel for large M since round 4) ----
 // One wave per SIMD: fw = wave >> 1 (128 features), tw = wave & 1 (128 tokens), wave tile 128 x 128 = 4 x 4 accumulators.
-// One K step of the tile in LDS is ONE 64 KiB image: A region (256 feature rows x 128 bytes) then B region (256 token
-// rows); row r of a region at (r >> 3) * 1024 + (r & 7) * 128, 16-byte chunks XOR-swizzled by swizzle(r) as above.  Two
-// images (steps t and t + 1) = 128 KiB.  The image is fed by 64 `buffer_load_dwordx4 ... lds` pieces of 1 KiB
-// (8 rows): wave w moves pieces 16 w .. 16 w + 15, i.e. waves 0, 1 the A region's rows 0..127 / 128..255, waves 2, 3
-// the B region's.
-constexpr int W4_STEP_BYTES = 65536, W4_REGION = 32768, W4_PIECES = 16;
-constexpr int W4_STAGE_BYTES = 8192;  // per wave: a 32-token slab of its output on the way to memory as whole lines
-MI_HD constexpr int w4_row_off(int r, int c) { return (r >> 3) * 1024 + (r & 7) * 128 + ((c ^ swizzle(r)) << 4); }
+// One K step of the tile in LDS is ONE image of 64 PIECES: a piece is what one `buffer_load_dwordx4 ... lds` wave
+// instruction lands - 1 KiB = eight 128-byte row slices (lane l -> slice l >> 3, 16-byte chunk l & 7: the eight lanes
+// of a slice fetch one whole line of a source row IN ORDER, which is what the address coalescer wants; a chunk
+// permutation inside the slice - the XOR swizzle of the kernels above - costs 3-5 % of the GEMM) - followed by 16
+// bytes of padding.  Pieces 0..31 hold the A region (256 feature rows), 32..63 the B region (256 token rows); wave w
+// moves pieces 16 w .. 16 w + 15, i.e. the 128 rows of one half of one region.
+// Which row goes where: row r7 = (b1 b0 x4 x3 x2 x1 x0) of a 128-row half lives in piece q = (b0 x3 x1 x0), slice
+// s = (b1 x2 x4).  A fragment read (row l31 of a 32-row block, one chunk for all 16 lanes of a ds_read_b128 lane
+// group) then finds its 16 rows in 16 different 16-byte bank slots: slot = (piece + 8 (s & 1) + chunk) mod 16 - the
+// padding shifts every piece by one slot - and the two lane-group row sets {x4 ^ x3 ^ x2 = 0 / 1} are each in
+// bijection with (x4, x3, x1, x0).  Both maps are additive, row = w4_piece_rows(q) + w4_slice_rows(s): a piece's
+// source offset is a per-lane constant plus a scalar.
+constexpr int W4_PIECE_BYTES = 1024 + 16, W4_PIECES = 16;  // (W4_PIECES: per wave)
+constexpr int W4_STEP_BYTES = 64 * W4_PIECE_BYTES;         // 66 560
+constexpr int W4_STAGE_BYTES = 4096;  // per wave: 32 tokens x 64 output features on their way to memory as whole lines
 MI_HD constexpr bool w4_wave_is_weight(int wave) { return wave < 2; }
-// row (inside its region) and K chunk fetched by lane `lane` of piece i of wave `wave`; it lands at byte 16 * lane of
-// the piece = where w4_row_off() expects (row, chunk)
-MI_HD constexpr int w4_dma_row(int wave, int i, int lane) { return (wave & 1) * 128 + i * 8 + (lane >> 3); }
-MI_HD constexpr int w4_dma_chunk(int i, int lane) { return (lane & 7) ^ (((i & 1) << 2) + (lane >> 4)); }  // = ^ swizzle(row)
-MI_HD constexpr int w4_piece_off(int wave, int i) { return (wave & 1) * 16384 + i * 1024; }  // inside the region
+MI_HD constexpr int w4_piece_of_row(int r7) { return 8 * ((r7 >> 5) & 1) + 4 * ((r7 >> 3) & 1) + (r7 & 3); }
+MI_HD constexpr int w4_slice_of_row(int r7) { return ((r7 >> 4) & 1) + 2 * ((r7 >> 2) & 1) + 4 * ((r7 >> 6) & 1); }
+MI_HD constexpr int w4_piece_rows(int q) { return 32 * ((q >> 3) & 1) + 8 * ((q >> 2) & 1) + (q & 3); }
+MI_HD constexpr int w4_slice_rows(int s) { return 16 * (s & 1) + 4 * ((s >> 1) & 1) + 64 * ((s >> 2) & 1); }
+// byte offset inside the image of 16-byte chunk c of row r (0..255) of region (0: A, 1: B)
+MI_HD constexpr int w4_row_off(int region, int r, int c) {
+  return (region * 32 + (r >> 7) * 16 + w4_piece_of_row(r & 127)) * W4_PIECE_BYTES + w4_slice_of_row(r & 127) * 128 + c * 16;
+}
+// feed: row (inside its region) and chunk fetched by lane `lane` of piece q of wave `wave`; lands at byte 16 * lane of the piece
+MI_HD constexpr int w4_dma_row(int wave, int q, int lane) { return (wave & 1) * 128 + w4_piece_rows(q) + w4_slice_rows(lane >> 3); }
+MI_HD constexpr int w4_dma_chunk(int lane) { return lane & 7; }
+MI_HD constexpr int w4_piece_off(int wave, int q) { return (wave * 16 + q) * W4_PIECE_BYTES; }  // inside the image
 // weight row of A-region row r for the tile at feature n0: plain, or SwiGLU (each wave's 128 rows = 64 gate rows, then
 // the 64 up rows that pair with them; n0 counts gate + up rows, n0 / 2 output columns)
 MI_HD constexpr int w4_weight_row(int r, int n0, int N, bool silu) {
   return silu ? ((r >> 6) & 1) * (N >> 1) + (n0 >> 1) + (r >> 7) * 64 + (r & 63) : n0 + r;
 }
-// fragment i (0..3) of wave half fw / tw, k group kk: region row, chunk frag_chunk(kk, hi)
+// fragment i (0..3) of wave half fw / tw, k group kk: region row, chunk frag_chunk(kk, hi); the kernel's address form:
+// per-lane w4_frag_lane(l31, hi) + half * 16 pieces + immediates w4_frag_imm(i, kk)
 MI_HD constexpr int w4_a_row(int fw, int i, int l31) { return fw * 128 + i * 32 + l31; }
 MI_HD constexpr int w4_b_row(int tw, int j, int l31) { return tw * 128 + j * 32 + l31; }
+MI_HD constexpr int w4_frag_lane(int l31, int hi) {
+  return (4 * ((l31 >> 3) & 1) + (l31 & 3)) * W4_PIECE_BYTES + (((l31 >> 4) & 1) + 2 * ((l31 >> 2) & 1)) * 128 + hi * 16;
+}
+MI_HD constexpr int w4_frag_imm(int i, int kk) { return (i & 1) * 8 * W4_PIECE_BYTES + (i >> 1) * 512 + kk * 32; }
 // accumulator acc[i][j], register r of lane (hi, l31)
 MI_HD constexpr int w4_acc_feature(int fw, int i, int r, int hi) { return fw * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 MI_HD constexpr int w4_acc_token(int tw, int j, int l31) { return tw * 128 + j * 32 + l31; }

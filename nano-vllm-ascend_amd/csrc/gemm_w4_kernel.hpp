@@ -14,6 +14,8 @@
 //     occupies the pipe for 32, so one per two MFMAs hides and one per MFMA does not (2573 cycles);
 //   * a piece then has a whole K step (~2000 cycles) to land before the wait that covers it.
 // Rows past M / N are never clamped: they lie beyond the buffer descriptor's range and arrive as zeros.
+// LDS image: 64 padded 1 KiB pieces per K step (gemm_tile_index.hpp) - the lanes of a piece fetch whole source lines in
+// order, and the padding, not a chunk permutation, keeps the fragment reads off each other's banks.
 //
 // Persistent like the kernel above: workgroup b computes tiles b, b + grid, ...; the piece stream runs on across tile
 // seams (the last two K steps of a tile fetch steps 0 and 1 of the next), a tile's stores overlap the next tile's
@@ -42,43 +44,36 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
   const uint32_t records = (uint32_t)(wgt ? a.N : a.M) * ld2;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wgt ? a.w : a.x), 0, records, 0x00020000);
-  // per-lane part of a piece's source offset: row (lane >> 3) of the piece's eight, chunk XOR-swizzled by the row -
-  // the swizzle of row 8 i + (lane >> 3) depends on i only through its parity
-  uint32_t voff[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)  // (V & 2048, ablation, wrong results: the lanes of a row fetch its chunks in ascending order)
-    voff[par] = (uint32_t)(lane >> 3) * ld2 + (uint32_t)((V & 2048) ? (lane & 7) : w4_dma_chunk(par, lane)) * 16;
-  // scalar part: first source row (as a byte offset) of pieces 0..7 and of pieces 8..15 of this wave's 128 region rows
-  // for the tile being FETCHED, and the K offset of the step being fetched.  Plain: 128 consecutive rows.  SwiGLU
-  // weights: 64 gate rows, then the 64 up rows N / 2 further on.
-  uint32_t f_lo, f_hi, f_k = kbeg_bytes;
+  // per-lane part of a piece's source offset: row slice lane >> 3 of the piece (gemm_tile_index.hpp: which rows those
+  // are), chunk lane & 7 - the eight lanes of a slice fetch one 128-byte line in order.  SwiGLU weights: a wave's 128
+  // region rows are 64 gate rows, then the 64 up rows N / 2 further on.
+  const int slice_rows = w4_slice_rows(lane >> 3);
+  uint32_t voff = (uint32_t)(lane & 7) * 16 +
+                  (wgt && EPI == TEPI_SILU ? (uint32_t)((slice_rows & 63) + (slice_rows >> 6) * (a.N >> 1)) : (uint32_t)slice_rows) * ld2;
+  if (V & 1024) voff = (uint32_t)lane * 16;  // ablation (wrong results): every piece from the operand's first 64 KiB
+  // scalar part: first source row (as a byte offset) of this wave's 128 region rows for the tile being FETCHED, and
+  // the K offset of the step being fetched
+  uint32_t f_row, f_k = kbeg_bytes;
   int f_kt = 0, f_blk = (int)blockIdx.x;
   auto fetch_tile = [&](int b) __attribute__((always_inline)) {
-    // past the workgroup's last tile the stream re-fetches its first one: two K steps of harmless, valid reads
-    const int tid = tile_of_block(b < ntiles ? b : (int)blockIdx.x, a.tiles_t, a.tiles_f, (V & 4) != 0);
-    const int m0_ = (tid / a.tiles_f) * TILE_T, n0_ = (tid % a.tiles_f) * TILE_F;
-    if (!wgt) {
-      f_lo = (uint32_t)(m0_ + (wave & 1) * 128) * ld2;
-      f_hi = f_lo + 64 * ld2;
-    } else if (EPI == TEPI_SILU) {
-      f_lo = (uint32_t)((n0_ >> 1) + (wave & 1) * 64) * ld2;
-      f_hi = f_lo + (uint32_t)(a.N >> 1) * ld2;
-    } else {
-      f_lo = (uint32_t)(n0_ + (wave & 1) * 128) * ld2;
-      f_hi = f_lo + 64 * ld2;
+    // past the workgroup's last tile every row is beyond the descriptor's range: the pieces of the stream's last two
+    // steps fetch nothing and complete at once (zeros land in the image nobody reads)
+    if (b >= ntiles) {
+      f_row = 0xF0000000u;
+      return;
     }
+    const int tid = tile_of_block(b, a.tiles_t, a.tiles_f, (V & 4) != 0);
+    const int m0_ = (tid / a.tiles_f) * TILE_T, n0_ = (tid % a.tiles_f) * TILE_F;
+    if (!wgt) f_row = (uint32_t)(m0_ + (wave & 1) * 128) * ld2;
+    else if (EPI == TEPI_SILU) f_row = (uint32_t)((n0_ >> 1) + (wave & 1) * 64) * ld2;
+    else f_row = (uint32_t)(n0_ + (wave & 1) * 128) * ld2;
   };
   fetch_tile(f_blk);
-  if (V & 1024) {  // ablation (wrong results): every piece comes from the operand's first 64 KiB - an L2-resident feed
-#pragma unroll
-    for (int par = 0; par < 2; ++par) voff[par] = (uint32_t)(lane >> 3) * 128 + (uint32_t)w4_dma_chunk(par, lane) * 16;
-  }
-  char* const region = lds + (wgt ? 0 : W4_REGION) + (wave & 1) * 16384;
+  char* const pieces = lds + wave * (W4_PIECES * W4_PIECE_BYTES);
   int wbuf = 0;  // image the next step's pieces go to
-  auto piece = [&](int i) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(region + wbuf * W4_STEP_BYTES + i * 1024), 16,
-                                             (V & 1024) ? voff[i & 1] + (uint32_t)(wave * 16 + i) * 1024
-                                                        : voff[i & 1] + ((i < 8 ? f_lo : f_hi) + (uint32_t)(i & 7) * 8 * ld2),
+  auto piece = [&](int q) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(pieces + wbuf * W4_STEP_BYTES + q * W4_PIECE_BYTES), 16,
+                                             (V & 1024) ? voff + (uint32_t)(wave * 16 + q) * 1024 : voff + (f_row + (uint32_t)w4_piece_rows(q) * ld2),
                                              (V & 1024) ? 0u : f_k, 0, 0);
   };
   // behind the sixteenth piece of a step: on to the next K step of the fetched tile, or to step 0 of the next tile
@@ -93,19 +88,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     }
   };
 
-  // ---- fragment reads: per-lane byte offsets (k group kk) into the image being read ----
-  int offa[4], offb[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int o = (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
-    offa[kk] = o + fw * 16384;
-    offb[kk] = o + W4_REGION + tw * 16384;
-  }
+  // ---- fragment reads: ONE per-lane byte offset per operand into the image being read; fragment and k group are
+  // immediates (w4_frag_imm) ----
+  int offa = w4_frag_lane(l31, hi) + fw * (16 * W4_PIECE_BYTES);
+  int offb = w4_frag_lane(l31, hi) + (32 + tw * 16) * W4_PIECE_BYTES;
+  int flip = W4_STEP_BYTES;  // to the other image and back
   u32x4 Ra[4][4], Rb[4][4];  // [k group][fragment]
   f32x16 acc[4][4];          // [feature block i][token block j]
   auto read1 = [&](int kk, int q) __attribute__((always_inline)) {  // q-th of the eight fragment reads of k group kk
-    if (q < 4) Ra[kk][q] = *reinterpret_cast<const u32x4*>(lds + q * 4096 + offa[kk]);
-    else Rb[kk][q - 4] = *reinterpret_cast<const u32x4*>(lds + (q - 4) * 4096 + offb[kk]);
+    if (q < 4) Ra[kk][q] = *reinterpret_cast<const u32x4*>(lds + w4_frag_imm(q, kk) + offa);
+    else Rb[kk][q - 4] = *reinterpret_cast<const u32x4*>(lds + w4_frag_imm(q - 4, kk) + offb);
   };
   auto mma1 = [&](int kk, int m, auto first) __attribute__((always_inline)) {
     const int i = m >> 2, j = m & 3;
@@ -140,11 +132,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     else if (V & 256) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ablation: pieces never waited for
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {  // the other image from here on
-      offa[kk] ^= W4_STEP_BYTES;
-      offb[kk] ^= W4_STEP_BYTES;
-    }
+    offa += flip;  // the other image from here on
+    offb += flip;
+    flip = -flip;
     // groups 2, 3: MFMAs of k group g, reads of k group g - 2 of the NEXT step, the pieces of the step after it
 #pragma unroll
     for (int g = 2; g < 4; ++g) {
@@ -247,31 +237,30 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
   // ---- the same epilogue with the rows leaving as WHOLE cache lines (V & 32768; the host guarantees full feature
   // tiles and 16-byte aligned rows).  Straight from the accumulator layout a store instruction writes 32 bytes of each
   // of 32 rows, and the CU's store path handles one line per cycle: 32 cycles for 1 KiB.  Through a per-wave LDS stage
-  // (a 32-token slab of the wave's 128 - SwiGLU 64 - output features, rows XOR-swizzled in 16-byte chunks) an
-  // instruction covers CPR lanes per row = 8 (4) full lines.  The stage is written and read with inline assembly: for
-  // a C++ access to LDS the compiler first drains the VMEM queue (the pieces in flight might alias it, for all it
-  // knows), and with it every earlier store of the epilogue.  LDS operations of one wave execute in order: no barrier;
-  // the reads of slab j are in flight while slab j + 1 is converted.
-  constexpr int ROWB = EPI == TEPI_SILU ? 128 : 256, CPR = ROWB / 16, RPI = 64 / CPR, NCH = EPI == TEPI_SILU ? 4 : 8;
+  // (32 tokens x 64 output features = 128-byte rows, 16-byte chunks XOR-swizzled by the row) an instruction covers
+  // eight lanes per row = 8 full lines.  The stage is written and read with inline assembly: for a C++ access to LDS
+  // the compiler first drains the VMEM queue (the pieces in flight might alias it, for all it knows), and with it every
+  // earlier store of the epilogue.  LDS operations of one wave execute in order: no barrier; the reads of one slab
+  // are in flight while the next one is converted.
+  // A slab = token block j x feature blocks (2 u, 2 u + 1); plain: u = 0, 1 (the wave's 128 features), SwiGLU: u = 0
+  // (its 64 outputs: gate block i, up block i + 2).
+  constexpr int NU = EPI == TEPI_SILU ? 1 : 2, NSLAB = 4 * NU;
   const uint32_t stg_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + 2 * W4_STEP_BYTES) + wave * W4_STAGE_BYTES;
-  const uint32_t stg_w = stg_base + (uint32_t)l31 * ROWB + (uint32_t)(((l31 & 7) ^ hi) << 4);  // ^ (4 i + 2 p2) << 4 per chunk
-  uint32_t stg_r[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par) {
-    const int r = lane / CPR, c = lane % CPR;
-    stg_r[par] = stg_base + (uint32_t)r * ROWB + (uint32_t)((c ^ ((par * RPI + r) & 7)) << 4);  // + it * RPI * ROWB as an immediate
-  }
+  const uint32_t stg_w = stg_base + (uint32_t)l31 * 128 + (uint32_t)(((l31 & 7) ^ hi) << 4);  // ^ (4 i' + 2 p2) << 4 per chunk
+  const uint32_t stg_r = stg_base + (uint32_t)(lane >> 3) * 128 + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);  // + 8 rows per read
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (uint32_t)a.M * (uint32_t)a.ldy * 2, 0x00020000);
-  const uint32_t y_lane = (uint32_t)(lane / CPR) * (uint32_t)a.ldy * 2 + (uint32_t)(lane % CPR) * 16;
+  const uint32_t y_lane = (uint32_t)(lane >> 3) * (uint32_t)a.ldy * 2 + (uint32_t)(lane & 7) * 16;
   auto epilogue_lines = [&](int m0, int n0) __attribute__((always_inline)) {
-    u32x4 out[NCH], back[NCH];
-    // (opaque per tile: otherwise the eight chunk addresses are hoisted out of the tile loop and live - spilled -
-    // through the whole K loop)
+    u32x4 out[4], back[4];
+    // (opaque per tile: otherwise the chunk addresses are hoisted out of the tile loop and live - spilled - through
+    // the whole K loop)
     uint32_t w_addr = stg_w;
     asm volatile("" : "+v"(w_addr));
-    auto convert = [&](int j) __attribute__((always_inline)) {
+    auto convert = [&](int slab) __attribute__((always_inline)) {
+      const int j = slab / NU, u = slab % NU;
 #pragma unroll
-      for (int i = 0; i < (EPI == TEPI_SILU ? 2 : 4); ++i) {
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * u + ii;
         u32x2 pk[4];
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -300,26 +289,27 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
         for (int p2 = 0; p2 < 2; ++p2) {
           const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
           const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
-          out[2 * i + p2] = u32x4{sx[0], sy[0], sx[1], sy[1]};  // features 32 i + 16 p2 + 8 hi .. + 7 of token l31
+          out[2 * ii + p2] = u32x4{sx[0], sy[0], sx[1], sy[1]};  // features 32 ii + 16 p2 + 8 hi .. + 7 of the slab, token l31
         }
       }
     };
     auto stage_in = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)  // chunk 2 ch + hi of row l31
+      for (int ch = 0; ch < 4; ++ch)  // chunk 2 ch + hi of row l31
         asm volatile("ds_write_b128 %0, %1" ::"v"(w_addr ^ (uint32_t)(ch << 5)), "v"(out[ch]) : "memory");
     };
     auto stage_out = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int it = 0; it < NCH; ++it)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(back[it]) : "v"(stg_r[(it * RPI >> 2) & 1]), "n"(it * RPI * ROWB) : "memory");
+      for (int it = 0; it < 4; ++it)  // rows 8 it + (lane >> 3): (row & 7) = lane >> 3 for every it
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(back[it]) : "v"(stg_r), "n"(it * 1024) : "memory");
     };
-    auto store_lines = [&](int j) __attribute__((always_inline)) {
+    auto store_lines = [&](int slab) __attribute__((always_inline)) {
+      const int j = slab / NU, u = slab % NU;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint32_t colb = (uint32_t)(EPI == TEPI_SILU ? (n0 >> 1) + fw * 64 : n0 + fw * 128) * 2;
+      const uint32_t colb = (uint32_t)(EPI == TEPI_SILU ? (n0 >> 1) + fw * 64 : n0 + fw * 128 + u * 64) * 2;
 #pragma unroll
-      for (int it = 0; it < NCH; ++it) {
-        const uint32_t rowb = (uint32_t)(m0 + tw * 128 + j * 32 + it * RPI) * (uint32_t)a.ldy * 2 + colb;
+      for (int it = 0; it < 4; ++it) {
+        const uint32_t rowb = (uint32_t)(m0 + tw * 128 + j * 32 + it * 8) * (uint32_t)a.ldy * 2 + colb;
         // (rows past M are beyond the descriptor's range: dropped)
         __builtin_amdgcn_raw_buffer_store_b128(back[it], yrsrc, y_lane + rowb, 0, 0);
       }
@@ -328,13 +318,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     stage_in();
     stage_out();
 #pragma unroll
-    for (int j = 1; j < 4; ++j) {
-      convert(j);
-      store_lines(j - 1);
+    for (int slab = 1; slab < NSLAB; ++slab) {
+      convert(slab);
+      store_lines(slab - 1);
       stage_in();
       stage_out();
     }
-    store_lines(3);
+    store_lines(NSLAB - 1);
   };
 
   // ---- prologue: steps 0 and 1 of the stream into images 0 and 1; step 0 landed and published; its k groups 0, 1 read ----
@@ -359,9 +349,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     kstep(std::true_type{});
     for (int kt = 1; kt < KT; ++kt) kstep(std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
+    // A workgroup's last tile: its (empty) past-the-end pieces must not outlive the workgroup's LDS - waited for HERE,
+    // not behind the stores: the waves end with their stores in flight
+    if (blk + stride >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((V & 32768) && EPI != TEPI_PARTIAL) epilogue_lines(m0, n0);
     else epilogue(m0, n0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the past-the-end pieces must not outlive the workgroup's LDS
 }

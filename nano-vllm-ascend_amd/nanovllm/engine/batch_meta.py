@@ -75,14 +75,14 @@ def prefill_meta(seqs: list[Sequence], block_size: int, skip_cached: bool = Fals
     pos = np.empty(total, dtype=np.int64)
     slots = np.empty(total, dtype=np.int32)
     within = np.arange(int(full.max()) if len(seqs) else 0, dtype=np.int64)
-    for s, a, n, k in zip(seqs, cu[:-1], lens, skip):
-        a, n, k = int(a), int(n), int(k)
-        w = within[k:k + n]
+    in_block = np.arange(block_size, dtype=np.int32)
+    for s, a, n, k in zip(seqs, cu[:-1].tolist(), lens.tolist(), skip.tolist()):
         ids[a:a + n] = np.frombuffer(s.ids_array(), dtype=np.int64)[k:k + n]
-        pos[a:a + n] = w
+        pos[a:a + n] = within[k:k + n]
         if s.block_table:
-            table = np.asarray(s.block_table[: s.num_blocks], dtype=np.int64)
-            slots[a:a + n] = table[w // block_size] * block_size + w % block_size
+            # slot of position p = table[p // block_size] * block_size + p % block_size: one broadcast over whole blocks
+            table = np.asarray(s.block_table[: s.num_blocks], dtype=np.int32)
+            slots[a:a + n] = (table[:, None] * block_size + in_block).reshape(-1)[k:k + n]
             if skip_cached and k < s.num_prefix_tokens:  # recomputed only for its logits
                 slots[a:a + s.num_prefix_tokens - k] = -1
         else:

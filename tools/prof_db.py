@@ -64,7 +64,32 @@ def window(path, anchor_substr, n_anchor, label):
         print(f"   {name[:96]:96s} {cnt:5d} {tot / cnt:9.2f} us avg {tot:10.1f} us {100 * tot / span:5.1f} %")
 
 
+def edges(path, anchor_substr, n_anchor, around=14):
+    """The kernels just before the first and just behind the last of the LAST n_anchor dispatches of the anchor kernel
+    (a prefill step's head: embedding .. first attention, and tail: last attention .. sampler), with start offsets,
+    durations and the idle gap in front of each - what a step spends outside its layers."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = list(cur.execute(f"""select s.kernel_name, d.start, d.end from {kd} d join {ks} s
+                                on d.kernel_id = s.id order by d.start"""))
+    anchors = [i for i, r in enumerate(rows) if anchor_substr in r[0]][-n_anchor:]
+    lo, hi = anchors[0], anchors[-1]
+    t0 = rows[lo][1]
+    for title, a, b in (("head", max(0, lo - around), lo + 1), ("tail", hi, min(len(rows), hi + around))):
+        print(f"{title}: (us relative to the first anchor's start; gap = idle time in front of the kernel)")
+        for i in range(a, b):
+            name, st, en = rows[i]
+            gap = (st - rows[i - 1][2]) / 1000.0 if i else 0.0
+            print(f"   {(st - t0) / 1000.0:10.1f}  {(en - st) / 1000.0:8.1f} us  gap {gap:8.1f}  {name[:90]}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 4 and sys.argv[2] == "--edges":
+        edges(sys.argv[1], sys.argv[3], int(sys.argv[4]))
+        sys.exit(0)
     if len(sys.argv) > 5 and sys.argv[2] == "--window":
         window(sys.argv[1], sys.argv[3], int(sys.argv[4]), sys.argv[5])
     elif len(sys.argv) > 4 and sys.argv[2] == "--last":

@@ -30,4 +30,4 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SA
 db=$(find /tmp/prof_sq2 -name "*.db" | head -1)
 python $R/tools/prof_pmc.py $db --last paged_attn_decode_kernel 560 >> $O/pmc_sq_attention.txt
 cd $R
-ls -la $O; cat $O/bench.json; tail -4 $O/kernel_trace.txt; cat $O/pmc_sq_attention.txt; tail -3 $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt
+ls -la $O; cat $O/bench.json; tail -4 $O/kernel_trace.txt; cat $O/pmc_sq_attention.txt; tail -3 $O/pmc_FETCH_SIZE.txt; tail -3 $O/pmc_WRITE_SIZE.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 O=gpurun_out/r04_s14; mkdir -p $O
 export PYTHONUNBUFFERED=1
-( GEMM_QUICK=1 GEMM_ABLATE=1 timeout 600 python tools/gemm_bench.py $O/gemm_ablate.json 2>&1 | grep -v Warn | cut -c1-1500 ) > $O/gemm_ablate.txt
+( GEMM_QUICK=1 timeout 600 python tools/gemm_bench.py $O/gemm_ablate.json 2>&1 | grep -v Warn | cut -c1-1500 ) > $O/gemm_ablate.txt
 python - <<PY
 import json
 for l in open("$O/gemm_ablate.txt"):

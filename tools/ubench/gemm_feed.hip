@@ -233,14 +233,20 @@ __global__ __launch_bounds__(256, 1) void pipe_kernel(const char* __restrict__ s
 // one behind every second MFMA of groups 2 and 3 (a piece blocks its wave ~60 cycles, an MFMA runs 32) and have a
 // whole K step to land.
 //   FEED 0: no pieces in the loop;  FEED 1: 16 pieces, 1 per 2 MFMAs over groups 2 and 3;  FEED 2: 16 pieces, 1 per MFMA over group 2
+//   FEED 3: FEED 1 with the piece's offset in the VECTOR offset (one v_add per piece) instead of the scalar one
+//   FEED 4 / 5 / 6: FEED 3 fetching what the qkv GEMM of the bench fetches (x: 16384 x 1024 bf16 = 32 MiB, w: 4096 x
+//           1024 = 8 MiB behind it; waves 0, 1 the weight panel of feature tile blockIdx & 15, waves 2, 3 the activation
+//           panel of token tile (blockIdx >> 4) + 16 (t / 16); 8 rows x 128 bytes per piece, rows 2 KiB apart) with the
+//           default / nt (aux 2) / sc1 (aux 16) cache policy on the loads
 template <int FEED>
 __global__ __launch_bounds__(256, 1) void pipe2_kernel(const char* __restrict__ src, float* __restrict__ sink, int ksteps) {
   __shared__ __attribute__((aligned(1024))) char lds[2 * KSTEP_BYTES];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const char* stream = src + (size_t)(blockIdx.x & 7) * ((size_t)ksteps * KSTEP_BYTES);
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, ksteps * KSTEP_BYTES, 0x00020000);
-  const int voff = wave * 16384 + lane * 16;
+  constexpr bool GEMM_LIKE = FEED >= 4;
+  const char* stream = GEMM_LIKE ? src : src + (size_t)(blockIdx.x & 7) * ((size_t)ksteps * KSTEP_BYTES);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, GEMM_LIKE ? (40 << 20) : ksteps * KSTEP_BYTES, 0x00020000);
+  const int voff = GEMM_LIKE ? (lane >> 3) * 2048 + (lane & 7) * 16 : wave * 16384 + lane * 16;
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -257,8 +263,17 @@ __global__ __launch_bounds__(256, 1) void pipe2_kernel(const char* __restrict__ 
   }
   u32x4 Ra[4][4], Rb[4][4];
   auto dma = [&](int t, int i, int buf) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + buf * KSTEP_BYTES + wave * 16384 + i * 1024),
-                                             16, voff, t * KSTEP_BYTES + i * 1024, 0, 0);
+    auto dst = (__attribute__((address_space(3))) void*)(lds + buf * KSTEP_BYTES + wave * 16384 + i * 1024);
+    if (FEED >= 4) {
+      // row base of this wave's 128 rows: weights behind the 32 MiB of activations
+      const int tile = wave < 2 ? (int)(blockIdx.x & 15) : (((int)blockIdx.x >> 4) + 16 * (t >> 4)) & 63;
+      const uint32_t rows = (wave < 2 ? (32u << 20) : 0u) + (uint32_t)(tile * 256 + (wave & 1) * 128 + i * 8) * 2048u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff + rows, (t & 15) * 128, 0, FEED == 5 ? 2 : (FEED == 6 ? 16 : 0));
+    } else if (FEED == 3) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff + (uint32_t)(i * 1024 + (ksteps & 0)), t * KSTEP_BYTES, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, t * KSTEP_BYTES + i * 1024, 0, 0);
+    }
   };
   auto read1 = [&](int kk, int q) __attribute__((always_inline)) {  // q-th of the eight fragment reads of k group kk
     if (q < 4) Ra[kk][q] = *reinterpret_cast<const u32x4*>(lds + q * 4096 + offa[kk]);
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void pipe2_kernel(const char* __restrict__ 
         if (FEED == 2 && g == 2) dma(t + 2, 2 * q, p);
         __builtin_amdgcn_sched_barrier(0);
         mma1(g, 2 * q + 1);
-        if (FEED == 1) dma(t + 2, (g - 2) * 8 + q, p);
+        if (FEED == 1 || FEED >= 3) dma(t + 2, (g - 2) * 8 + q, p);
         if (FEED == 2 && g == 2) dma(t + 2, 2 * q + 1, p);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -318,6 +333,71 @@ __global__ __launch_bounds__(256, 1) void pipe2_kernel(const char* __restrict__ 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+// MFMA shape under the power limit: the same flops per K step as 64 v_mfma_f32_32x32x16_bf16 or 128
+// v_mfma_f32_16x16x32_bf16 (half the accumulator register traffic per flop, twice the operand traffic), nothing else
+// in the loop; operands are random bf16 patterns loaded once.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int SHAPE>
+__global__ __launch_bounds__(256, 1) void mfma_shape_kernel(const char* __restrict__ src, float* __restrict__ sink, int ksteps) {
+  const int lane = threadIdx.x & 63;
+  u32x4 A[8], B[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    A[i] = *reinterpret_cast<const u32x4*>(src + (size_t)(i * 64 + lane) * 16 + (size_t)(blockIdx.x & 255) * 65536);
+    B[i] = *reinterpret_cast<const u32x4*>(src + (size_t)((8 + i) * 64 + lane) * 16 + (size_t)(blockIdx.x & 255) * 65536);
+  }
+  float s = 0.f;
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  if (SHAPE == 32) {
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int t = 0; t < ksteps; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(i + kk) & 7]), __builtin_bit_cast(bf16x8, B[(j + 2 * kk) & 7]), acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  } else {
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    for (int t = 0; t < ksteps; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[(i + ks) & 7]), __builtin_bit_cast(bf16x8, B[(j + 3 * ks) & 7]), acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  }
+  const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { sink[1024 + 2 * blockIdx.x] = (float)(c1 - c0); sink[1025 + 2 * blockIdx.x] = (float)(r1 - r0); }
   if (s == 12345.678f) sink[threadIdx.x] = s;
 }
 
@@ -355,7 +435,7 @@ static double run(const char* src, float* sink, int ksteps) {
 
 int main() {
   const int ksteps = 64;
-  const size_t bytes = (size_t)8 * ksteps * KSTEP_BYTES;
+  const size_t bytes = (size_t)40 << 20;  // >= 8 streams of ksteps x 64 KiB; the GEMM-like modes: 32 MiB of activations + 8 MiB of weights
   char* src; float* sink;
   CK(hipMalloc(&src, bytes)); CK(hipMalloc(&sink, 8192));
   // random bf16-ish data (DVFS: zero operands clock higher)
@@ -382,5 +462,12 @@ int main() {
   t = run_fn(pipe2_kernel<0>, src, sink, ksteps); printf("  reads only, no feed                         %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
   t = run_fn(pipe2_kernel<1>, src, sink, ksteps); printf("  + 16 pieces, 1 per 2 MFMAs, groups 2 and 3  %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
   t = run_fn(pipe2_kernel<2>, src, sink, ksteps); printf("  + 16 pieces, 1 per MFMA, group 2            %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<3>, src, sink, ksteps); printf("  1 per 2 MFMAs, offset in the vector offset  %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<4>, src, sink, ksteps); printf("  the qkv GEMM's fetch pattern (40 MiB)       %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<5>, src, sink, ksteps); printf("  ... loads nt                                %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<6>, src, sink, ksteps); printf("  ... loads sc1                               %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  printf("MFMA shape under the power limit (MFMAs only, random operands)\n");
+  t = run_fn(mfma_shape_kernel<32>, src, sink, ksteps); printf("  64 x v_mfma_f32_32x32x16_bf16 per K step    %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(mfma_shape_kernel<16>, src, sink, ksteps); printf("  128 x v_mfma_f32_16x16x32_bf16 per K step   %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
   return 0;
 }
