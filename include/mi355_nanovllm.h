@@ -313,6 +313,21 @@ int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream 
 size_t mi_gemm_bf16_workspace(int M, int N, int K, int epilogue);
 int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y, int64_t ldy,
                  int M, int N, int K, int epilogue, void* workspace, size_t ws_bytes, mi_stream stream);
+/* The packed qkv projection of a prefill step with the K / V side of qwen3.py:79-90 + attention.py:55-58 in its
+ * epilogue (round 4): qkv[M][N] = x @ w^T (+ bias) as mi_gemm_bf16, but only the q heads (columns
+ * [0, n_q_heads * 128)) are written to `qkv`; every k head is k-normed (k_w, or NULL: none), rotated (positions,
+ * cos_sin as mi_qknorm_rope_store) and stored into k_cache, every v head into v_cache, at `slots` (flat int32 [M]:
+ * block * block_size + offset; negative = not stored) in the fragment-native tile layout - the same bits
+ * mi_gemm_bf16 + mi_qknorm_rope_store(q_out = NULL) leave in the caches (tests/test_gemm_qkv_store_gpu.py).
+ * The attention that follows reads q from the packed rows (mi_paged_attn_prefill_fused).
+ * MI_EUNSUPPORTED unless head_dim == 128, N == (n_q_heads + 2 n_kv_heads) * 128, N % 256 == 0, ldy % 8 == 0,
+ * block_size % 16 == 0 and (M, N) is a large-M shape (>= 256 tiles of 256 x 256): the caller then takes the two
+ * launches. */
+int mi_gemm_bf16_qkv_store(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* qkv,
+                           int64_t ldy, int M, int N, int K, const mi_bf16* k_w, float eps, const int64_t* positions,
+                           const float* cos_sin, mi_bf16* k_cache, mi_bf16* v_cache, const int32_t* slots,
+                           int n_q_heads, int n_kv_heads, int head_dim, int block_size, mi_stream stream);
+
 /* Tuning form of mi_gemm_bf16 (tools/gemm_bench.py): variant = 16 * prefetch depth + schedule flags, see
  * csrc/gemm_tile.hip; MI_EUNSUPPORTED for variants that are not compiled. */
 int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, mi_bf16* y, int64_t ldy, int M, int N, int K,

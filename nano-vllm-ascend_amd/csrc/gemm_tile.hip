@@ -36,13 +36,14 @@
 
 #include "mi_common.hpp"
 #include "gemm_tile_index.hpp"
+#include "kv_store.hpp"
 
 namespace mi {
 using namespace gt;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-enum { TEPI_NONE = 0, TEPI_SILU = 1, TEPI_PARTIAL = 2 };
+enum { TEPI_NONE = 0, TEPI_SILU = 1, TEPI_PARTIAL = 2, TEPI_QKV = 3 };
 
 struct TileArgs {
   const uint16_t* x;
@@ -53,6 +54,17 @@ struct TileArgs {
   int M, N, K;
   int tiles_f, tiles_t;
   float* part;  // split-K (gridDim.y > 1): fp32 partial sums [gridDim.y][M][N] instead of y
+  // TEPI_QKV (mi_gemm_bf16_qkv_store): the K and V heads of the packed qkv projection go straight to the paged cache
+  struct QkvStore {
+    const uint16_t* k_w;       // k-norm weight [128] or null
+    const int64_t* positions;  // [M]
+    const float* cos_sin;      // [max_position][128]
+    uint16_t* k_cache;
+    uint16_t* v_cache;
+    const int32_t* slots;      // [M] flat slots (block * block_size + offset; negative: not stored)
+    float eps;
+    int n_q_heads, n_kv_heads, block_size;
+  } qkv;
 };
 
 // Tuning variants (mi_gemm_bf16_ex; the product entry point uses kDefaultV):
@@ -762,6 +774,30 @@ extern "C" int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, con
   }
   if (mid) return bias ? launch_mid<TEPI_NONE, true>(a, st) : launch_mid<TEPI_NONE, false>(a, st);
   return bias ? launch_tile<TEPI_NONE, true>(a, st) : launch_tile<TEPI_NONE, false>(a, st);
+}
+
+// The packed qkv projection with the K / V heads stored straight into the paged cache (TEPI_QKV, gemm_w4_kernel.hpp)
+extern "C" int mi_gemm_bf16_qkv_store(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* qkv,
+                                      int64_t ldy, int M, int N, int K, const mi_bf16* k_w, float eps,
+                                      const int64_t* positions, const float* cos_sin, mi_bf16* k_cache,
+                                      mi_bf16* v_cache, const int32_t* slots, int n_q_heads, int n_kv_heads,
+                                      int head_dim, int block_size, mi_stream stream) {
+  const int rc = check_tile_gemm(x, ldx, w, bias, qkv, ldy, M, N, K, 0);
+  if (rc != MI_OK) return rc;
+  if (!positions || !cos_sin || !k_cache || !v_cache || !slots || n_q_heads <= 0 || n_kv_heads <= 0) return MI_EINVAL;
+  if (!aligned16(k_cache) || !aligned16(v_cache) || !aligned16(slots) || !aligned16(cos_sin) || (k_w && !aligned16(k_w))) return MI_EINVAL;
+  // one wave = one head; whole feature tiles and 16-byte aligned output rows (the whole-line stores of the q heads)
+  if (head_dim != 128 || N != (n_q_heads + 2 * n_kv_heads) * 128 || N % TILE_F || ldy % 8 || block_size <= 0 || block_size % 16)
+    return MI_EUNSUPPORTED;
+  if (use_mid(M, N, K) || (int64_t)M * ldy * 2 >= ((int64_t)1 << 32)) return MI_EUNSUPPORTED;  // the large-M kernel only
+  if (M == 0) return MI_OK;
+  TileArgs a{x, w, bias, qkv, ldx, ldy, M, N, K, N / TILE_F, (M + TILE_T - 1) / TILE_T, nullptr,
+             {k_w, positions, cos_sin, k_cache, v_cache, slots, eps, n_q_heads, n_kv_heads, block_size}};
+  const int ntiles = a.tiles_f * a.tiles_t;
+  const dim3 grid(ntiles > kPersistentGrid ? kPersistentGrid : ntiles);
+  if (bias) hipLaunchKernelGGL((gemm_w4_kernel<TEPI_QKV, true, kLineStores>), grid, dim3(256), 0, S(stream), a);
+  else hipLaunchKernelGGL((gemm_w4_kernel<TEPI_QKV, false, kLineStores>), grid, dim3(256), 0, S(stream), a);
+  return check_launch();
 }
 
 // tuning entry point (tools/gemm_bench.py): variant = schedule flags V, no bias, plain epilogue

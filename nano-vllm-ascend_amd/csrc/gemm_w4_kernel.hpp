@@ -111,9 +111,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     }
   };
 
-  // One K step.  FIRST: step 0 of a tile (group 0 starts the accumulators).
-  auto kstep = [&](auto first) __attribute__((always_inline)) {
+  // One K step.  FIRST: step 0 of a tile (group 0 starts the accumulators).  LAST (the qkv-store kernel only): the
+  // tile's last step - the k groups 0, 1 of the NEXT tile's first step are not read here but behind the epilogue
+  // (read_first_groups): 64 registers its K / V branches need, for ~300 cycles of exposed LDS latency per tile
+  // (measured on the plain kernels: 3-5 % of the GEMM - they keep the prefetch).
+  constexpr bool kRereadAfterEpilogue = EPI == TEPI_QKV;
+  auto kstep = [&](auto first, auto last) __attribute__((always_inline)) {
     using First = decltype(first);
+    constexpr bool LAST = kRereadAfterEpilogue && decltype(last)::value;
     // groups 0, 1: MFMAs of k group g, reads of k group g + 2 of the same image
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         mma1(g, 2 * q, std::false_type{});
-        if (!(V & 64)) read1(g - 2, q);
+        if (!(V & 64) && !LAST) read1(g - 2, q);
         __builtin_amdgcn_sched_barrier(0);
         mma1(g, 2 * q + 1, std::false_type{});
         if (!(V & 32)) piece((g - 2) * 8 + q);
@@ -327,6 +332,161 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     store_lines(NSLAB - 1);
   };
 
+  // ---- TEPI_QKV: the packed qkv projection whose K and V heads never reach the qkv rows (VERDICT r03 item 1b;
+  // qwen3.py:79-90 + attention.py:55-58 of the reference: split, k-norm, RoPE, store_kvcache).  head_dim 128: a wave's
+  // 128 features are exactly ONE head (q, k or v - wave-uniform).  Q heads: the ordinary whole-line stores (the
+  // attention kernel norms and rotates q in its operand load).  K heads: after the epilogue's half-wave exchange the
+  // lane pair (hi = 0 / 1) of a token holds the head as 8-dim groups 2 kk + hi - the distribution of
+  // head_rmsnorm_rope_q32 (kv_store.hpp), which is bit-identical to the 8-lanes-per-head form of mi_qknorm_rope_store;
+  // its 16-byte groups are the cache tile's own chunks: stored straight from the registers, no staging.  V heads: the
+  // cache tile is token-transposed (4 tokens x {d, d + 16} per 16-byte chunk): the (d, d + 16) pairs of a token go
+  // through the wave's LDS stage as 32-bit words and come back as chunks; four tokens whose slots are not four
+  // consecutive ones of a tile (sequence seams, skipped tokens) are scattered element by element.
+  auto epilogue_qkv = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int head = (n0 >> 7) + fw, nq = a.qkv.n_q_heads, nkv = a.qkv.n_kv_heads, bs = a.qkv.block_size;
+    if (head < nq) {
+      epilogue_lines(m0, n0);
+      return;
+    }
+    if (head >= nq + 2 * nkv) return;
+    const bool is_v = head >= nq + nkv;
+    const int hk = head - nq - (is_v ? nkv : 0), tpb = bs >> 4;
+    // Everything lane-dependent below is derived from an OPAQUE copy of the lane id: computed here, per tile.  Derived
+    // from `lane` the compiler hoists dozens of such values out of the tile loop, they live through the K loop, and
+    // the register file of the loop (256 accumulators + 128 fragment registers) starts spilling accumulators.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int hi = lane_e >> 5, l31 = lane_e & 31;
+    const uint32_t stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + 2 * W4_STEP_BYTES) + wave * W4_STAGE_BYTES;
+    auto value = [&](int i, int j, int r) __attribute__((always_inline)) -> float {  // the GEMM output element, un-rounded
+      float o = acc[i][j][r];
+      if (BIAS) o += bf2f(a.bias[n0 + fw * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+      return o;
+    };
+#ifdef MI_QKV_ABLATE  // timing experiments (tools/sessions): 1 = K heads skipped, 2 = V heads skipped, 3 = both
+    if ((MI_QKV_ABLATE & 1) && !is_v) return;
+    if ((MI_QKV_ABLATE & 2) && is_v) return;
+#endif
+    if (!is_v) {
+      // The table rows are two dependent global loads away (position, then its cos / sin row) with ONE wave per SIMD to
+      // hide them: positions and slots of all four token blocks are requested first, the row of block j + 1 as soon
+      // as block j has been rotated.
+      int slot[4];
+      const float* cs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tok = m0 + w4_acc_token(tw, j, l31);
+        const int tk = tok < a.M ? tok : a.M - 1;
+        slot[j] = tok < a.M ? a.qkv.slots[tk] : -1;
+        cs[j] = a.qkv.cos_sin + a.qkv.positions[tk] * 128;
+      }
+      RopeRegs32 rope;  // (ONE set of 64 registers)
+      rope_regs_q32_load(rope, cs[0], hi);
+
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4 xp[8];  // the head of token l31 as packed bf16: xp[kk] = dims 16 kk + 8 hi .. + 7
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x2 pk[4];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            pk[rq] = u32x2{pack_bf(value(i, j, 4 * rq), value(i, j, 4 * rq + 1)), pack_bf(value(i, j, 4 * rq + 2), value(i, j, 4 * rq + 3))};
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+            xp[2 * i + p2] = u32x4{sx[0], sy[0], sx[1], sy[1]};  // dims 32 i + 16 p2 + 8 hi .. + 7 = group 2 (2 i + p2) + hi
+          }
+        }
+        head_rmsnorm_rope_q32_packed(xp, a.qkv.k_w, rope, hi, a.qkv.eps);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < 3) rope_regs_q32_load(rope, cs[j + 1], hi);  // under this block's stores and the next one's conversion
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot[j] >= 0) {
+          const int blk = slot[j] / bs, off = slot[j] - blk * bs;
+          uint16_t* tile = a.qkv.k_cache + kv_tile_base(blk, hk, off, nkv, tpb);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) *reinterpret_cast<u32x4*>(tile + k_tile_off(off & 15, 8 * (2 * kk + hi))) = xp[kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (one token block at a time: interleaved blocks need the registers twice)
+      }
+      return;
+    }
+    // V: words (d, d + 16) of token l31 into the stage at [32-dim block][token group l31 >> 2][(d & 15) ^ group][l31 & 3]
+    const int tg = l31 >> 2;
+    uint32_t w_e[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w_e[e] = stage + (uint32_t)((tg * 16 + ((4 * hi + e) ^ tg)) * 16 + (l31 & 3) * 4);
+    const uint32_t r_addr = stage + (uint32_t)lane_e * 16;
+    // the slots of the token quadruples this lane_e will store (chunk it * 64 + lane_e of a stage image: token group
+    // tgp = (it & 1) * 4 + (lane_e >> 4) of block j), requested up front: one round trip instead of one per image
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    i32x4 sl4[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int tok0 = m0 + tw * 128 + j * 32 + 4 * (h2 * 4 + (lane_e >> 4));
+        if (tok0 + 3 < a.M) {
+          sl4[j][h2] = *reinterpret_cast<const i32x4*>(a.qkv.slots + tok0);
+        } else {
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) sl4[j][h2][tt] = tok0 + tt < a.M ? a.qkv.slots[tok0 + tt] : -1;
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // the 32-dim blocks 2 u, 2 u + 1 of the head: 256 chunks = the 4 KiB stage
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int rq = 0; rq < 2; ++rq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // dims d = 32 (2 u + ii) + 8 rq + 4 hi + e and d + 16, rounded to bf16 as the qkv rows would hold them
+              const uint32_t wv = pack_bf(value(2 * u + ii, j, 4 * rq + e), value(2 * u + ii, j, 4 * (rq + 2) + e));
+              if (ii == 0 && rq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(w_e[e]), "v"(wv) : "memory");
+              else if (ii == 0) asm volatile("ds_write_b32 %0, %1 offset:128" ::"v"(w_e[e]), "v"(wv) : "memory");
+              else if (rq == 0) asm volatile("ds_write_b32 %0, %1 offset:2048" ::"v"(w_e[e]), "v"(wv) : "memory");
+              else asm volatile("ds_write_b32 %0, %1 offset:2176" ::"v"(w_e[e]), "v"(wv) : "memory");
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 back[4];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(back[0]) : "v"(r_addr) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(back[1]) : "v"(r_addr) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(back[2]) : "v"(r_addr) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(back[3]) : "v"(r_addr) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(back[0]), "+v"(back[1]), "+v"(back[2]), "+v"(back[3])::"memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          // chunk it * 64 + lane_e of the stage: 32-dim block it >> 1, token group tgp, stored position lane_e & 15
+          const int tgp = (it & 1) * 4 + (lane_e >> 4), d15 = (lane_e & 15) ^ tgp;
+          const int d = (2 * u + (it >> 1)) * 32 + d15;  // the chunk holds dims d and d + 16 of tokens tok0 .. tok0 + 3
+          const int sl[4] = {sl4[j][it & 1][0], sl4[j][it & 1][1], sl4[j][it & 1][2], sl4[j][it & 1][3]};
+          const uint32_t w0 = back[it][0], w1 = back[it][1], w2 = back[it][2], w3 = back[it][3];
+          if (sl[0] >= 0 && (sl[0] & 3) == 0 && sl[1] == sl[0] + 1 && sl[2] == sl[0] + 2 && sl[3] == sl[0] + 3) {
+            const int blk = sl[0] / bs, off = sl[0] - blk * bs;
+            uint16_t* tile = a.qkv.v_cache + kv_tile_base(blk, hk, off, nkv, tpb);
+            *reinterpret_cast<u32x4*>(tile + v_tile_off(off & 15, d)) =
+                u32x4{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16), (w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
+          } else {
+            const uint32_t wt[4] = {w0, w1, w2, w3};
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+              if (sl[tt] >= 0) {
+                const int blk = sl[tt] / bs, off = sl[tt] - blk * bs;
+                uint16_t* tile = a.qkv.v_cache + kv_tile_base(blk, hk, off, nkv, tpb);
+                tile[v_tile_off(off & 15, d)] = (uint16_t)(wt[tt] & 0xffffu);
+                tile[v_tile_off(off & 15, d + 16)] = (uint16_t)(wt[tt] >> 16);
+              }
+          }
+        }
+      }
+    }
+  };
+
   // ---- prologue: steps 0 and 1 of the stream into images 0 and 1; step 0 landed and published; its k groups 0, 1 read ----
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -337,23 +497,39 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  // k groups 0, 1 of the image the fragment offsets point at: the first step of the next tile
+  auto read_first_groups = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    read1(0, q);
-    read1(1, q);
-  }
+    for (int q = 0; q < 8; ++q) {
+      read1(0, q);
+      read1(1, q);
+    }
+  };
+  read_first_groups();
 
   for (int blk = (int)blockIdx.x; blk < ntiles; blk += stride) {
     const int tid = tile_of_block(blk, a.tiles_t, a.tiles_f, (V & 4) != 0);
     const int m0 = (tid / a.tiles_f) * TILE_T, n0 = (tid % a.tiles_f) * TILE_F;
-    kstep(std::true_type{});
-    for (int kt = 1; kt < KT; ++kt) kstep(std::false_type{});
+    if constexpr (kRereadAfterEpilogue) {
+      if (KT == 1) {
+        kstep(std::true_type{}, std::true_type{});
+      } else {
+        kstep(std::true_type{}, std::false_type{});
+        for (int kt = 1; kt < KT - 1; ++kt) kstep(std::false_type{}, std::false_type{});
+        kstep(std::false_type{}, std::true_type{});
+      }
+    } else {
+      kstep(std::true_type{}, std::false_type{});
+      for (int kt = 1; kt < KT; ++kt) kstep(std::false_type{}, std::false_type{});
+    }
     __builtin_amdgcn_sched_barrier(0);
     // A workgroup's last tile: its (empty) past-the-end pieces must not outlive the workgroup's LDS - waited for HERE,
     // not behind the stores: the waves end with their stores in flight
     if (blk + stride >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((V & 32768) && EPI != TEPI_PARTIAL) epilogue_lines(m0, n0);
+    if constexpr (EPI == TEPI_QKV) epilogue_qkv(m0, n0);
+    else if ((V & 32768) && EPI != TEPI_PARTIAL) epilogue_lines(m0, n0);
     else epilogue(m0, n0);
     __builtin_amdgcn_sched_barrier(0);
+    if (kRereadAfterEpilogue && blk + stride < ntiles) read_first_groups();
   }
 }

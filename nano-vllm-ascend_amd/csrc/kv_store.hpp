@@ -121,8 +121,24 @@ __device__ __forceinline__ void head_rope_frag(float (&x)[4][8], const float* cs
 // in x[kk][e], i.e. the 8-dim groups 2 kk + hi.  Group j < 8 is the 8-lane form's a of lane j, group 8 + j its b:
 // lane hi holds (a, b) = (x[m], x[m + 4]) of the 8-lane lanes j = 2 m + hi.  Sums are associated as head_rmsnorm's
 // (per lane a then b, then the xor-1 / 2 / 4 tree: the xor-1 partner sits in the other lane), so the bits agree.
-__device__ __forceinline__ void head_rmsnorm_rope_q32(float (&x)[8][8], const uint16_t* w, const float* cs, int hi,
-                                                      float eps) {
+// the table values a lane needs: c[m] / sn[m] = cos / sin of the 8-dim group 2 m + hi (cos_sin row: 64 cos, then 64 sin)
+struct RopeRegs32 {
+  float4 c[4][2], s[4][2];
+};
+__device__ __forceinline__ void rope_regs_q32_load(RopeRegs32& r, const float* cs, int hi) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float* cp = cs + 8 * (2 * m + hi);
+    r.c[m][0] = *reinterpret_cast<const float4*>(cp);
+    r.c[m][1] = *reinterpret_cast<const float4*>(cp + 4);
+    r.s[m][0] = *reinterpret_cast<const float4*>(cp + 64);
+    r.s[m][1] = *reinterpret_cast<const float4*>(cp + 68);
+  }
+}
+// the arithmetic of head_rmsnorm_rope_q32 on table values that are already in registers (the tile GEMM's qkv
+// epilogue requests them a token block ahead)
+__device__ __forceinline__ void head_rmsnorm_rope_q32_regs(float (&x)[8][8], const uint16_t* w, const RopeRegs32& r, int hi,
+                                                           float eps) {
 #pragma clang fp contract(off)
   if (w != nullptr) {
     float t[4];
@@ -151,11 +167,7 @@ __device__ __forceinline__ void head_rmsnorm_rope_q32(float (&x)[8][8], const ui
   }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const float* cp = cs + 8 * (2 * m + hi);
-    const float4 c0 = *reinterpret_cast<const float4*>(cp);
-    const float4 c1 = *reinterpret_cast<const float4*>(cp + 4);
-    const float4 s0 = *reinterpret_cast<const float4*>(cp + 64);
-    const float4 s1 = *reinterpret_cast<const float4*>(cp + 68);
+    const float4 c0 = r.c[m][0], c1 = r.c[m][1], s0 = r.s[m][0], s1 = r.s[m][1];
     const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
@@ -164,6 +176,77 @@ __device__ __forceinline__ void head_rmsnorm_rope_q32(float (&x)[8][8], const ui
       x[m][i] = rbf(x1 * c[i] - x2 * sn[i]);
       x[m + 4][i] = rbf(x2 * c[i] + x1 * sn[i]);
     }
+  }
+}
+__device__ __forceinline__ void head_rmsnorm_rope_q32(float (&x)[8][8], const uint16_t* w, const float* cs, int hi,
+                                                      float eps) {
+  RopeRegs32 r;
+  rope_regs_q32_load(r, cs, hi);
+  head_rmsnorm_rope_q32_regs(x, w, r, hi, eps);
+}
+
+// The same arithmetic once more, on the head held as PACKED bf16 (xp[kk] = dims 16 kk + 8 hi .. + 7, i.e. x[kk][0..7] of
+// the form above) and group by group, so that only 16 values are unpacked at a time: the tile GEMM's qkv epilogue
+// has ~190 registers for everything.  Every value of x above is a bf16 (the inputs are GEMM outputs rounded to bf16,
+// every result is rbf()'d): packing and unpacking are exact, the operations and their order are the ones above.
+__device__ __forceinline__ void head_rmsnorm_rope_q32_packed(u32x4 (&xp)[8], const uint16_t* w, const RopeRegs32& r, int hi,
+                                                             float eps) {
+#pragma clang fp contract(off)
+  float rs = 1.0f;
+  if (w != nullptr) {
+    float t[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo = lo_bf(xp[m][i]), hh = hi_bf(xp[m][i]);
+        ss += lo * lo;
+        ss += hh * hh;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo = lo_bf(xp[m + 4][i]), hh = hi_bf(xp[m + 4][i]);
+        ss += lo * lo;
+        ss += hh * hh;
+      }
+      t[m] = ss + __shfl_xor(ss, 32, 64);
+    }
+    const float ss = (t[0] + t[1]) + (t[2] + t[3]);
+    rs = 1.0f / sqrtf(ss / 128.0f + eps);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float xa[8], xb[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xa[2 * i] = lo_bf(xp[m][i]);
+      xa[2 * i + 1] = hi_bf(xp[m][i]);
+      xb[2 * i] = lo_bf(xp[m + 4][i]);
+      xb[2 * i + 1] = hi_bf(xp[m + 4][i]);
+    }
+    if (w != nullptr) {
+      float wa[8], wb[8];
+      load16(w + 8 * (2 * m + hi), wa);
+      load16(w + 64 + 8 * (2 * m + hi), wb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xa[i] = rbf(rbf(xa[i] * rs) * wa[i]);
+        xb[i] = rbf(rbf(xb[i] * rs) * wb[i]);
+      }
+    }
+    const float4 c0 = r.c[m][0], c1 = r.c[m][1], s0 = r.s[m][0], s1 = r.s[m][1];
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float ya[8], yb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x1 = xa[i], x2 = xb[i];
+      ya[i] = rbf(x1 * c[i] - x2 * sn[i]);
+      yb[i] = rbf(x2 * c[i] + x1 * sn[i]);
+    }
+    xp[m] = pack16(ya);
+    xp[m + 4] = pack16(yb);
   }
 }
 

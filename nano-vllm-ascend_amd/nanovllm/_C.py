@@ -103,6 +103,8 @@ _SIGNATURES = {
     "mi_gemm_bf16_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mi_gemm_bf16": (c_int, [_p, c_int64, _p, _p, _p, c_int64, c_int, c_int, c_int, c_int, _p, c_size_t, _p]),
     "mi_gemm_bf16_ex": (c_int, [_p, c_int64, _p, _p, c_int64, c_int, c_int, c_int, c_int, _p]),
+    "mi_gemm_bf16_qkv_store": (c_int, [_p, c_int64, _p, _p, _p, c_int64, c_int, c_int, c_int, _p, c_float, _p, _p, _p, _p, _p,
+                                       c_int, c_int, c_int, c_int, _p]),
     "mi_pack_weight": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_packed": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
     "mi_gemm_bf16_packed_splitk": (c_int, [_p, _p, _p, c_int, c_int, c_int, c_int, _p]),

@@ -79,7 +79,23 @@ class Qwen3Attention(nn.Module):
             self.q_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
             self.k_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
 
+    def _kv_store_in_projection(self, x: torch.Tensor) -> bool:
+        """A prefill step whose qkv projection can carry k-norm + RoPE + the K / V cache store in its epilogue
+        (mi_gemm_bf16_qkv_store): the large-M tile kernel's shapes, head_dim 128, plain bf16 weights.  OPT-IN
+        (MI355_QKV_STORE=1): bit-identical caches, but measured slower than the two launches it replaces (DESIGN.md
+        section 4.4: 162 vs 147 us per layer at 16 x 1024 tokens) - with one wave per SIMD the epilogue's dependent
+        table loads have nothing to hide behind."""
+        ctx, proj = get_context(), self.qkv_proj
+        return (self.fused and ctx.is_prefill and self.attn.k_cache.numel() > 0 and self.attn.fusable and x.is_cuda
+                and x.dim() == 2 and ctx.slot_mapping is not None and ctx.slot_mapping.dim() == 1
+                and not isinstance(getattr(proj, "weight_packed", None), ops.Fp8Weight)
+                and proj.weight.dtype == torch.bfloat16 and proj.weight.shape[1] % 64 == 0
+                and ops.qkv_store_takes(x.shape[0], proj.weight.shape[0], self.head_dim, ctx.block_size)
+                and os.environ.get("MI355_PREFILL_FUSED_Q", "1") != "0" and os.environ.get("MI355_QKV_STORE", "0") == "1")
+
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
+        if self._kv_store_in_projection(hidden_states):
+            return self.o_proj(self._attend_fused(positions, None, hidden_states).flatten(1, -1))
         qkv = self.qkv_proj(hidden_states)
         if self.fused and self.attn.k_cache.numel() > 0 and self.attn.fusable:
             o = self._attend_fused(positions, qkv)
@@ -100,20 +116,27 @@ class Qwen3Attention(nn.Module):
         q, k = self.rotary_emb(positions, q, k)
         return self.attn(q, k, v)
 
-    def _attend_fused(self, positions: torch.Tensor, qkv: torch.Tensor) -> torch.Tensor:
+    def _attend_fused(self, positions: torch.Tensor, qkv: torch.Tensor | None, x: torch.Tensor | None = None) -> torch.Tensor:
+        """qkv None (with the layer's input x, see _kv_store_in_projection): the projection itself stores K / V."""
         ctx, attn = get_context(), self.attn
         attn.block_size = ctx.block_size
         rope = self.rotary_emb
-        if rope.cos_sin_cache.device != qkv.device:
-            rope.cos_sin_cache = rope.cos_sin_cache.to(qkv.device)
+        dev = x.device if qkv is None else qkv.device
+        if rope.cos_sin_cache.device != dev:
+            rope.cos_sin_cache = rope.cos_sin_cache.to(dev)
         qw = self.q_norm.weight if self.qk_norm else None
         kw = self.k_norm.weight if self.qk_norm else None
-        if ctx.is_prefill and qkv.shape[0] >= 64 and os.environ.get("MI355_PREFILL_FUSED_Q", "1") != "0":
+        if qkv is None or (ctx.is_prefill and qkv.shape[0] >= 64 and os.environ.get("MI355_PREFILL_FUSED_Q", "1") != "0"):
             # prefill-sized: K / V go to the cache (whole tiles), the queries are normed and rotated inside the
             # attention kernel's Q-operand load - q is never written to and read back from HBM
-            ops.qknorm_rope_store(qkv, qw, kw, self.rms_norm_eps, positions, rope.cos_sin_cache, attn.k_cache,
-                                  attn.v_cache, ctx.slot_mapping, self.num_heads, self.num_kv_heads,
-                                  ctx.block_size, store_q=False)
+            if qkv is None:  # ... from the projection's epilogue: the k / v columns of the qkv rows are never written
+                qkv = ops.gemm_qkv_store(x, self.qkv_proj.weight, self.qkv_proj.bias, kw, self.rms_norm_eps, positions,
+                                         rope.cos_sin_cache, attn.k_cache, attn.v_cache, ctx.slot_mapping,
+                                         self.num_heads, self.num_kv_heads, ctx.block_size)
+            else:
+                ops.qknorm_rope_store(qkv, qw, kw, self.rms_norm_eps, positions, rope.cos_sin_cache, attn.k_cache,
+                                      attn.v_cache, ctx.slot_mapping, self.num_heads, self.num_kv_heads,
+                                      ctx.block_size, store_q=False)
             kv_lens = ctx.kv_lens
             if kv_lens is None:
                 kv_lens = (ctx.cu_seqlens_k[1:] - ctx.cu_seqlens_k[:-1]).contiguous()

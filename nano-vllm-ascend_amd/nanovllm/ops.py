@@ -467,6 +467,34 @@ def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | 
     return out
 
 
+def qkv_store_takes(rows: int, n_features: int, head_dim: int, block_size: int) -> bool:
+    """Shapes mi_gemm_bf16_qkv_store accepts: the large-M tile kernel (at least 256 tiles of 256 x 256), head_dim 128,
+    whole feature tiles, block sizes in whole cache tiles."""
+    tiles = -(-rows // 256) * -(-n_features // 256)
+    return head_dim == HEAD_DIM and n_features % 256 == 0 and block_size % 16 == 0 and tiles >= 256
+
+
+def gemm_qkv_store(x, w, bias, k_w, eps: float, positions, cos_sin, k_cache, v_cache, slots, n_q_heads: int,
+                   n_kv_heads: int, block_size: int, out=None) -> torch.Tensor:
+    """The packed qkv projection of a prefill step with k-norm + RoPE + the K / V cache store in the GEMM's epilogue
+    (mi_gemm_bf16_qkv_store): returns the [M][N] qkv rows of which ONLY the q columns are written."""
+    require_gpu(x, w, bias, positions, cos_sin, k_cache, v_cache, slots)
+    _bf16(x, w, bias, k_cache, v_cache)
+    assert w.dim() == 2 and w.is_contiguous() and x.stride(-1) == 1
+    K, N = x.shape[-1], w.shape[0]
+    if x.dim() != 2 or x.stride(0) % 8:
+        x = x.reshape(-1, K).contiguous()
+    M = x.shape[0]
+    assert N == (n_q_heads + 2 * n_kv_heads) * HEAD_DIM and positions.dtype == torch.int64 and positions.is_contiguous()
+    assert slots.dtype == torch.int32 and slots.dim() == 1 and slots.is_contiguous() and slots.numel() == M
+    if out is None:
+        out = torch.empty((M, N), dtype=_BF16, device=x.device)
+    check(lib.mi_gemm_bf16_qkv_store(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(out), out.stride(0), M, N, K, ptr(k_w),
+                                     float(eps), ptr(positions), ptr(cos_sin), ptr(k_cache), ptr(v_cache), ptr(slots),
+                                     n_q_heads, n_kv_heads, HEAD_DIM, block_size, stream()), "mi_gemm_bf16_qkv_store")
+    return out
+
+
 _GEMM_WS: dict[tuple, torch.Tensor] = {}
 _GEMM_WS_RETIRED: list[torch.Tensor] = []
 

@@ -69,6 +69,19 @@ def test_bench_workload_bs32_paging_invariance_and_decode_equals_reprefill():
         assert a_tables != b_tables and a_tokens == b_tokens
         for x, y in zip(a_logits, b_logits):
             assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+        # the opt-in qkv projection that stores K / V from its epilogue (mi_gemm_bf16_qkv_store) leaves the same bits in
+        # the caches: the same logits in every step, prefill and decode
+        import os
+
+        os.environ["MI355_QKV_STORE"] = "1"
+        try:
+            llm.scheduler.block_manager.hash_to_block_id.clear()
+            q_logits, _, q_tokens, _ = run(llm, prompts)
+        finally:
+            del os.environ["MI355_QKV_STORE"]
+        assert q_tokens == a_tokens
+        for x, y in zip(a_logits, q_logits):
+            assert torch.equal(x.view(torch.int16), y.view(torch.int16))
         # decode == re-prefill for two of the 32 sequences, every decode step
         first_decode = len(a_logits) - 4
         worst = 0.0
