@@ -26,6 +26,40 @@ from nanovllm.engine.sequence import Sequence
 _NO_HASH = -1
 
 
+class _Tokens:
+    """The token ids of a sealed block as a VIEW of its sequence's token list (full blocks are never modified once
+    sealed): allocate() seals 64 blocks per 1024-token prompt, and slicing touches every one of the 16 int objects of a
+    block (reference counts: memory writes to cold objects) for a list that is read only if the block's hash is ever
+    hit.  Compares, iterates and indexes like the list it stands for."""
+    __slots__ = ("src", "lo", "n")
+
+    def __init__(self, src: list[int], lo: int, n: int):
+        self.src, self.lo, self.n = src, lo, n
+
+    def list(self) -> list[int]:
+        return self.src[self.lo:self.lo + self.n]
+
+    def __eq__(self, other):
+        return self.list() == (other.list() if isinstance(other, _Tokens) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        return iter(self.list())
+
+    def __getitem__(self, i):
+        return self.list()[i]
+
+    def __repr__(self):
+        return repr(self.list())
+
+    __hash__ = None
+
+
 class Block:
     __slots__ = ("block_id", "ref_count", "hash", "token_ids")
 
@@ -119,7 +153,7 @@ class BlockManager:
         for bid, chain, lo in zip(ids, chains, range(hits * bs, n_full * bs, bs)):
             blk = blocks[bid]
             assert blk.ref_count == 0
-            blk.ref_count, blk.hash, blk.token_ids = 1, chain, tokens[lo:lo + bs]
+            blk.ref_count, blk.hash, blk.token_ids = 1, chain, _Tokens(tokens, lo, bs)
         lookup.update(zip(chains, ids))  # in block order: a later duplicate hash replaces an earlier one, as assigning one by one
         for bid in ids[n_sealed:]:  # the open tail block, if any
             blk = blocks[bid]

@@ -434,7 +434,7 @@ def test_tp_decode_picks_tokens_in_the_graph(monkeypatch):
     assert same >= 0.8 * 60, (same, one, two)
 
 
-@pytest.mark.parametrize("prompt_len", [128, 1040])
+@pytest.mark.parametrize("prompt_len", [128, pytest.param(1040, marks=pytest.mark.gpu_slow)])  # (configs[0] as written: 128)
 def test_config0_bs1_128_token_prompt_greedy_full_qwen3_0p6b(prompt_len):
     """BASELINE.json configs[0]: Qwen3-0.6B (full shape, synthetic weights), bs=1, 128-token prompt,
     greedy.  The engine (hipGraph decode) against the CPU oracle on the same weights and tokens:
