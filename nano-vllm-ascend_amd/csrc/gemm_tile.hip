@@ -466,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(const TileArgs a) {
 }
 
 #include "gemm_w4_kernel.hpp"
+#include "gemm_w16_kernel.hpp"
 
 // ---------------------------------------------------------------------------
 // The same GEMM on 128 x 128 tiles, for shapes whose 256 x 256 tiles cannot fill the chip (64 < M <= ~2048 rows:
@@ -656,25 +657,29 @@ static int tile_ksplit(int M, int N, int K) {
   return ks;
 }
 
-// V & kEightWaves: the eight-wave ping-pong kernel of rounds 2-3 (tuning / comparison only); otherwise the
-// four-wave kernel (gemm_w4_kernel.hpp), with whole-line output stores (kLineStores) wherever the output allows it:
-// full feature tiles, 16-byte aligned rows, 32-bit byte offsets.  V & kDirectStores keeps the direct form (tuning).
-constexpr int kEightWaves = 1 << 20, kLineStores = 32768, kDirectStores = 1 << 18;
+// The large-M kernel: gemm_w16_kernel (four waves, v_mfma_f32_16x16x32_bf16), with whole-line output stores
+// (kLineStores) wherever the output allows it: full feature tiles, 16-byte aligned rows, 32-bit byte offsets.
+// Tuning / comparison variants: V & kDirectStores keeps the direct stores; V & kMfma32 = the same kernel on
+// v_mfma_f32_32x32x16_bf16 (gemm_w4_kernel: the first form of round 4, still the qkv-store kernel); V & kEightWaves = the
+// eight-wave ping-pong kernel of rounds 2-3.
+constexpr int kEightWaves = 1 << 20, kMfma32 = 1 << 19, kLineStores = 32768, kDirectStores = 1 << 18;
 template <int EPI, bool BIAS, int V = kDefaultV>
 static int launch_tile(const TileArgs& a, hipStream_t st, int ksplit = 1) {
   // persistent workgroups: one per CU; the grid is a multiple of 8, so a workgroup stays in one XCD class
   const int ntiles = a.tiles_f * a.tiles_t;
   const bool persistent = !(V & 16) && ntiles > kPersistentGrid;
   const dim3 grid(persistent ? kPersistentGrid : ntiles, ksplit);
+  constexpr int VK = V & ~(kDirectStores | kMfma32 | kEightWaves);  // the kernel's own flags
+  const bool lines = EPI != TEPI_PARTIAL && !(V & (kDirectStores | 8 | 512)) && a.N % TILE_F == 0 && a.ldy % 8 == 0 &&
+                     (int64_t)a.M * a.ldy * 2 < ((int64_t)1 << 32) && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
   if constexpr ((V & kEightWaves) != 0) {
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, V & ~kEightWaves>), grid, dim3(512), 0, st, a);
-  } else if constexpr (EPI == TEPI_PARTIAL || (V & (kDirectStores | 8 | 512)) != 0) {
-    hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V & ~kDirectStores>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BIAS, VK>), grid, dim3(512), 0, st, a);
+  } else if constexpr ((V & kMfma32) != 0) {
+    if (lines) hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, VK | kLineStores>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, VK>), grid, dim3(256), 0, st, a);
   } else {
-    const bool lines = a.N % TILE_F == 0 && a.ldy % 8 == 0 && (int64_t)a.M * a.ldy * 2 < ((int64_t)1 << 32) &&
-                       (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
-    if (lines) hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V | kLineStores>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_w4_kernel<EPI, BIAS, V>), grid, dim3(256), 0, st, a);
+    if (lines) hipLaunchKernelGGL((gemm_w16_kernel<EPI, BIAS, VK | kLineStores>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_w16_kernel<EPI, BIAS, VK>), grid, dim3(256), 0, st, a);
   }
   return check_launch();
 }
@@ -795,6 +800,7 @@ extern "C" int mi_gemm_bf16_qkv_store(const mi_bf16* x, int64_t ldx, const mi_bf
              {k_w, positions, cos_sin, k_cache, v_cache, slots, eps, n_q_heads, n_kv_heads, block_size}};
   const int ntiles = a.tiles_f * a.tiles_t;
   const dim3 grid(ntiles > kPersistentGrid ? kPersistentGrid : ntiles);
+  // (the 32 x 32 x 16 form of the kernel: the K-head arithmetic is written for its accumulator layout)
   if (bias) hipLaunchKernelGGL((gemm_w4_kernel<TEPI_QKV, true, kLineStores>), grid, dim3(256), 0, S(stream), a);
   else hipLaunchKernelGGL((gemm_w4_kernel<TEPI_QKV, false, kLineStores>), grid, dim3(256), 0, S(stream), a);
   return check_launch();
@@ -808,34 +814,27 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
   const TileArgs a{x, w, nullptr, y, ldx, ldy, M, N, K, (N + TILE_F - 1) / TILE_F, (M + TILE_T - 1) / TILE_T, nullptr};
   hipStream_t st = S(stream);
   switch (variant) {
-    // the four-wave product kernel and its variants
+    // the product kernel (four waves, 16 x 16 x 32 MFMAs) and its variants
     case 0: return launch_tile<TEPI_NONE, false, 0>(a, st);
     case 4: return launch_tile<TEPI_NONE, false, 4>(a, st);
     case 8: return launch_tile<TEPI_NONE, false, 8>(a, st);
     case 16: return launch_tile<TEPI_NONE, false, 16>(a, st);
-    case 20: return launch_tile<TEPI_NONE, false, 20>(a, st);
     case 32: return launch_tile<TEPI_NONE, false, 32>(a, st);
     case 64: return launch_tile<TEPI_NONE, false, 64>(a, st);
     case 96: return launch_tile<TEPI_NONE, false, 96>(a, st);
     case 224: return launch_tile<TEPI_NONE, false, 224>(a, st);
-    case 256: return launch_tile<TEPI_NONE, false, 256>(a, st);
     case 512: return launch_tile<TEPI_NONE, false, 512>(a, st);
-    case 768: return launch_tile<TEPI_NONE, false, 768>(a, st);
-    case 1024: return launch_tile<TEPI_NONE, false, 1024>(a, st);
-    case 1536: return launch_tile<TEPI_NONE, false, 1536>(a, st);
-    case 2048: return launch_tile<TEPI_NONE, false, 2048>(a, st);
-    case 2560: return launch_tile<TEPI_NONE, false, 2560>(a, st);
     case kDirectStores: return launch_tile<TEPI_NONE, false, kDirectStores>(a, st);
+    // the same kernel on 32 x 32 x 16 MFMAs
+    case kMfma32: return launch_tile<TEPI_NONE, false, kMfma32>(a, st);
+    case kMfma32 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 512>(a, st);
+    case kMfma32 + kDirectStores: return launch_tile<TEPI_NONE, false, kMfma32 + kDirectStores>(a, st);
+    case kMfma32 + 4096 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 4096 + 512>(a, st);
     // the eight-wave kernel of rounds 2-3 and its variants
     case kEightWaves: return launch_tile<TEPI_NONE, false, kEightWaves>(a, st);
     case kEightWaves + 2: return launch_tile<TEPI_NONE, false, kEightWaves + 2>(a, st);
-    case kEightWaves + 4: return launch_tile<TEPI_NONE, false, kEightWaves + 4>(a, st);
-    case kEightWaves + 8: return launch_tile<TEPI_NONE, false, kEightWaves + 8>(a, st);
     case kEightWaves + 16: return launch_tile<TEPI_NONE, false, kEightWaves + 16>(a, st);
-    case kEightWaves + 512: return launch_tile<TEPI_NONE, false, kEightWaves + 512>(a, st);
-    case kEightWaves + 1024: return launch_tile<TEPI_NONE, false, kEightWaves + 1024>(a, st);
     case kEightWaves + 8192: return launch_tile<TEPI_NONE, false, kEightWaves + 8192>(a, st);
-    case kEightWaves + 9216: return launch_tile<TEPI_NONE, false, kEightWaves + 9216>(a, st);
     case 65536: return launch_mid<TEPI_NONE, false, 4>(a, st);  // the 128-tile kernel, no K slices, four-stage ring
     case 65538: return launch_mid<TEPI_NONE, false, 2>(a, st);  // ... with a two-stage ring, two workgroups per CU
     case 65539: return launch_mid<TEPI_NONE, false, 3>(a, st);

@@ -133,5 +133,41 @@ MI_HD constexpr int w4_frag_imm(int i, int kk) { return (i & 1) * 8 * W4_PIECE_B
 MI_HD constexpr int w4_acc_feature(int fw, int i, int r, int hi) { return fw * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 MI_HD constexpr int w4_acc_token(int tw, int j, int l31) { return tw * 128 + j * 32 + l31; }
 
+// ---- the same four-wave kernel on v_mfma_f32_16x16x32_bf16 (gemm_w16_kernel: the product kernel; the 32 x 32 form above
+// remains for the qkv-store epilogue) ----
+// Wave tile 128 x 128 = 8 x 8 accumulators of 16 x 16; a K step is two k halves of 32.  A fragment read: lane
+// (r16 = lane & 15, q = lane >> 4) reads row r16 of a 16-row fragment, 16-byte chunk 4 * khalf + q.  A ds_read_b128 lane
+// group then holds 8 rows at chunk c and the OTHER 8 rows at chunk c + 1 ({0-3, 12-15} vs {4-11}), so the image is
+// padded by 32 bytes per 1 KiB piece - a piece shifts the 16-byte bank slots by TWO - and row (b2 b1 b0 x3 x2 x1 x0)
+// of a 128-row half lives in piece (b0 x3 x1 x0), slice (b2 b1 x3^x2): slot = 8 x2 + 4 x1 + 2 x0 + chunk (mod 16), even
+// for the rows read at chunk c, odd for those read at c + 1.  The row of (piece, slice) is
+// w16_piece_rows(q) + w16_slice_rows(s, x3 of the piece): additive but for the one bit x2 = (s & 1) ^ x3.
+constexpr int W16_PIECE_BYTES = 1024 + 32;
+constexpr int W16_STEP_BYTES = 64 * W16_PIECE_BYTES;  // 67 584
+MI_HD constexpr int w16_piece_of_row(int r7) { return 8 * ((r7 >> 4) & 1) + 4 * ((r7 >> 3) & 1) + (r7 & 3); }
+MI_HD constexpr int w16_slice_of_row(int r7) { return (((r7 >> 3) ^ (r7 >> 2)) & 1) + 2 * ((r7 >> 5) & 1) + 4 * ((r7 >> 6) & 1); }
+MI_HD constexpr int w16_piece_x3(int q) { return (q >> 2) & 1; }
+MI_HD constexpr int w16_piece_rows(int q) { return 16 * ((q >> 3) & 1) + 8 * ((q >> 2) & 1) + (q & 3); }
+MI_HD constexpr int w16_slice_rows(int s, int x3) { return 4 * ((s & 1) ^ x3) + 32 * ((s >> 1) & 1) + 64 * ((s >> 2) & 1); }
+MI_HD constexpr int w16_row_off(int region, int r, int c) {
+  return (region * 32 + (r >> 7) * 16 + w16_piece_of_row(r & 127)) * W16_PIECE_BYTES + w16_slice_of_row(r & 127) * 128 + c * 16;
+}
+MI_HD constexpr int w16_dma_row(int wave, int q, int lane) {
+  return (wave & 1) * 128 + w16_piece_rows(q) + w16_slice_rows(lane >> 3, w16_piece_x3(q));
+}
+MI_HD constexpr int w16_piece_off(int wave, int q) { return (wave * 16 + q) * W16_PIECE_BYTES; }
+// fragment f (0..7) of wave half fw / tw, k half kh: the kernel's address form = region + half + per-lane + immediate
+MI_HD constexpr int w16_frag_row(int half, int f, int r16) { return half * 128 + f * 16 + r16; }
+MI_HD constexpr int w16_frag_chunk(int kh, int q) { return 4 * kh + q; }
+MI_HD constexpr int w16_frag_lane(int r16, int q) {
+  return (4 * ((r16 >> 3) & 1) + (r16 & 3)) * W16_PIECE_BYTES + (((r16 >> 3) ^ (r16 >> 2)) & 1) * 128 + q * 16;
+}
+MI_HD constexpr int w16_frag_imm(int f, int kh) { return (f & 1) * 8 * W16_PIECE_BYTES + ((f >> 1) & 1) * 256 + (f >> 2) * 512 + kh * 64; }
+// SwiGLU: rows 0..63 of a wave's half are gate rows, 64..127 the up rows that pair with them (fragments f and f + 4)
+MI_HD constexpr int w16_weight_row(int r, int n0, int N, bool silu) { return w4_weight_row(r, n0, N, silu); }
+// accumulator acc[f][t], register e (0..3) of lane (n = lane & 15, q = lane >> 4): feature 16 f + 4 q + e, token 16 t + n
+MI_HD constexpr int w16_acc_feature(int fw, int f, int e, int q) { return fw * 128 + f * 16 + 4 * q + e; }
+MI_HD constexpr int w16_acc_token(int tw, int t, int n) { return tw * 128 + t * 16 + n; }
+
 }  // namespace gt
 }  // namespace mi

@@ -506,6 +506,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     }
   };
   read_first_groups();
+  // V & 4096 (measurement, tools/gemm_clock.py): shader cycles and 100 MHz reference ticks of the whole tile loop of
+  // every workgroup, written over the first output bytes when everything else is done
+  unsigned long long clk0 = 0, ref0 = 0;
+  if (V & 4096) {
+    clk0 = __builtin_readcyclecounter();
+    ref0 = __builtin_amdgcn_s_memrealtime();
+  }
 
   for (int blk = (int)blockIdx.x; blk < ntiles; blk += stride) {
     const int tid = tile_of_block(blk, a.tiles_t, a.tiles_f, (V & 4) != 0);
@@ -531,5 +538,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     else epilogue(m0, n0);
     __builtin_amdgcn_sched_barrier(0);
     if (kRereadAfterEpilogue && blk + stride < ntiles) read_first_groups();
+  }
+  if (V & 4096) {
+    const unsigned long long clk1 = __builtin_readcyclecounter(), ref1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      float* o = reinterpret_cast<float*>(a.y) + 2 * blockIdx.x;
+      o[0] = (float)(clk1 - clk0);
+      o[1] = (float)(ref1 - ref0);
+    }
   }
 }

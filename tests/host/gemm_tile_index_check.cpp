@@ -7,6 +7,7 @@
 //      semantics -> accumulator layout -> output columns, plain and SwiGLU row pairing) equals x @ w^T
 //   5. the same for the 128 x 128 kernel (gemm_mid_kernel)
 //   6. the same for the four-wave 256 x 256 kernel (gemm_w4_kernel)
+//   7. the 16 x 16 x 32 form of that kernel (gemm_w16_kernel)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -342,6 +343,63 @@ int main() {
             }
       }
     }
+  }
+  // ---- 7: the 16 x 16 x 32 form of the four-wave kernel (gemm_w16_kernel): image, fragment reads, bank slots, pairing ----
+  {
+    std::vector<Cell> wimg(W16_STEP_BYTES / 16);
+    std::vector<int> region_of(W16_STEP_BYTES / 16, -1);
+    for (int wave = 0; wave < 4; ++wave)
+      for (int q = 0; q < W4_PIECES; ++q)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int region = w4_wave_is_weight(wave) ? 0 : 1;
+          const int byte = w16_piece_off(wave, q) + lane * 16;
+          const int r = w16_dma_row(wave, q, lane), c = lane & 7;
+          CHECK(byte == w16_row_off(region, r, c), "w16 DMA wave %d piece %d lane %d lands at %d, layout says %d", wave, q, lane, byte, w16_row_off(region, r, c));
+          Cell& cell = wimg[byte / 16];
+          cell.row = r;
+          cell.chunk = c;
+          cell.writers++;
+          region_of[byte / 16] = region;
+        }
+    for (int h = 0; h < 2; ++h) {
+      std::vector<int> seen(256 * 8, 0);
+      for (size_t k = 0; k < wimg.size(); ++k) {
+        const bool pad = (k * 16) % W16_PIECE_BYTES >= 1024;
+        CHECK(wimg[k].writers == (pad ? 0 : 1), "w16 image cell %zu: %d writers", k, wimg[k].writers);
+        if (!pad && region_of[k] == h) seen[wimg[k].row * 8 + wimg[k].chunk]++;
+      }
+      for (int v : seen) CHECK(v == 1, "w16 region %d: a (row, chunk) is held %d times", h, v);
+    }
+    for (int wave = 0; wave < 4; ++wave) {
+      const int fw = wave >> 1, tw = wave & 1;
+      for (int kh = 0; kh < 2; ++kh)
+        for (int op = 0; op < 2; ++op)
+          for (int f = 0; f < 8; ++f) {
+            int addr[64];
+            for (int lane = 0; lane < 64; ++lane) {
+              const int r16 = lane & 15, q = lane >> 4;
+              addr[lane] = (op * 32 + (op ? tw : fw) * 16) * W16_PIECE_BYTES + w16_frag_lane(r16, q) + w16_frag_imm(f, kh);
+              const int r = w16_frag_row(op ? tw : fw, f, r16), c = w16_frag_chunk(kh, q);
+              CHECK(addr[lane] == w16_row_off(op, r, c), "w16 fragment address form: %d vs %d", addr[lane], w16_row_off(op, r, c));
+              const Cell& cell = wimg[addr[lane] / 16];
+              CHECK(region_of[addr[lane] / 16] == op && cell.row == r && cell.chunk == c, "w16 fragment lane %d: row %d chunk %d", lane, cell.row, cell.chunk);
+            }
+            for (const auto& g : groups) {
+              int used[16] = {0};
+              for (int l : g) used[(addr[l] / 16) % 16]++;
+              for (int sl = 0; sl < 16; ++sl) CHECK(used[sl] <= 1, "w16: bank slot %d used %d times in one lane group", sl, used[sl]);
+            }
+          }
+    }
+    // SwiGLU pairing: accumulator fragments f (gate) and f + 4 (up) of a wave hold the same output column
+    for (int fw = 0; fw < 2; ++fw)
+      for (int f = 0; f < 4; ++f)
+        for (int q = 0; q < 4; ++q)
+          for (int e = 0; e < 4; ++e) {
+            const int N = 1024, n0 = 512;
+            const int g = w16_weight_row(w16_acc_feature(fw, f, e, q), n0, N, true), u = w16_weight_row(w16_acc_feature(fw, f + 4, e, q), n0, N, true);
+            CHECK(u == g + N / 2 && g == (n0 >> 1) + fw * 64 + f * 16 + 4 * q + e, "w16 silu pairing: gate row %d up row %d", g, u);
+          }
   }
   if (fails) { std::printf("%d check(s) failed\n", fails); return 1; }
   std::printf("gemm_tile index replay: ok\n");

@@ -129,7 +129,8 @@ def test_gemm_tile_full_prefill_shape_and_variants(ops):
     assert_bf16_close(y[:2048], want, max_frac=2e-2, atol=K * 2.0 ** -22)
     assert_bf16_close(y[-300:], oracle.linear(x[-300:], w), max_frac=2e-2, atol=K * 2.0 ** -22)
     E8 = 1 << 20  # the eight-wave kernel of rounds 2-3 (kept as a tuning variant) and its schedule flags
-    for variant in (8, 16, 1 << 18, E8, E8 + 2, E8 + 16, E8 + 8192):  # (1 << 18: direct instead of whole-line stores)
+    for variant in (8, 16, 1 << 18, 1 << 19, (1 << 19) + (1 << 18), E8, E8 + 2, E8 + 16, E8 + 8192):  # (1 << 18: direct instead of
+        # whole-line stores; 1 << 19: the kernel's 32 x 32 x 16 form)
         yv = ops.gemm_tile(xd, wd, variant=variant)
         assert torch.equal(yv.view(torch.int16), y.view(torch.int16)), variant
     side = torch.cuda.Stream()

@@ -401,6 +401,116 @@ __global__ __launch_bounds__(256, 1) void mfma_shape_kernel(const char* __restri
   if (s == 12345.678f) sink[threadIdx.x] = s;
 }
 
+// (a kernel of its own: sharing a function with the 32 x 32 branch left the 64 accumulators shuffled through
+// v_accvgpr_mov every iteration)
+__global__ __launch_bounds__(256, 1) void mfma16_kernel(const char* __restrict__ src, float* __restrict__ sink, int ksteps) {
+  const int lane = threadIdx.x & 63;
+  u32x4 A[8], B[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    A[i] = *reinterpret_cast<const u32x4*>(src + (size_t)(i * 64 + lane) * 16 + (size_t)(blockIdx.x & 255) * 65536);
+    B[i] = *reinterpret_cast<const u32x4*>(src + (size_t)((8 + i) * 64 + lane) * 16 + (size_t)(blockIdx.x & 255) * 65536);
+  }
+  f32x4 acc[64];
+#pragma unroll
+  for (int m = 0; m < 64; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int t = 0; t < ksteps; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 64; ++m)
+        // (in place by inline assembly: with the builtin hipcc gives the result a different register quad than the
+        // addend and copies 64 quads around at the loop's back edge)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(A[((m >> 3) + ks) & 7]), "v"(B[((m & 7) + 3 * ks) & 7]));
+  }
+  const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { sink[1024 + 2 * blockIdx.x] = (float)(c1 - c0); sink[1025 + 2 * blockIdx.x] = (float)(r1 - r0); }
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 64; ++m) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+// pipe3: the pipe2 loop on v_mfma_f32_16x16x32_bf16 (the vendor kernel's shape; 4.6 % more clock than 32x32x16 under the
+// power limit, see below): a K step is two k halves of 64 MFMAs (8 x 8 accumulators of 16 x 16), fragments of the next
+// half are read during the current one (two register sets of 16 fragments), one wait + barrier per K step behind the
+// first half, the sixteen pieces one behind every fourth MFMA of the second half.  MFMAs in place by inline assembly.
+template <int FEED>
+__global__ __launch_bounds__(256, 1) void pipe3_kernel(const char* __restrict__ src, float* __restrict__ sink, int ksteps) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * KSTEP_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr bool GEMM_LIKE = FEED >= 4;
+  const char* stream = GEMM_LIKE ? src : src + (size_t)(blockIdx.x & 7) * ((size_t)ksteps * KSTEP_BYTES);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, GEMM_LIKE ? (40 << 20) : ksteps * KSTEP_BYTES, 0x00020000);
+  const int voff = GEMM_LIKE ? (lane >> 3) * 2048 + (lane & 7) * 16 : wave * 16384 + lane * 16;
+  f32x4 acc[64];
+#pragma unroll
+  for (int m = 0; m < 64; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // conflict-free stand-in addresses: fragment f of half h of operand o at o * 32 KiB + (wave half) * 16 KiB + h * 8 KiB + f * 1 KiB + 16 * lane
+  int offa = (wave >> 1) * 16384 + lane * 16, offb = 32768 + (wave & 1) * 16384 + lane * 16;
+  u32x4 Ra[2][8], Rb[2][8];
+  auto dma = [&](int t, int i, int buf) __attribute__((always_inline)) {
+    auto dst = (__attribute__((address_space(3))) void*)(lds + buf * KSTEP_BYTES + wave * 16384 + i * 1024);
+    if (FEED >= 4) {
+      const int tile = wave < 2 ? (int)(blockIdx.x & 15) : (((int)blockIdx.x >> 4) + 16 * (t >> 4)) & 63;
+      const uint32_t rows = (wave < 2 ? (32u << 20) : 0u) + (uint32_t)(tile * 256 + (wave & 1) * 128 + i * 8) * 2048u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff + rows, (t & 15) * 128, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff + (uint32_t)(i * 1024 + (ksteps & 0)), t * KSTEP_BYTES, 0, 0);
+    }
+  };
+  auto read1 = [&](int h, int q) __attribute__((always_inline)) {  // q-th of the sixteen fragment reads of k half h
+    if (q < 8) Ra[h][q] = *reinterpret_cast<const u32x4*>(lds + h * 8192 + q * 1024 + offa);
+    else Rb[h][q - 8] = *reinterpret_cast<const u32x4*>(lds + h * 8192 + (q - 8) * 1024 + offb);
+  };
+  auto mma1 = [&](int h, int m) __attribute__((always_inline)) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(Ra[h][m >> 3]), "v"(Rb[h][m & 7]));
+  };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(0, i, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(1, i, 1);
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 16; ++q) read1(0, q);
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int t = 0; t < ksteps; ++t) {
+    const int p = t & 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {  // first half: MFMAs of k half 0, reads of k half 1 of the same image
+      mma1(0, 4 * q);
+      mma1(0, 4 * q + 1);
+      read1(1, q);
+      mma1(0, 4 * q + 2);
+      mma1(0, 4 * q + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    offa ^= KSTEP_BYTES;
+    offb ^= KSTEP_BYTES;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {  // second half: k half 1; reads of k half 0 of the NEXT step; the pieces of step t + 2
+      mma1(1, 4 * q);
+      mma1(1, 4 * q + 1);
+      read1(0, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(1, 4 * q + 2);
+      mma1(1, 4 * q + 3);
+      if (FEED) dma(t + 2, q, p);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { sink[1024 + 2 * blockIdx.x] = (float)(c1 - c0); sink[1025 + 2 * blockIdx.x] = (float)(r1 - r0); }
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 64; ++m) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
 static double g_cycles_per_step, g_mhz;
 typedef void (*pipe_fn)(const char*, float*, int);
 static double run_fn(pipe_fn fn, const char* src, float* sink, int ksteps);
@@ -468,6 +578,13 @@ int main() {
   t = run_fn(pipe2_kernel<6>, src, sink, ksteps); printf("  ... loads sc1                               %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
   printf("MFMA shape under the power limit (MFMAs only, random operands)\n");
   t = run_fn(mfma_shape_kernel<32>, src, sink, ksteps); printf("  64 x v_mfma_f32_32x32x16_bf16 per K step    %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
-  t = run_fn(mfma_shape_kernel<16>, src, sink, ksteps); printf("  128 x v_mfma_f32_16x16x32_bf16 per K step   %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(mfma16_kernel, src, sink, ksteps); printf("  128 x v_mfma_f32_16x16x32_bf16 per K step   %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  printf("the two-groups-ahead loop on 128 x v_mfma_f32_16x16x32_bf16 per K step (in-place inline assembly), next to its 32 x 32 x 16 twin\n");
+  t = run_fn(pipe2_kernel<0>, src, sink, ksteps); printf("  32x32x16: reads only                        %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe3_kernel<0>, src, sink, ksteps); printf("  16x16x32: reads only                        %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<3>, src, sink, ksteps); printf("  32x32x16: + 16 pieces                       %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe3_kernel<1>, src, sink, ksteps); printf("  16x16x32: + 16 pieces                       %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe2_kernel<4>, src, sink, ksteps); printf("  32x32x16: the qkv GEMM's fetch pattern      %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
+  t = run_fn(pipe3_kernel<4>, src, sink, ksteps); printf("  16x16x32: the qkv GEMM's fetch pattern      %8.1f  %6.3f  %7.0f   %6.0f cyc  %5.0f MHz\n", t, t / ksteps, flop / t / 1e6, g_cycles_per_step, g_mhz);
   return 0;
 }
