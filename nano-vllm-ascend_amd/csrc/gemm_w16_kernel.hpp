@@ -281,9 +281,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w16_kernel(const TileArgs a) {
     kstep(std::true_type{});
     for (int kt = 1; kt < KT; ++kt) kstep(std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
-    // the matrix pipe's results are a software-managed hazard for what reads the accumulators next (the compiler
-    // cannot see inline-assembly MFMAs): 16 passes of margin
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // The matrix pipe's results are a software-managed hazard for what reads the accumulators next, and the compiler
+    // cannot see inline-assembly MFMAs: 32 cycles of margin, inside an asm statement that "modifies" accumulators -
+    // every read of an accumulator the compiler generates for the epilogue (v_accvgpr_read copies are placed by the
+    // register allocator, which no scheduling barrier constrains) depends on one of these three statements, and the
+    // two empty ones follow the fence in program order.  (An asm statement takes at most 30 operands.)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[1][4]), "+a"(acc[1][5]), "+a"(acc[1][6]), "+a"(acc[1][7]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]));
+    asm volatile("" : "+a"(acc[2][6]), "+a"(acc[2][7]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]), "+a"(acc[3][4]), "+a"(acc[3][5]), "+a"(acc[3][6]), "+a"(acc[3][7]), "+a"(acc[4][0]), "+a"(acc[4][1]), "+a"(acc[4][2]), "+a"(acc[4][3]), "+a"(acc[4][4]), "+a"(acc[4][5]), "+a"(acc[4][6]), "+a"(acc[4][7]), "+a"(acc[5][0]), "+a"(acc[5][1]), "+a"(acc[5][2]));
+    asm volatile("" : "+a"(acc[5][3]), "+a"(acc[5][4]), "+a"(acc[5][5]), "+a"(acc[5][6]), "+a"(acc[5][7]), "+a"(acc[6][0]), "+a"(acc[6][1]), "+a"(acc[6][2]), "+a"(acc[6][3]), "+a"(acc[6][4]), "+a"(acc[6][5]), "+a"(acc[6][6]), "+a"(acc[6][7]), "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]), "+a"(acc[7][6]), "+a"(acc[7][7]));
     // A workgroup's last tile: its (empty) past-the-end pieces must not outlive the workgroup's LDS
     if (blk + stride >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (LINES) epilogue_lines(m0, n0);
