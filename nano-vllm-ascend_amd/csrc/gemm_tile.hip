@@ -824,6 +824,7 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
     case 96: return launch_tile<TEPI_NONE, false, 96>(a, st);
     case 224: return launch_tile<TEPI_NONE, false, 224>(a, st);
     case 512: return launch_tile<TEPI_NONE, false, 512>(a, st);
+    case 4096 + 512: return launch_tile<TEPI_NONE, false, 4096 + 512>(a, st);
     case kDirectStores: return launch_tile<TEPI_NONE, false, kDirectStores>(a, st);
     // the same kernel on 32 x 32 x 16 MFMAs
     case kMfma32: return launch_tile<TEPI_NONE, false, kMfma32>(a, st);

@@ -274,6 +274,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w16_kernel(const TileArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < 16; ++q) read1(0, q);
+  // V & 4096 (measurement, tools/gemm_clock.py): shader cycles and 100 MHz reference ticks of the whole tile loop of
+  // every workgroup, written over the first output bytes when everything else is done
+  unsigned long long clk0 = 0, ref0 = 0;
+  if (V & 4096) {
+    clk0 = __builtin_readcyclecounter();
+    ref0 = __builtin_amdgcn_s_memrealtime();
+  }
 
   for (int blk = (int)blockIdx.x; blk < ntiles; blk += stride) {
     const int tid = tile_of_block(blk, a.tiles_t, a.tiles_f, (V & 4) != 0);
@@ -294,5 +301,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w16_kernel(const TileArgs a) {
     if constexpr (LINES) epilogue_lines(m0, n0);
     else epilogue(m0, n0);
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (V & 4096) {
+    const unsigned long long clk1 = __builtin_readcyclecounter(), ref1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      float* o = reinterpret_cast<float*>(a.y) + 2 * blockIdx.x;
+      o[0] = (float)(clk1 - clk0);
+      o[1] = (float)(ref1 - ref0);
+    }
   }
 }

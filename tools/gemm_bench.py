@@ -44,7 +44,7 @@ def main():
         (256, 4096, 1024, "qkv@256"), (128, 4096, 1024, "qkv@128"), (128, 1024, 3072, "down@128"), (8192, 8192, 8192, "8k^3"),
     ]
     E8 = 1 << 20  # the eight-wave ping-pong kernel of rounds 2-3 (kept for comparison)
-    variants = {"tile": 0, "direct_stores": 1 << 18, "mfma_32x32x16": 1 << 19, "no_stores(timing only)": 512,
+    variants = {"tile": 0, "xcd_rect": 4, "direct_stores": 1 << 18, "mfma_32x32x16": 1 << 19, "no_stores(timing only)": 512,
                 "mfma_32x32x16_no_stores": (1 << 19) + 512, "eight_wave_r03": E8}
     if os.environ.get("GEMM_QUICK"):  # the four prefill projections only
         shapes = shapes[:4]
