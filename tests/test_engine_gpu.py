@@ -624,9 +624,11 @@ def test_full_size_properties_paging_invariance_and_decode_equals_reprefill():
         llm.exit()
 
 
-# ("both" runs the replicas line and the tp line of the same world size: the single-mode twins are gpu_slow)
+# ("both" runs the replicas line and the tp line of the same world size: the single-mode twins and the four-rank
+# run - 23 s - are gpu_slow)
 @pytest.mark.parametrize("mode,ranks", [pytest.param("replicas", 2, marks=pytest.mark.gpu_slow),
-                                        pytest.param("tp", 2, marks=pytest.mark.gpu_slow), ("both", 2), ("both", 4)])
+                                        pytest.param("tp", 2, marks=pytest.mark.gpu_slow), ("both", 2),
+                                        pytest.param("both", 4, marks=pytest.mark.gpu_slow)])
 def test_bench_ranks_on_one_gpu(mode, ranks):
     """bench.py for N > 1 on a 1-GPU box (all ranks on cuda:0, gloo instead of RCCL).  `python bench.py --gpus N`
     starts its ranks itself - the command the driver uses for N = 1 must not die for N > 1 - and the default mode

@@ -1,7 +1,8 @@
 """Tile GEMM (mi_gemm_bf16) against the library GEMM behind F.linear on the prefill shapes of the bench
 (16384 tokens x the four Qwen3-0.6B projections) and a few others; every schedule variant of
 mi_gemm_bf16_ex.  Timed as hipGraph replays of REPS back-to-back launches on random data (the guide's rule 25:
-zero-filled operands clock higher).  Usage: python tools/gemm_bench.py [out.json]"""
+zero-filled operands clock higher).  The timing-only variants (no stores, GEMM_ABLATE=1) exist in an
+EXPERIMENTS=1 build of the library only.  Usage: python tools/gemm_bench.py [out.json]"""
 import json
 import os
 import sys
@@ -11,7 +12,7 @@ import torch.nn.functional as F
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "nano-vllm-ascend_amd"))
-from nanovllm import ops  # noqa: E402
+from nanovllm import _C, ops  # noqa: E402
 
 DEV = "cuda:0"
 REPS = 10
@@ -44,8 +45,9 @@ def main():
         (256, 4096, 1024, "qkv@256"), (128, 4096, 1024, "qkv@128"), (128, 1024, 3072, "down@128"), (8192, 8192, 8192, "8k^3"),
     ]
     E8 = 1 << 20  # the eight-wave ping-pong kernel of rounds 2-3 (kept for comparison)
-    variants = {"tile": 0, "xcd_rect": 4, "direct_stores": 1 << 18, "mfma_32x32x16": 1 << 19, "no_stores(timing only)": 512,
-                "mfma_32x32x16_no_stores": (1 << 19) + 512, "eight_wave_r03": E8}
+    variants = {"tile": 0, "xcd_rect": 4, "direct_stores": 1 << 18, "mfma_32x32x16": 1 << 19, "eight_wave_r03": E8}
+    if _C.HAS_EXPERIMENTS:  # timing only (y is not the product): an EXPERIMENTS=1 build
+        variants.update({"no_stores(timing only)": 512, "mfma_32x32x16_no_stores": (1 << 19) + 512})
     if os.environ.get("GEMM_QUICK"):  # the four prefill projections only
         shapes = shapes[:4]
     if os.environ.get("GEMM_MID"):  # the two kernels side by side over the mid-size shapes
@@ -53,9 +55,10 @@ def main():
         shapes = [(M, N, K, f"{name}@{M}") for M in ((16384,) if os.environ.get("GEMM_MID") == "big" else (128, 256, 512, 1024, 2048, 4096))
                   for N, K, name in ((4096, 1024, "qkv"), (1024, 2048, "o_proj"), (6144, 1024, "gate_up"), (1024, 3072, "down"))]
     if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
+        if not _C.HAS_EXPERIMENTS:
+            sys.exit("GEMM_ABLATE=1 needs a library built with `make -C nano-vllm-ascend_amd/csrc EXPERIMENTS=1`")
         variants = {"tile": 0, "no_dma": 32, "no_next_step_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
-                    "pieces_never_waited": 256, "no_stores": 512, "never_waited_no_stores": 768,
-                    "l2_resident_feed": 1024, "l2_resident_feed_no_stores": 1536, "l2_resident_stores": 2048}
+                    "no_stores": 512}
     rows = []
     for M, N, K, label in shapes:
         g = torch.Generator().manual_seed(M + N + K)

@@ -1,6 +1,7 @@
 """Shader clock and cycles per K step INSIDE the four-wave tile GEMM (variant 4096 + 512 of mi_gemm_bf16_ex: the tile
 loop without output stores, stamped with the cycle counter and the 100 MHz reference clock per workgroup), for the
-product kernel (16 x 16 x 32 MFMAs) and its 32 x 32 x 16 form.
+product kernel (16 x 16 x 32 MFMAs) and its 32 x 32 x 16 form.  Needs a library built with
+`make -C nano-vllm-ascend_amd/csrc EXPERIMENTS=1` (the stamped variants are not in the default build).
 usage: python tools/gemm_clock.py"""
 import os
 import sys
@@ -9,7 +10,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vllm-ascend_amd"))
-from nanovllm import ops  # noqa: E402
+from nanovllm import _C, ops  # noqa: E402
+
+if not _C.HAS_EXPERIMENTS:
+    sys.exit("tools/gemm_clock.py needs an EXPERIMENTS=1 build of the library")
 
 DEV = "cuda:0"
 for form, base in (("16x16x32", 0), ("32x32x16", 1 << 19)):
