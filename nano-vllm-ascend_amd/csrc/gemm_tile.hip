@@ -833,6 +833,9 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
     case 4096 + 512: return launch_tile<TEPI_NONE, false, 4096 + 512>(a, st);
     case kMfma32 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 512>(a, st);
     case kMfma32 + 4096 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 4096 + 512>(a, st);
+    case kMfma32 + 256: return launch_tile<TEPI_NONE, false, kMfma32 + 256>(a, st);    // pieces never waited for
+    case kMfma32 + 1024: return launch_tile<TEPI_NONE, false, kMfma32 + 1024>(a, st);  // feed from 64 KiB of L2
+    case kMfma32 + 1024 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 1024 + 512>(a, st);
 #endif
     // the eight-wave kernel of rounds 2-3 and its variants
     case kEightWaves: return launch_tile<TEPI_NONE, false, kEightWaves>(a, st);

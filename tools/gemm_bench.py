@@ -58,7 +58,8 @@ def main():
         if not _C.HAS_EXPERIMENTS:
             sys.exit("GEMM_ABLATE=1 needs a library built with `make -C nano-vllm-ascend_amd/csrc EXPERIMENTS=1`")
         variants = {"tile": 0, "no_dma": 32, "no_next_step_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
-                    "no_stores": 512}
+                    "no_stores": 512, "mfma32_pieces_never_waited": (1 << 19) + 256, "mfma32_l2_resident_feed": (1 << 19) + 1024,
+                    "mfma32_l2_resident_feed_no_stores": (1 << 19) + 1536}
     rows = []
     for M, N, K, label in shapes:
         g = torch.Generator().manual_seed(M + N + K)
