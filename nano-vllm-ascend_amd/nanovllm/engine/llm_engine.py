@@ -73,6 +73,12 @@ class LLMEngine:
         # workers queue the same step when its message arrives (ModelRunner.loop)
         self.lookahead = config.decode_lookahead and os.environ.get("MI355_LOOKAHEAD", "1") != "0"
         self._inflight = None  # (handle, sequences, rows dropped after launch) of a queued decode step
+        # ... and the same between consecutive PREFILL steps (one GPU): while a long prefill step runs, the next one is
+        # admitted (Scheduler.lookahead_prefill: only when that is the decision schedule() would take afterwards) and
+        # queued behind it, so the device goes from one to the other without the host's 0.6 ms in between
+        self._inflight_prefill = None  # (handle, sequences) of a queued prefill step
+        self.prefill_lookahead_min_tokens = 4096  # a step in flight this long hides the next one's launch sequence
+        self.prefill_lookahead_launches = 0
         self._exited = False
         if kwargs.get("warmup", True):
             self.warmup_model()
@@ -129,28 +135,55 @@ class LLMEngine:
             for s in seqs:
                 if s.request_id == request_id and not s.is_finished:
                     dropped.add(id(s))
+        # (a queued PREFILL step's rows of the request are recognised by their finished state when it is collected)
         self.scheduler.abort_seq_group(request_id)
 
     def is_finished(self) -> bool:
-        return self.scheduler.is_finished() and self._inflight is None
+        return self.scheduler.is_finished() and self._inflight is None and self._inflight_prefill is None
 
     def step(self):
         if self._inflight is not None:
             return self._step_lookahead(*self._inflight)
+        if self._inflight_prefill is not None:
+            queued, self._inflight_prefill = self._inflight_prefill, None
+            return self._step_prefill(*queued)
         seqs, is_prefill = self.scheduler.schedule()
         if self.lookahead and not is_prefill and seqs and self.model_runner.can_launch_decode(len(seqs)):
             return self._step_lookahead(self.model_runner.call("launch_decode", seqs), seqs, set())
+        if self.lookahead and is_prefill and seqs and self.model_runner.can_launch_prefill:
+            return self._step_prefill(self.model_runner.call("launch_prefill", seqs), seqs)
         token_ids = self.model_runner.call("run", seqs, is_prefill)
         if is_prefill:
-            now = perf_counter()
-            for s in seqs:
-                if s.num_completion_tokens == 0 and s.seq_id not in self.ttft:
-                    s.first_token_time = now
-                    self.ttft[s.seq_id] = now - s.arrival_time
+            self._stamp_first_tokens(seqs)
         self.scheduler.postprocess(seqs, token_ids)
         outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
                    for s in seqs if s.is_finished]
         num_tokens = sum(len(s) for s in seqs) if is_prefill else -len(seqs)
+        return outputs, num_tokens
+
+    def _stamp_first_tokens(self, seqs):
+        now = perf_counter()
+        for s in seqs:
+            if s.num_completion_tokens == 0 and s.seq_id not in self.ttft:
+                s.first_token_time = now
+                self.ttft[s.seq_id] = now - s.arrival_time
+
+    def _step_prefill(self, handle, seqs):
+        """One prefill step whose launch is already queued (`handle`): admit and queue the NEXT prefill step first when
+        Scheduler.lookahead_prefill allows it, then wait for this step's first tokens and postprocess them."""
+        runner, sched = self.model_runner, self.scheduler
+        nxt = sched.lookahead_prefill(seqs, self.prefill_lookahead_min_tokens)
+        if nxt:
+            self._inflight_prefill = (runner.call("launch_prefill", nxt), nxt)
+            self.prefill_lookahead_launches += 1
+        tokens = runner.collect_prefill(handle)
+        num_tokens = sum(len(s) for s in seqs)
+        live = [(s, t) for s, t in zip(seqs, tokens) if not s.is_finished]  # (aborted while the step was queued)
+        seqs, tokens = [s for s, _ in live], [t for _, t in live]
+        self._stamp_first_tokens(seqs)
+        sched.postprocess(seqs, tokens)
+        outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
+                   for s in seqs if s.is_finished]
         return outputs, num_tokens
 
     def _step_lookahead(self, handle, seqs, dropped):

@@ -341,8 +341,13 @@ class ModelRunner:
         self._events_recorded = [False, False]
         # prefill metadata staging: ids + positions (8 B) + slots (4 B) per token, per-sequence vectors, tables
         nbytes = cfg.max_num_batched_tokens * 20 + B * (W + 4) * 4 + 4096
-        self.prefill_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        # (two pinned buffers, alternating: launch_prefill queues a step behind the one whose upload may not have run;
+        # ONE device buffer - the uploads are ordered on the stream behind the kernels that read the previous contents)
+        self.prefill_hosts = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
         self.prefill_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._pflip = 0
+        self.prefill_tokens_hosts = [torch.zeros(B, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        self.prefill_events = [torch.cuda.Event() for _ in range(2)]
 
     def _fill_decode_stage(self, seqs: list[Sequence], bucket: int, src_rows=None) -> int:
         """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the next pinned
@@ -369,22 +374,25 @@ class ModelRunner:
     # ------------------------------------------------------------------ metadata -> context
     def prepare_prefill(self, seqs: list[Sequence]):
         """prefill_meta() packed into ONE pinned staging buffer and uploaded with ONE async copy (the
-        reference issues seven pinned allocations + copies, model_runner.py:271-290).  The buffer is
-        reused every step: a step ends with the sampler's stream sync, so the previous upload is done."""
+        reference issues seven pinned allocations + copies, model_runner.py:271-290).  The two pinned buffers
+        alternate: the upload of the step before last is done (its tokens were collected) when one is reused."""
         m = batch_meta.prefill_meta(seqs, self.block_size, skip_cached=self.config.prefix_aware_prefill)
+        self._pflip ^= 1
         arrays = (m.input_ids, m.positions, m.slot_mapping, m.cu_seqlens_q, m.cu_seqlens_k, m.kv_lens,
                   np.ascontiguousarray(m.block_tables))
         offs, off = [], 0
         for a in arrays:
             offs.append(off)
             off += (a.nbytes + 15) // 16 * 16
-        if off > self.prefill_host.numel():  # grow (rare: sized for max_num_batched_tokens up front)
-            self.prefill_host = torch.empty(off * 2, dtype=torch.uint8, pin_memory=True)
+        if off > self.prefill_dev.numel():  # grow (rare: sized for max_num_batched_tokens up front)
             self.prefill_dev = torch.empty(off * 2, dtype=torch.uint8, device=self.device)
-        host = self.prefill_host.numpy()
+        if off > self.prefill_hosts[self._pflip].numel():
+            self.prefill_hosts[self._pflip] = torch.empty(off * 2, dtype=torch.uint8, pin_memory=True)
+        pinned = self.prefill_hosts[self._pflip]
+        host = pinned.numpy()
         for a, o in zip(arrays, offs):
             host[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
-        self.prefill_dev[:off].copy_(self.prefill_host[:off], non_blocking=True)
+        self.prefill_dev[:off].copy_(pinned[:off], non_blocking=True)
 
         def dev(i, dtype, shape=None):
             a = arrays[i]
@@ -539,6 +547,36 @@ class ModelRunner:
         self.last_logits = self.graph_logits[bucket]
         self._steps_run += 1
         return (b, real)
+
+    # ------------------------------------------------------------------ queued prefill (one GPU)
+    @property
+    def can_launch_prefill(self) -> bool:
+        """A prefill step can be queued without waiting for its tokens (launch_prefill / collect_prefill).  One GPU only:
+        the TP workers' prefill ends in the exchange-status check of run()."""
+        return self.world_size == 1
+
+    @torch.inference_mode()
+    def launch_prefill(self, seqs: list[Sequence]):
+        """run(seqs, True) without its last step: metadata upload, the model, the sampler and the token copy are queued
+        on the stream, an event marks their end; collect_prefill() waits for it.  The engine queues the NEXT prefill
+        step between the two (Scheduler.lookahead_prefill)."""
+        real = len(seqs)
+        input_ids, positions = self.prepare_prefill(seqs)
+        b = self._pflip
+        temps = self.prepare_sample(seqs)
+        logits = self.run_model(input_ids, positions, True, None)
+        self.last_logits = logits
+        self.sampler(logits, temps, out=self.tokens_dev[:real])
+        self.prefill_tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+        self.prefill_events[b].record()
+        self._steps_run += 1
+        reset_context()
+        return (b, real)
+
+    def collect_prefill(self, handle) -> list[int]:
+        b, real = handle
+        self.prefill_events[b].synchronize()
+        return self.prefill_tokens_hosts[b][:real].tolist()
 
     def collect(self, handle) -> list[int]:
         b, real = handle

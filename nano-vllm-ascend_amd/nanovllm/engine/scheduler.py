@@ -140,6 +140,38 @@ class Scheduler:
         picked = self._pick_decode(deferred)
         return picked, deferred
 
+    def lookahead_prefill(self, inflight: list[Sequence], min_inflight_tokens: int) -> list[Sequence] | None:
+        """The prefill step that follows the prefill step in flight over `inflight`, admitted BEFORE that step's first
+        tokens are known - only when the admission is provably the one schedule() would make after postprocess():
+
+        * no can_allocate() of this admission can fail (the free list covers every candidate of the window), so the
+          blocks the step in flight may free - appended behind the ones taken here - change neither who is admitted
+          nor any block id;
+        * the step would be closed by the token budget or the sequence count, not by the end of the queue: a request
+          arriving while the step in flight runs could not have joined it either (admission never skips);
+        * the step in flight is long enough (min_inflight_tokens) for the next one's launch sequence to hide behind it -
+          queueing a step behind a short one would only delay the short one's tokens.
+
+        Returns the admitted sequences, or None: decide synchronously."""
+        if not self.waiting or sum(len(s) - s.num_cached_tokens for s in inflight) < min_inflight_tokens:
+            return None
+        blocks = tokens = count = 0
+        closed = False
+        for seq in self.waiting:
+            if count == self.max_num_seqs:
+                closed = True
+                break
+            blocks += seq.num_blocks
+            if not closed and tokens + len(seq) > self.max_num_batched_tokens:
+                closed = True  # (keep summing the blocks: cache hits may let the real admission go further)
+            tokens += len(seq)
+            count += 1
+        if blocks > len(self.block_manager.free_block_ids):
+            return None
+        if not (closed or count == self.max_num_seqs or tokens == self.max_num_batched_tokens):
+            return None
+        return self._admit_prefill() or None
+
     def resolve(self, seqs: list[Sequence], token_ids: list[int], deferred: list[Sequence],
                 queued: list[Sequence] | None) -> list[Sequence]:
         """The value half of postprocess() for a step whose successor `queued` is already in flight: fill in

@@ -289,6 +289,39 @@ def test_lookahead_decode_equals_step_by_step_decode():
     assert a[1][:5] == b[1][:5] and a[3][:5] == b[3][:5]
 
 
+def test_prefill_steps_queued_behind_one_another_keep_the_tokens():
+    """Prefill lookahead (LLMEngine._step_prefill: while a prefill step runs the next one is admitted, its metadata
+    uploaded and its launches queued behind it - alternating pinned staging buffers, one event per step) against the
+    synchronous loop: ten prompts behind a 256-token budget = four prefill steps, three of them queued ahead; greedy
+    and sampled requests (the sampler's draws are keyed by step and row: both unchanged), one request that ends with
+    its first token, shared prefixes between consecutive steps (a queued step reads KV blocks the step in front of it
+    is still writing)."""
+    from nanovllm import LLM, SamplingParams
+
+    gen = torch.Generator().manual_seed(33)
+    common = torch.randint(0, 4096, (32,), generator=gen).tolist()
+    prompts = [(common if i in (2, 3, 6) else []) + torch.randint(0, 4096, (n,), generator=gen).tolist()
+               for i, n in enumerate((70, 90, 48, 60, 100, 80, 40, 96, 75, 30))]
+    sps = [SamplingParams(max_tokens=m, ignore_eos=True, greedy=(i % 3 != 1), temperature=0.9)
+           for i, m in enumerate((6, 9, 4, 1, 7, 5, 8, 3, 6, 5))]
+
+    def run(lookahead):
+        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=16, max_num_batched_tokens=256,
+                  max_model_len=256, num_kvcache_blocks=200, warmup=False, sampling_seed=5,
+                  decode_lookahead=lookahead)
+        try:
+            llm.prefill_lookahead_min_tokens = 0  # (the product default only queues behind steps of >= 4096 tokens)
+            outs = llm.generate(prompts, sps, use_tqdm=False)
+            return [o["token_ids"] for o in outs], [o["cache_tokens"] for o in outs], llm.prefill_lookahead_launches
+        finally:
+            llm.exit()
+
+    (a, ca, na), (b, cb, nb) = run(False), run(True)
+    assert na == 0 and nb >= 2
+    assert [len(t) for t in a] == [6, 9, 4, 1, 7, 5, 8, 3, 6, 5]
+    assert a == b and ca == cb and sum(ca) >= 64
+
+
 _TP1_RUNS: dict = {}
 
 

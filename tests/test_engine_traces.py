@@ -132,6 +132,9 @@ def test_sequence_wire_roundtrip():
             assert r.token_ids == s.token_ids
 
 
+_PREFILL_AHEAD: dict = {}  # scenario -> prefill steps the engine queued behind a running prefill step
+
+
 class _TraceRunner:
     """ModelRunner stand-in that checks every launched step against the REFERENCE's recorded trace and samples
     with the recording's stand-in sampler.  Under lookahead a step is launched before the previous step's tokens
@@ -191,9 +194,19 @@ class _TraceRunner:
     def collect(self, handle):
         return handle
 
+    can_launch_prefill = True
+
+    def launch_prefill(self, seqs):
+        return self._check_and_sample(seqs, True, [-1] * len(seqs))
+
+    def collect_prefill(self, handle):
+        return handle
+
     def call(self, name, seqs, *args):
         if name == "launch_decode":  # the engine's RPC entry: a step queued behind the running one
             return self.launch_decode(seqs, *args)
+        if name == "launch_prefill":
+            return self.launch_prefill(seqs)
         assert name == "run"
         return self._check_and_sample(seqs, args[0], [-1] * len(seqs)) if seqs else []
 
@@ -214,6 +227,9 @@ def test_lookahead_engine_reproduces_the_reference_trace(sc):
     eng = object.__new__(LLMEngine)
     eng.scheduler = Scheduler(cfg)
     eng.block_size, eng.tokenizer, eng.ttft, eng.lookahead, eng._inflight = c["block_size"], None, {}, True, None
+    # prefill steps are queued behind one another too, whenever Scheduler.lookahead_prefill can prove the admission
+    # (no minimum length of the step in flight here: every opportunity is taken)
+    eng._inflight_prefill, eng.prefill_lookahead_min_tokens, eng.prefill_lookahead_launches = None, 0, 0
     order, index = [], {}
     eng.model_runner = _TraceRunner(sc, index)
     for _, toks, max_tokens, ignore_eos in sorted(sc["arrivals"], key=lambda a: a[0]):
@@ -227,6 +243,12 @@ def test_lookahead_engine_reproduces_the_reference_trace(sc):
         assert guard < 2000
     assert eng.model_runner.step == len(sc["steps"])  # every recorded step was launched, none extra
     assert eng.model_runner.lookahead_launches > 0    # and some of them one step ahead
+    _PREFILL_AHEAD[sc["name"]] = eng.prefill_lookahead_launches
     assert [list(s.token_ids) for s in order] == sc["final_tokens"]
     assert [s.num_cached_tokens for s in order] == sc["final_cached"]
     assert len(eng.scheduler.block_manager.free_block_ids) == c["num_kvcache_blocks"] - 1
+
+
+def test_some_recorded_prefill_steps_were_queued_ahead():
+    """(runs after the parametrised replay above) the replay exercised the prefill lookahead, not only its refusals."""
+    assert _PREFILL_AHEAD and sum(_PREFILL_AHEAD.values()) > 0, _PREFILL_AHEAD

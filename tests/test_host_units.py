@@ -591,6 +591,7 @@ class _ScriptedRunner:
         self.max_launch_rows = max_rows
         self.device_tokens = []  # tokens of the step launched last ("tokens_dev")
         self.steps = []          # (seq ids, positions, input ids, block tables) per decode step
+        self.prefills = []       # seq ids per prefill step
 
     @classmethod
     def _next(cls, seq, input_id, position):
@@ -612,14 +613,25 @@ class _ScriptedRunner:
     def collect(self, handle):
         return handle
 
+    can_launch_prefill = True
+
+    def launch_prefill(self, seqs):
+        self.prefills.append([s.seq_id for s in seqs])
+        self.device_tokens = [self._next(s, s.last_token, s.num_tokens - 1) for s in seqs]
+        return list(self.device_tokens)
+
+    def collect_prefill(self, handle):
+        return handle
+
     def call(self, name, seqs, *args):
         if name == "launch_decode":
             return self.launch_decode(seqs, *args)
+        if name == "launch_prefill":
+            return self.launch_prefill(seqs)
         assert name == "run"
         is_prefill = args[0]
         if is_prefill:
-            self.device_tokens = [self._next(s, s.last_token, s.num_tokens - 1) for s in seqs]
-            return list(self.device_tokens)
+            return self.launch_prefill(seqs)
         return self._decode(seqs, [-1] * len(seqs))
 
 
@@ -631,6 +643,7 @@ def _scripted_engine(lookahead, **cfg):
     eng.model_runner = _ScriptedRunner()
     eng.block_size = eng.scheduler.block_manager.block_size
     eng.tokenizer, eng.ttft, eng.lookahead, eng._inflight = None, {}, lookahead, None
+    eng._inflight_prefill, eng.prefill_lookahead_min_tokens, eng.prefill_lookahead_launches = None, 0, 0
     return eng
 
 
@@ -803,3 +816,96 @@ def test_lookahead_fuzz_against_the_synchronous_engine(seed):
     assert d0 == d1
     if eos < 0:
         assert s0 == s1 and f0 == f1 and h0 == h1
+
+
+# ----------------------------------------------------------------------------- lookahead prefill
+def test_prefill_lookahead_rules():
+    """Scheduler.lookahead_prefill admits the next prefill step behind the one in flight only when that is provably the
+    admission schedule() would make after the step in flight was postprocessed."""
+    def waiting_engine(n_wait, nblk=200, budget=64, max_num_seqs=8, first=(20, 20, 20)):
+        Sequence.counter = __import__("itertools").count()
+        s = sched(num_kvcache_blocks=nblk, max_num_batched_tokens=budget, max_num_seqs=max_num_seqs)
+        for k, n in enumerate(first):
+            s.add(Sequence([1000 * (k + 1) + j for j in range(n)],
+                           SamplingParams(max_tokens=4, ignore_eos=True, temperature=1.0), block_size=4))
+        for i in range(n_wait):
+            s.add(Sequence([100 * (i + 1) + j for j in range(20)],
+                           SamplingParams(max_tokens=4, ignore_eos=True, temperature=1.0), block_size=4))
+        flying, is_prefill = s.schedule()
+        assert is_prefill and len(flying) == 3
+        return s, flying
+
+    s, flying = waiting_engine(0)
+    assert s.lookahead_prefill(flying, 0) is None                      # nothing waits
+    s, flying = waiting_engine(5)
+    assert s.lookahead_prefill(flying, 61) is None                     # the step in flight (60 tokens) is too short
+    assert len(s.waiting) == 5 and len(s.running) == 3                 # ... and nothing was touched
+    s, flying = waiting_engine(2)
+    assert s.lookahead_prefill(flying, 0) is None                      # 40 of 64 tokens: a late request could still join
+    s, flying = waiting_engine(5, nblk=3 * 5 + 4 * 5 + 1)              # one block short of covering all five candidates
+    assert s.lookahead_prefill(flying, 0) is None and len(s.waiting) == 5
+    s, flying = waiting_engine(5, nblk=3 * 5 + 5 * 5 + 1)
+    nxt = s.lookahead_prefill(flying, 0)                               # closed by the budget (3 x 20 <= 64 < 4 x 20)
+    assert [q.seq_id for q in nxt] == [3, 4, 5] and len(s.waiting) == 2
+    assert [q.seq_id for q in s.running] == [0, 1, 2, 3, 4, 5]
+    s, flying = waiting_engine(3, max_num_seqs=3, budget=1000)
+    assert len(s.lookahead_prefill(flying, 0)) == 3                    # closed by the sequence count
+    s, flying = waiting_engine(3, budget=60)
+    assert len(s.lookahead_prefill(flying, 0)) == 3                    # exactly at the budget: nobody else fits
+
+
+@pytest.mark.parametrize("eos", [-1, 5])
+def test_prefill_lookahead_chain_reproduces_the_synchronous_engine(eos):
+    """Many prompts behind a small token budget: the prefill steps are queued behind one another.  Same prefill steps,
+    same token streams and the same allocator state as the plain loop - with requests that end at their first token
+    (by length, and by EOS when it is on) between two queued steps."""
+    rng = np.random.default_rng(11)
+    reqs = [([int(t) for t in rng.integers(0, 23, n)], m) for n, m in
+            ((14, 5), (9, 1), (11, 7), (13, 3), (12, 1), (10, 9), (15, 2), (8, 6), (9, 4), (14, 1), (7, 5), (12, 8))]
+    outs = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=eos, num_kvcache_blocks=80, max_num_batched_tokens=40, max_num_seqs=6)
+        for p, m in reqs:
+            eng.add_request(p, SamplingParams(max_tokens=m, ignore_eos=False, temperature=1.0))
+        done = _drain(eng)
+        bm = eng.scheduler.block_manager
+        assert not bm.used_block_ids and eng._inflight is None and eng._inflight_prefill is None
+        outs.append((done, eng.model_runner.prefills, eng.model_runner.steps, list(bm.free_block_ids),
+                     dict(bm.hash_to_block_id), eng.prefill_lookahead_launches))
+    sync, look = outs
+    assert sync[5] == 0 and look[5] >= 2
+    assert sync[0] == look[0] and sync[1] == look[1]
+    assert sync[3] == look[3] and sync[4] == look[4]
+    if eos < 0:
+        assert sync[2] == look[2]
+    else:
+        assert any(len(sync[0][i]) < m for i, (_, m) in enumerate(reqs))  # the scripted model does hit EOS
+
+
+def test_prefill_lookahead_abort_drops_the_rows_of_the_queued_step():
+    """abort_request while the aborted request's prompt is in the QUEUED prefill step: its first token is discarded
+    when that step is collected, its blocks are free, the other streams are untouched."""
+    outs = []
+    for abort in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(True, eos=-1, num_kvcache_blocks=60, max_num_batched_tokens=24, max_num_seqs=4)
+        for i in range(6):
+            eng.add_request([i + 1] * 11, SamplingParams(max_tokens=6, ignore_eos=True, temperature=1.0),
+                            request_id=f"r{i}")
+        done = {}
+        for step in range(60):
+            if eng.is_finished():
+                break
+            if step == 1:
+                assert eng._inflight_prefill is not None  # requests 2 and 3 are in the queued step
+                assert [s.request_id for s in eng._inflight_prefill[1]] == ["r2", "r3"]
+                if abort:
+                    eng.abort_request("r3")
+            for seq_id, toks, _, _ in eng.step()[0]:
+                done[seq_id] = list(toks)
+        outs.append(done)
+        assert not eng.scheduler.block_manager.used_block_ids and eng._inflight_prefill is None
+    full, aborted = outs
+    assert sorted(full) == list(range(6)) and sorted(aborted) == [0, 1, 2, 4, 5]
+    assert all(aborted[i] == full[i] for i in aborted)

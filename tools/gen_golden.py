@@ -338,6 +338,15 @@ def gen_engine():
                       (1, [rng.randrange(1, 900) for _ in range(10)], 30, False),
                       (3, [rng.randrange(1, 900) for _ in range(33)], 4, True),
                       (3, [rng.randrange(1, 900) for _ in range(5)], 6, True)], False, eos=500),
+        # three prefill steps back to back, each closed by the token budget (what the engine's prefill lookahead
+        # queues behind one another); a request that ends with its first token frees its blocks between two of them
+        run_scenario("prefill_chain_b16", 16, 64, 4, 128, 128,
+                     [(0, [rng.randrange(1, 900) for _ in range(n)], m, True)
+                      for n, m in ((40, 6), (44, 1), (40, 5), (50, 4), (60, 1), (30, 3), (20, 7))], False),
+        # the same chain with so few blocks that the later admissions depend on what the earlier steps free
+        run_scenario("prefill_chain_tight_b16", 16, 12, 4, 128, 128,
+                     [(0, [rng.randrange(1, 900) for _ in range(n)], m, True)
+                      for n, m in ((40, 6), (44, 1), (40, 5), (50, 4), (60, 1), (30, 3), (20, 7))], True),
     ]
     with open(os.path.join(OUT, "engine_traces.json"), "w") as f:
         json.dump(scenarios, f, separators=(",", ":"))

@@ -22,6 +22,7 @@ def main():
     llm = LLM.from_config_dict(QWEN3_0_6B, kvcache_block_size=16, max_num_seqs=32, max_model_len=4096,
                                max_num_batched_tokens=16384, num_kvcache_blocks=4096, synthetic_seed=0, sampling_seed=0)
     runner, sched = llm.model_runner, llm.scheduler
+    llm.prefill_lookahead_min_tokens = 1 << 60  # one step at a time: this is the timeline of a step on its own
     marks = {}
 
     def stamp(name):
