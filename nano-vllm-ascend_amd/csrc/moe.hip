@@ -48,7 +48,13 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restri
   }
   sum = wave_sum(sum);
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) p[i] = p[i] / sum;  // softmax(dim=1, dtype=float)
+  for (int i = 0; i < EPL; ++i) {
+    p[i] = p[i] / sum;  // softmax(dim=1, dtype=float)
+    // non-finite router logits (a NaN upstream): the picks below must still be k DISTINCT valid experts - an id left
+    // unwritten or out of range would send mi_moe_sort's counters and the grouped GEMMs out of bounds.  The weights
+    // of such a token are NaN (0 / 0), as the reference's would be; nothing changes for finite logits.
+    if (!(p[i] == p[i])) p[i] = 0.f;
+  }
   // top-k by repeated arg-max; equal probabilities: the lower expert id first
   float sel_p = 0.f;  // lane j < top_k keeps the j-th pick
   int sel_e = 0;

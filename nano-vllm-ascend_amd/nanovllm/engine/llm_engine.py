@@ -123,6 +123,12 @@ class LLMEngine:
             if self.tokenizer is None:
                 raise ValueError("this model directory has no tokenizer: pass token ids")
             prompt = self.tokenizer.encode(prompt)
+        if len(prompt) > self.scheduler.max_model_len:
+            # max_model_len (Config: already clamped to the model's max_position_embeddings) bounds the RoPE table and the
+            # static block-table width: a longer prompt would read past both.  The reference does not check either (its
+            # rotary cache is then indexed out of range, rotary_embedding.py:42); fail before anything is scheduled.
+            raise ValueError(f"prompt of {len(prompt)} tokens exceeds max_model_len = {self.scheduler.max_model_len} "
+                             "(Config.max_model_len, clamped to the model's max_position_embeddings)")
         seq = Sequence(prompt, sampling_params, request_id=request_id, block_size=self.block_size)
         seq.prompt_hashes(self.block_size)  # request preprocessing (with the token array built by Sequence): before the clock
         seq.arrival_time = perf_counter()

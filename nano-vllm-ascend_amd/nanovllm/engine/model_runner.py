@@ -551,9 +551,11 @@ class ModelRunner:
     # ------------------------------------------------------------------ queued prefill (one GPU)
     @property
     def can_launch_prefill(self) -> bool:
-        """A prefill step can be queued without waiting for its tokens (launch_prefill / collect_prefill).  One GPU only:
-        the TP workers' prefill ends in the exchange-status check of run()."""
-        return self.world_size == 1
+        """A prefill step can be queued without waiting for its tokens (launch_prefill / collect_prefill).  One GPU without
+        a process group only: the TP workers' prefill ends in the exchange-status check of run(), and a step that issues
+        RCCL collectives (also the one-rank group of MI355_TP1_COLLECTIVES) is waited for with the stream
+        synchronisation of run()."""
+        return self.world_size == 1 and not self.collective
 
     @torch.inference_mode()
     def launch_prefill(self, seqs: list[Sequence]):

@@ -909,3 +909,16 @@ def test_prefill_lookahead_abort_drops_the_rows_of_the_queued_step():
     full, aborted = outs
     assert sorted(full) == list(range(6)) and sorted(aborted) == [0, 1, 2, 4, 5]
     assert all(aborted[i] == full[i] for i in aborted)
+
+
+def test_add_request_refuses_prompts_longer_than_max_model_len():
+    """max_model_len bounds the RoPE table and the static block-table width: a longer prompt fails at add_request
+    (the reference indexes its rotary cache out of range instead); a prompt of exactly max_model_len tokens is served."""
+    eng = _scripted_engine(True, eos=-1, num_kvcache_blocks=40, max_num_batched_tokens=64, max_model_len=24)
+    sp = SamplingParams(max_tokens=3, ignore_eos=True, temperature=1.0)
+    with pytest.raises(ValueError, match="max_model_len"):
+        eng.add_request(list(range(25)), sp)
+    assert eng.is_finished()
+    eng.add_request(list(range(24)), sp)
+    done = _drain(eng)
+    assert len(done) == 1 and len(next(iter(done.values()))) == 1  # ends by length with its first token

@@ -1040,3 +1040,30 @@ def test_moe_route_ties_and_uniform_logits(ops):
                                 ops.pack_expert_weights(dn.to(DEV)), K)
     assert ids[0].tolist() == [0, 1, 2, 3] and ids[1].tolist() == [0, 1, 2, 40]
     assert torch.equal(w[0].cpu().float(), torch.full((K,), 0.25))
+
+
+def test_moe_route_non_finite_logits_still_pick_distinct_valid_experts(ops):
+    """A NaN / Inf in a token's router logits (a fault upstream) must not leave an expert id unwritten or out of range -
+    mi_moe_sort's counters and the grouped GEMMs index by it.  Such a token gets k distinct valid experts and NaN
+    weights (its output is NaN, as the reference's would be); the other tokens are untouched."""
+    T, E, K, H, I = 70, 8, 2, 128, 64
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(T, E, generator=g).bfloat16()
+    clean = logits.clone()
+    logits[3] = float("nan")
+    logits[17, 5] = float("inf")
+    logits[40, 2] = float("nan")
+    x = torch.randn(T, H, generator=g).bfloat16()
+    gu = (torch.randn(E, 2 * I, H, generator=g) * 0.05).bfloat16()
+    dn = (torch.randn(E, H, I, generator=g) * 0.05).bfloat16()
+    packed = ops.pack_expert_weights(gu.to(DEV)), ops.pack_expert_weights(dn.to(DEV))
+    out, ids, w = ops.moe_forward(x.to(DEV), logits.to(DEV), *packed, K)
+    ref, rids, rw = ops.moe_forward(x.to(DEV), clean.to(DEV), *packed, K)
+    torch.cuda.synchronize()
+    ids = ids.cpu()
+    assert int(ids.min()) >= 0 and int(ids.max()) < E
+    assert all(len(set(row)) == K for row in ids.tolist())
+    good = [t for t in range(T) if t not in (3, 17, 40)]
+    assert torch.equal(ids[good], rids.cpu()[good]) and torch.equal(w.cpu()[good], rw.cpu()[good])
+    assert torch.equal(out.cpu()[good].view(torch.int16), ref.cpu()[good].view(torch.int16))
+    assert bool(torch.isfinite(out.cpu()[good].float()).all())
