@@ -30,8 +30,9 @@ engine first (that is where p50 TTFT comes from), so the KV cache is resident in
 when the timed region starts.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  prefill_roofline  MFMA flops of one prefill step (16 x 1024 tokens: projections, causal attention, head) / its wall
-                time vs the 2.5 PFLOP/s dense bf16 peak - the TTFT half of the metric;
+  prefill_roofline  MFMA flops of one prefill step (16 x 1024 tokens: projections, causal attention, head) / the wall
+                time of the whole prefill phase (host included; the engine queues the second step behind the first)
+                divided by its steps, vs the 2.5 PFLOP/s dense bf16 peak - the TTFT half of the metric;
   roofline      the dominant kernel (paged_attn_decode, the fused step form the engine runs) timed live
                 with HIP events on its launch stream over the engine's real KV cache: algorithmic KV
                 bytes per launch / average duration vs the 8 TB/s HBM peak; `traffic` = those bytes x
