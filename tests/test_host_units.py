@@ -922,3 +922,63 @@ def test_add_request_refuses_prompts_longer_than_max_model_len():
     eng.add_request(list(range(24)), sp)
     done = _drain(eng)
     assert len(done) == 1 and len(next(iter(done.values()))) == 1  # ends by length with its first token
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_prefill_lookahead_fuzz_with_arrivals_and_aborts(seed):
+    """Seeded request streams that keep several prefill steps' worth of prompts waiting (small token budget), with
+    requests arriving and being aborted between steps, EOS on in half of the seeds, memory tight in a third: every
+    request's token stream equals the synchronous engine's (the scripted model's tokens depend on a request's own
+    history only), nothing is left allocated, and without arrivals / aborts / EOS the prefill steps themselves and the
+    final allocator state are equal as well."""
+    import random
+
+    rng = random.Random(500 + seed)
+    eos = 5 if seed % 2 else -1
+    quiet = seed % 4 == 0  # no arrivals, no aborts: step-for-step comparable
+    budget = rng.choice((24, 40, 64))
+    nblk = rng.choice((14, 30, 120))
+    n_req = rng.randrange(6, 16)
+    reqs = [([rng.randrange(0, 23) for _ in range(rng.randrange(2, min(budget, 20)))], rng.randrange(1, 12))
+            for _ in range(n_req)]
+    arrive = [0 if quiet or rng.random() < 0.6 else rng.randrange(1, 12) for _ in reqs]
+    aborts = {} if quiet else {rng.randrange(1, 10): f"r{rng.randrange(n_req)}" for _ in range(rng.randrange(0, 3))}
+    outs = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=eos, num_kvcache_blocks=nblk, max_num_batched_tokens=budget, max_num_seqs=5,
+                               max_model_len=48)
+        pending = sorted(((a, i) for i, a in enumerate(arrive)), key=lambda t: (t[0], t[1]))
+        ids, done, step = {}, {}, 0
+        while pending or not eng.is_finished():
+            while pending and pending[0][0] <= step:
+                _, i = pending.pop(0)
+                p, m = reqs[i]
+                ids[i] = eng.add_request(p, SamplingParams(max_tokens=m, ignore_eos=False, temperature=1.0),
+                                         request_id=f"r{i}").seq_id
+            if step in aborts:
+                eng.abort_request(aborts[step])
+            if not eng.is_finished():
+                for seq_id, toks, _, _ in eng.step()[0]:
+                    done[seq_id] = list(toks)
+            step += 1
+            assert step < 4000
+        bm = eng.scheduler.block_manager
+        assert not bm.used_block_ids and eng._inflight is None and eng._inflight_prefill is None
+        outs.append(({i: done.get(s) for i, s in ids.items()}, eng.model_runner.prefills, list(bm.free_block_ids),
+                     eng.prefill_lookahead_launches))
+    (d0, p0, f0, n0), (d1, p1, f1, n1) = outs
+    assert n0 == 0
+    never_aborted = [i for i in d0 if f"r{i}" not in aborts.values()]
+    assert all(d0[i] == d1[i] and d0[i] is not None for i in never_aborted), (d0, d1)
+    if quiet and eos < 0:
+        assert p0 == p1 and f0 == f1
+    _FUZZ_PREFILL_AHEAD.append(n1)
+
+
+_FUZZ_PREFILL_AHEAD: list = []
+
+
+def test_prefill_lookahead_fuzz_did_queue_steps_ahead():
+    """(runs after the parametrised fuzz above) the fuzz exercised the lookahead, not only its refusals"""
+    assert sum(_FUZZ_PREFILL_AHEAD) >= 10, _FUZZ_PREFILL_AHEAD
