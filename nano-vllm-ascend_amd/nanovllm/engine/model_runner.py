@@ -561,7 +561,8 @@ class ModelRunner:
     def launch_prefill(self, seqs: list[Sequence]):
         """run(seqs, True) without its last step: metadata upload, the model, the sampler and the token copy are queued
         on the stream, an event marks their end; collect_prefill() waits for it.  The engine queues the NEXT prefill
-        step between the two (Scheduler.lookahead_prefill)."""
+        step between the two (Scheduler.lookahead_prefill) - `last_logits` (the parity hook) then names the logits of
+        the step launched LAST, not of the step just collected."""
         real = len(seqs)
         input_ids, positions = self.prepare_prefill(seqs)
         b = self._pflip
