@@ -323,6 +323,7 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
     random.seed(rank if tp == 1 else 0)  # replicas: every rank its own prompts
     prompts = [[random.randint(0, 10000) for _ in range(PROMPT_LEN)] for _ in range(BATCH)]
     sp = SamplingParams(temperature=1.0, max_tokens=total_new, ignore_eos=True, greedy=True)
+    llm.gc.watch()  # every collection of the run with its generation, duration and whether a step was in progress
     seqs = [llm.add_request(p, sp) for p in prompts]
     # prefill (2 steps of 16 x 1024 tokens; the engine queues the second behind the first): the whole phase on the
     # wall clock - scheduling, metadata, launches, both steps on the device - divided by its steps
@@ -333,7 +334,9 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
         llm.step()
         prefill_steps += 1
     torch.cuda.synchronize()
-    prefill_phase_ms = (time.perf_counter() - t_p) * 1e3
+    t_p_end = time.perf_counter()
+    prefill_phase_ms = (t_p_end - t_p) * 1e3
+    prefill_trace = [dict(r) for r in llm.prefill_trace]
     ttft = sorted(llm.ttft[s.seq_id] for s in seqs)
     for _ in range(args.warmup):
         llm.step()
@@ -349,7 +352,7 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
     torch.cuda.synchronize()
     if replicas:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_local = time.perf_counter() - t0
     ctx1 = len(seqs[0])
     n_rep = 1
     if replicas:  # the slowest rank's clock; TTFTs of all ranks
@@ -390,6 +393,20 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
                    **({"weights": os.environ["BENCH_QUANT"]} if os.environ.get("BENCH_QUANT") else {})},
         "ttft_p50_ms": statistics.median(ttft) * 1e3, "ttft_max_ms": ttft[-1] * 1e3,
         "prefill_steps": prefill_steps,
+        # where the prefill phase's time went, per step, on the phase's own clock (0 = the first step() call): when the
+        # host started / finished queueing the step's launches, how long the step ran on the device (HIP events around it
+        # on the launch stream), when its first tokens were stamped on the host
+        "prefill_steps_ms": [{"tokens": r["tokens"], "seqs": r["seqs"],
+                              "launch_start_ms": (r["launch_start"] - t_p) * 1e3, "host_launch_ms": r["host_launch_ms"],
+                              "device_ms": r["device_ms"],
+                              "stamp_ms": (r["stamp"] - t_p) * 1e3 if r["stamp"] is not None else None,
+                              "queued_behind_previous": r["queued_behind_previous"]} for r in prefill_trace],
+        "prefill_lookahead_min_tokens": llm.prefill_lookahead_min_tokens,
+        # the garbage collector during the run (engine/host_gc.py): nothing may run a full pass inside a step
+        "gc": {"control": llm.gc.enabled, "settle_ms": llm.gc.stats["settle_ms"],
+               "frozen_objects": llm.gc.stats["frozen_objects"],
+               "in_prefill": llm.gc.summary(t_p, t_p_end), "in_timed_region": llm.gc.summary(t0, t0 + elapsed_local),
+               "policy": {k: llm.gc.stats[k] for k in ("young", "mid", "full_idle")}},
         "prefill_roofline": {"bound": "mfma", "achieved": pf / (pf_ms * 1e-3) / 1e12, "peak": PREFILL_MFMA_PEAK * tp / 1e12,
                              "unit": "TFLOP/s", "frac": pf / (pf_ms * 1e-3) / (PREFILL_MFMA_PEAK * tp),
                              "flops_per_step": pf, "ms_per_step": pf_ms, "tokens_per_step": per_step * PROMPT_LEN,

@@ -309,7 +309,12 @@ int mi_pack_weight(const mi_bf16* w, mi_bf16* w_packed, int N, int K, mi_stream 
  * ldx % 8 == 0, ldy % 4 == 0.
  * Shapes whose tiles cannot fill the chip (few token rows x a narrow projection, e.g. 1024 x 1024 x 3072) are
  * computed as K slices into `workspace` (fp32, mi_gemm_bf16_workspace bytes; 0 = not needed for this shape) and
- * summed in slice order by a second launch - deterministic, one rounding. */
+ * summed in slice order by a second launch - deterministic, one rounding.
+ * The operands are addressed with 32-bit byte offsets: (N + 256) * K * 2 and (M + 256) * ldx * 2 must stay below 2^31.
+ * mi_gemm_bf16_max_rows answers that contract for a caller (F.linear takes any shape: layers/linear.py walks longer
+ * activations through the kernel in row pieces): the largest M one launch takes for this weight shape and row
+ * stride, 0 if the weight shape itself is refused (then MI_EUNSUPPORTED from mi_gemm_bf16). */
+int64_t mi_gemm_bf16_max_rows(int N, int K, int64_t ldx);
 size_t mi_gemm_bf16_workspace(int M, int N, int K, int epilogue);
 int mi_gemm_bf16(const mi_bf16* x, int64_t ldx, const mi_bf16* w, const mi_bf16* bias, mi_bf16* y, int64_t ldy,
                  int M, int N, int K, int epilogue, void* workspace, size_t ws_bytes, mi_stream stream);

@@ -753,6 +753,15 @@ static int check_tile_gemm(const void* x, int64_t ldx, const void* w, const void
 
 using namespace mi;
 
+// The shape contract of mi_gemm_bf16 as a query (the same tests as check_tile_gemm): the largest M one launch takes on
+// a [N][K] weight with activation row stride ldx, 0 when the weight shape itself is refused.
+extern "C" int64_t mi_gemm_bf16_max_rows(int N, int K, int64_t ldx) {
+  if (N <= 0 || K <= 0 || K % BK || N % 4 || ldx < K || ldx % 8) return 0;
+  if (((int64_t)N + 256) * K * 2 >= (int64_t)1 << 31) return 0;
+  const int64_t m = (((int64_t)1 << 30) - 1) / ldx - 256;  // (M + 256) * ldx * 2 < 2^31
+  return m > 0 ? m : 0;
+}
+
 extern "C" size_t mi_gemm_bf16_workspace(int M, int N, int K, int epilogue) {
   if (M <= 0 || N <= 0 || K <= 0 || K % BK || epilogue != 0) return 0;
   const int ks = gemm_ksplit(M, N, K);

@@ -100,6 +100,7 @@ _SIGNATURES = {
     ),
     "mi_silu_mul": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_skinny": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, _p]),
+    "mi_gemm_bf16_max_rows": (c_int64, [c_int, c_int, c_int64]),
     "mi_gemm_bf16_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mi_gemm_bf16": (c_int, [_p, c_int64, _p, _p, _p, c_int64, c_int, c_int, c_int, c_int, _p, c_size_t, _p]),
     "mi_gemm_bf16_ex": (c_int, [_p, c_int64, _p, _p, c_int64, c_int, c_int, c_int, c_int, _p]),

@@ -11,7 +11,11 @@ Tensor-parallel ranks: either spawned here as child processes (the reference's m
 engine and the other ranks call `run_worker(model, **kwargs)`.
 
 TTFT is recorded per request as (end of the prefill step that produced its first token
-- add_request time), the definition of bench/serving_bench.py:35-48,112-121.
+- add_request time), the definition of bench/serving_bench.py:35-48,112-121: a HOST clock reading taken when the step's
+tokens are on the host.  Two things keep host hiccups out of it: the garbage collector never runs a full pass inside
+step() (engine/host_gc.py), and a queued prefill step whose tokens have already arrived is collected and stamped BEFORE
+the next step's launch sequence starts (_step_prefill).  `prefill_trace` keeps, per prefill step, when its launch
+sequence started and ended on the host, how long it ran on the device (HIP events) and when its tokens were stamped.
 """
 from __future__ import annotations
 
@@ -24,6 +28,7 @@ from time import perf_counter
 import torch.multiprocessing as mp
 
 from nanovllm.config import Config
+from nanovllm.engine.host_gc import HostGc
 from nanovllm.engine.model_runner import ModelRunner
 from nanovllm.engine.scheduler import Scheduler
 from nanovllm.engine.sequence import Sequence
@@ -77,11 +82,28 @@ class LLMEngine:
         # admitted (Scheduler.lookahead_prefill: only when that is the decision schedule() would take afterwards) and
         # queued behind it, so the device goes from one to the other without the host's 0.6 ms in between
         self._inflight_prefill = None  # (handle, sequences) of a queued prefill step
-        self.prefill_lookahead_min_tokens = 4096  # a step in flight this long hides the next one's launch sequence
+        # a step in flight this long hides the next one's launch sequence: Config.prefill_lookahead_min_tokens, or (< 0)
+        # derived after warm-up from what a prefill step's launch sequence costs this host and what a token costs this
+        # device (_derive_prefill_lookahead_min_tokens)
+        self.prefill_lookahead_min_tokens = (config.prefill_lookahead_min_tokens
+                                             if config.prefill_lookahead_min_tokens >= 0 else 4096)
         self.prefill_lookahead_launches = 0
+        self.prefill_trace: list[dict] = []  # one record per prefill step (see _trace_prefill)
+        self.gc = HostGc(enabled=config.gc_control and os.environ.get("MI355_GC_CONTROL", "1") != "0")
         self._exited = False
         if kwargs.get("warmup", True):
             self.warmup_model()
+        # everything alive now is permanent: one full collection, then frozen (engine/host_gc.py).  The full pass walks
+        # every object of the process and leaves the CPU caches cold for the launch path - measured: the first prefill
+        # step after it takes the host 1.1 ms longer to launch and, launch-bound in its first layers, the device 0.6 ms
+        # longer to run (profiles/r05_ttft_2x2.txt) - so it runs BEFORE the warm-up's last phase, not after it.
+        self.gc.settle()
+        if kwargs.get("warmup", True):
+            self.warmup_full_house()
+            if config.prefill_lookahead_min_tokens < 0:
+                self._derive_prefill_lookahead_min_tokens()
+        self.ttft.clear()
+        self.prefill_trace.clear()
         atexit.register(self.exit)
 
     @staticmethod
@@ -104,6 +126,34 @@ class LLMEngine:
         self.generate(prompts, SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=2), use_tqdm=False)
         self.ttft.clear()
 
+    def warmup_full_house(self):
+        """The shape a full house arrives in (not in the reference, whose steps are never queued behind one another):
+        max_num_seqs prompts that fill the token budget TWICE, greedy - two prefill steps of max_num_seqs / 2 sequences,
+        the second queued behind the first (_step_prefill), then one decode step of the largest bucket.  Whatever a
+        first step of that shape costs once (pinned staging of that size class, the sampler's greedy branch, allocator
+        growth, code that has never run) is paid here, before any request's clock runs."""
+        cfg = self.config
+        per_seq = min(cfg.max_model_len - 2, 2 * cfg.max_num_batched_tokens // max(2, cfg.max_num_seqs))
+        blocks = cfg.max_num_seqs * (per_seq // self.block_size + 2)
+        if (cfg.max_num_seqs >= 2 and per_seq >= 16 and blocks <= len(self.scheduler.block_manager.free_block_ids)
+                and os.environ.get("MI355_WARMUP_FULL_HOUSE", "1") != "0"):  # (the switch exists for A/B runs)
+            prompts = [[randint(0, 10000) % self._vocab() for _ in range(per_seq)] for _ in range(cfg.max_num_seqs)]
+            self.generate(prompts, SamplingParams(ignore_eos=True, max_tokens=2, greedy=True), use_tqdm=False)
+        self.ttft.clear()
+
+    def _derive_prefill_lookahead_min_tokens(self):
+        """Queueing step k + 1 behind step k pays when k's device time covers k + 1's launch sequence on the host.  Both
+        were just measured by the warm-up's prefill steps (prefill_trace): the host's launch time per step (it does not
+        depend on the token count: one launch sequence per layer) and the device's time per token of the longest step."""
+        steps = [t for t in self.prefill_trace if t.get("device_ms") and t["tokens"] >= 1024]
+        if not steps:
+            return
+        launch_ms = sorted(t["host_launch_ms"] for t in steps)[len(steps) // 2]
+        big = max(steps, key=lambda t: t["tokens"])
+        per_token_ms = big["device_ms"] / big["tokens"]
+        want = int(1.25 * launch_ms / per_token_ms)
+        self.prefill_lookahead_min_tokens = max(512, min(want, self.config.max_num_batched_tokens))
+
     def _vocab(self) -> int:
         text = getattr(self.config.hf_config, "text_config", self.config.hf_config)
         return text.vocab_size
@@ -112,6 +162,7 @@ class LLMEngine:
         if self._exited:
             return
         self._exited = True
+        self.gc.release()
         self.model_runner.call("exit")
         del self.model_runner
         for p in self.ps:
@@ -148,6 +199,16 @@ class LLMEngine:
         return self.scheduler.is_finished() and self._inflight is None and self._inflight_prefill is None
 
     def step(self):
+        self.gc.enter_step()  # no automatic collection from here on: HostGc.slack() is where the young ones run
+        try:
+            out = self._step()
+        finally:
+            self.gc.leave_step()
+        if out[1] and self.is_finished():
+            self.gc.idle()  # the last request just left: the one place a full collection may run
+        return out
+
+    def _step(self):
         if self._inflight is not None:
             return self._step_lookahead(*self._inflight)
         if self._inflight_prefill is not None:
@@ -157,36 +218,61 @@ class LLMEngine:
         if self.lookahead and not is_prefill and seqs and self.model_runner.can_launch_decode(len(seqs)):
             return self._step_lookahead(self.model_runner.call("launch_decode", seqs), seqs, set())
         if self.lookahead and is_prefill and seqs and self.model_runner.can_launch_prefill:
-            return self._step_prefill(self.model_runner.call("launch_prefill", seqs), seqs)
+            return self._step_prefill(self._launch_prefill(seqs), seqs)
+        t0 = perf_counter()
         token_ids = self.model_runner.call("run", seqs, is_prefill)
         if is_prefill:
-            self._stamp_first_tokens(seqs)
+            now = self._stamp_first_tokens(seqs)
+            self.prefill_trace.append({"tokens": sum(len(s) - s.num_prefix_tokens for s in seqs), "seqs": len(seqs),
+                                       "launch_start": t0, "launch_end": now, "host_launch_ms": (now - t0) * 1e3,
+                                       "device_ms": None, "stamp": now, "queued_behind_previous": False})
         self.scheduler.postprocess(seqs, token_ids)
         outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
                    for s in seqs if s.is_finished]
         num_tokens = sum(len(s) for s in seqs) if is_prefill else -len(seqs)
         return outputs, num_tokens
 
-    def _stamp_first_tokens(self, seqs):
+    def _launch_prefill(self, seqs, behind_previous: bool = False):
+        """Queue a prefill step; the handle carries the step's trace record."""
+        t0 = perf_counter()
+        handle = self.model_runner.call("launch_prefill", seqs)
+        t1 = perf_counter()
+        rec = {"tokens": sum(len(s) - s.num_prefix_tokens for s in seqs), "seqs": len(seqs), "launch_start": t0,
+               "launch_end": t1, "host_launch_ms": (t1 - t0) * 1e3, "device_ms": None, "stamp": None,
+               "queued_behind_previous": behind_previous}
+        if len(self.prefill_trace) >= 4096:  # a serving engine runs for days: keep the tail
+            del self.prefill_trace[:2048]
+        self.prefill_trace.append(rec)
+        return (handle, rec)
+
+    def _stamp_first_tokens(self, seqs) -> float:
         now = perf_counter()
         for s in seqs:
             if s.num_completion_tokens == 0 and s.seq_id not in self.ttft:
                 s.first_token_time = now
                 self.ttft[s.seq_id] = now - s.arrival_time
+        return now
 
-    def _step_prefill(self, handle, seqs):
-        """One prefill step whose launch is already queued (`handle`): admit and queue the NEXT prefill step first when
-        Scheduler.lookahead_prefill allows it, then wait for this step's first tokens and postprocess them."""
+    def _step_prefill(self, launched, seqs):
+        """One prefill step whose launch is already queued (`launched` = (runner handle, trace record)): admit and queue
+        the NEXT prefill step first when Scheduler.lookahead_prefill allows it, then wait for this step's first tokens
+        and postprocess them.  A step whose tokens are already on the host is NOT made to wait for the next one's launch
+        sequence (3-4 ms of host time): it is collected and stamped at once, the next step is then scheduled by the
+        following step() call."""
+        handle, rec = launched
         runner, sched = self.model_runner, self.scheduler
-        nxt = sched.lookahead_prefill(seqs, self.prefill_lookahead_min_tokens)
-        if nxt:
-            self._inflight_prefill = (runner.call("launch_prefill", nxt), nxt)
-            self.prefill_lookahead_launches += 1
+        if not runner.prefill_done(handle):
+            nxt = sched.lookahead_prefill(seqs, self.prefill_lookahead_min_tokens)
+            if nxt:
+                self._inflight_prefill = (self._launch_prefill(nxt, behind_previous=True), nxt)
+                self.prefill_lookahead_launches += 1
+            self.gc.slack()
         tokens = runner.collect_prefill(handle)
+        rec["device_ms"] = runner.prefill_device_ms(handle)
         num_tokens = sum(len(s) for s in seqs)
         live = [(s, t) for s, t in zip(seqs, tokens) if not s.is_finished]  # (aborted while the step was queued)
         seqs, tokens = [s for s, _ in live], [t for _, t in live]
-        self._stamp_first_tokens(seqs)
+        rec["stamp"] = self._stamp_first_tokens(seqs)
         sched.postprocess(seqs, tokens)
         outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
                    for s in seqs if s.is_finished]
@@ -206,6 +292,7 @@ class LLMEngine:
             row_of = {id(s): i for i, s in enumerate(seqs)}
             src = [row_of[id(s)] if s.token_pending else -1 for s in nxt]
             queued = (runner.call("launch_decode", nxt, src), nxt, set())
+        self.gc.slack()  # the device has the next step: the host's only idle time in a step
         tokens = runner.collect(handle)
         if len(live) != len(seqs):
             tokens = [t for s, t in zip(seqs, tokens) if id(s) not in dropped]

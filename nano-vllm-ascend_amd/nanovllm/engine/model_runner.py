@@ -96,6 +96,7 @@ class ModelRunner:
             self.channel = StepChannel(config.hccl_port, self.world_size, rank,
                                        slot_words(config.max_num_batched_tokens, config.max_num_seqs,
                                                   config.max_model_len, config.kvcache_block_size))
+            self.channel.skip_cached_prefix = bool(config.prefix_aware_prefill)
         self.xgmi = None
         self._steps_run = 0
         if self.world_size > 1:
@@ -347,7 +348,10 @@ class ModelRunner:
         self.prefill_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._pflip = 0
         self.prefill_tokens_hosts = [torch.zeros(B, dtype=torch.int64, pin_memory=True) for _ in range(2)]
-        self.prefill_events = [torch.cuda.Event() for _ in range(2)]
+        # (start, end) of a queued prefill step on the device: the end event is what collect_prefill waits for, the pair
+        # gives the step's device time to the engine's prefill trace
+        self.prefill_starts = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.prefill_events = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     def _fill_decode_stage(self, seqs: list[Sequence], bucket: int, src_rows=None) -> int:
         """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the next pinned
@@ -564,6 +568,7 @@ class ModelRunner:
         step between the two (Scheduler.lookahead_prefill) - `last_logits` (the parity hook) then names the logits of
         the step launched LAST, not of the step just collected."""
         real = len(seqs)
+        self.prefill_starts[self._pflip ^ 1].record()  # (prepare_prefill flips to this buffer)
         input_ids, positions = self.prepare_prefill(seqs)
         b = self._pflip
         temps = self.prepare_sample(seqs)
@@ -576,10 +581,19 @@ class ModelRunner:
         reset_context()
         return (b, real)
 
+    def prefill_done(self, handle) -> bool:
+        """Have the queued step's tokens already reached the host?  (No wait.)"""
+        return self.prefill_events[handle[0]].query()
+
     def collect_prefill(self, handle) -> list[int]:
         b, real = handle
         self.prefill_events[b].synchronize()
         return self.prefill_tokens_hosts[b][:real].tolist()
+
+    def prefill_device_ms(self, handle) -> float:
+        """Device time of a collected prefill step, metadata upload to token copy (HIP events on the launch stream)."""
+        b = handle[0]
+        return self.prefill_starts[b].elapsed_time(self.prefill_events[b])
 
     def collect(self, handle) -> list[int]:
         b, real = handle

@@ -7,17 +7,23 @@ Here the block is addressed by name (derived from the rendezvous port), so it al
 works when the ranks are started independently (torchrun), and a step is a flat int64
 message:
 
-    [generation, method, is_prefill, n_seqs, payload_len, n_extra, payload..., extra...]
+    [generation, method, is_prefill, n_seqs, payload_len, n_extra, part_len, more, body part ...]
 
 `extra` carries a method's small integer arguments: for "launch_decode" (a decode step queued behind the running
-one, engine lookahead) the row of the previous step's token buffer each sequence's input id comes from.
+one, engine lookahead) the row of the previous step's token buffer each sequence's input id comes from.  The body
+(payload then extra) of a message that does not fit one slot continues in the following slots (`more` = 1 on every
+part but the last): a prefill step ships the token ids behind each sequence's cached prefix, and with prefix-cache
+hits the scheduler's token budget does not bound that sum by one slot (57 sequences sharing a prefix made a
+117 819-word step against a 25 094-word slot) - a slot is the unit of transfer, not a limit on a step.
 
-Messages live in a ring of four slots; a worker consumes them in order.  No acknowledgement is needed: a published
-step cannot finish on rank 0 before every worker has joined its collectives, i.e. has read it, and rank 0 never
-publishes more than two messages past a step whose results it has waited for (the engine's lookahead queues ONE step
-behind the running one) - so at most two messages are unread when a third is written, and a slot is re-used only four
-messages later.  A reader checks the slot's own generation and fails loudly if it was lapped anyway.  Steps without
-collectives are never published (ModelRunner.call drops empty `run` calls on every rank).
+Messages live in a ring of four slots; a worker consumes them in order and acknowledges each part it has copied out
+(word 1 + rank of the segment).  Rank 0 re-uses a slot only when every worker has acknowledged the part that lived there
+four parts earlier - with one-part messages that never waits (a published step cannot finish on rank 0 before every
+worker has joined its collectives, and the engine's lookahead queues ONE step behind the running one), with a
+many-part message it is the flow control.  A worker that does not acknowledge within `ACK_TIMEOUT_S` is an error on
+rank 0 (never an overwrite, also under `python -O`); a reader checks the slot's own generation and fails loudly if it
+was lapped anyway.  Steps without collectives are never published (ModelRunner.call drops empty `run` calls on every
+rank).
 """
 from __future__ import annotations
 
@@ -29,16 +35,18 @@ import numpy as np
 from nanovllm.engine.sequence import Sequence
 
 _METHODS = ("run", "exit", "launch_decode", "abort")
-_HEADER = 6
+_HEADER = 8
 _DEFAULT_CAPACITY = 1 << 18  # int64 words per slot (2 MiB) when the caller does not size the channel
 _SLOTS = 4
-_BASE = 8            # word 0: newest generation published
+_BASE = 8            # word 0: newest generation published; word r (1 <= r < world <= 8): the newest part rank r has consumed
+ACK_TIMEOUT_S = 120.0
 
 
 def slot_words(max_num_batched_tokens: int, max_num_seqs: int, max_model_len: int, block_size: int) -> int:
-    """int64 words of the largest step message: a prefill step carries every scheduled token id once, every step up to
-    max_num_seqs records of 11 header words + a block table (Sequence.to_wire) - sized from the configuration
-    (four fixed 16 MiB slots were just over Docker's default 64 MB /dev/shm, which RCCL also uses)."""
+    """int64 words of a slot: what a step message normally needs in ONE part - a prefill step carries the scheduled
+    token ids once, every step up to max_num_seqs records of 11 header words + a block table (Sequence.to_wire) - sized
+    from the configuration (four fixed 16 MiB slots were just over Docker's default 64 MB /dev/shm, which
+    RCCL also uses).  Longer messages (prefix-cache hits, see the module text) travel in several parts."""
     table = -(-(max_model_len + 1) // block_size)
     return _HEADER + max_num_batched_tokens + max_num_seqs * (12 + table + 1) + 1024
 
@@ -51,8 +59,12 @@ class StepChannel:
     def __init__(self, port: int, world_size: int, rank: int, capacity_words: int = _DEFAULT_CAPACITY):
         import torch.distributed as dist
 
-        self.rank = rank
-        _CAPACITY = self.capacity = int(capacity_words)  # every rank derives it from the same configuration
+        self.rank, self.world_size = rank, world_size
+        self.skip_cached_prefix = False  # prefill steps ship only the tokens behind the cached prefix (set by ModelRunner)
+        self.parts_sent = 0              # (statistics: parts published, messages that needed more than one)
+        self.multipart_messages = 0
+        assert 1 <= world_size <= _BASE
+        _CAPACITY = self.capacity = max(int(capacity_words), _HEADER + 64)  # every rank derives it from the same configuration
         nbytes = (_BASE + _SLOTS * _CAPACITY) * 8
         if rank == 0:
             try:
@@ -73,46 +85,84 @@ class StepChannel:
             self.buf = np.ndarray((_BASE + _SLOTS * _CAPACITY,), dtype=np.int64, buffer=self.shm.buf)
         self.generation = 0
 
+    def _wait_for_slot(self, gen: int) -> None:
+        """Part `gen` goes where part gen - _SLOTS lived: every worker must have copied that one out."""
+        need = gen - _SLOTS
+        if need <= 0 or self.world_size == 1:
+            return
+        acks = self.buf[1:self.world_size]
+        spins, deadline = 0, None
+        while int(acks.min()) < need:
+            spins += 1
+            if spins > 2000:
+                time.sleep(0)
+                if deadline is None:
+                    deadline = time.monotonic() + ACK_TIMEOUT_S
+                elif time.monotonic() > deadline:
+                    raise RuntimeError(f"control channel: a worker has not read part {need} after {ACK_TIMEOUT_S:.0f} s "
+                                       f"(acknowledged: {[int(a) for a in acks]})")
+
     def send(self, method: str, seqs: list[Sequence] | None = None, is_prefill: bool = False,
              extra: list[int] | None = None) -> None:
         payload: list[int] = []
+        skip = is_prefill and self.skip_cached_prefix
         for s in seqs or ():
-            payload.extend(s.to_wire(is_prefill))
+            payload.extend(s.to_wire(is_prefill, skip))
         n, extra = len(payload), list(extra or ())
-        _CAPACITY = self.capacity
-        assert _HEADER + n + len(extra) <= _CAPACITY, "step message exceeds the control channel"
-        gen = self.generation + 1
-        b = self.buf[_BASE + (gen % _SLOTS) * _CAPACITY:]
-        b[0] = 0  # the slot is being rewritten
-        if n:
-            b[_HEADER:_HEADER + n] = payload
-        if extra:
-            b[_HEADER + n:_HEADER + n + len(extra)] = extra
-        b[1] = _METHODS.index(method)
-        b[2] = int(is_prefill)
-        b[3] = len(seqs or ())
-        b[4] = n
-        b[5] = len(extra)
-        b[0] = gen             # the slot is complete ...
-        self.generation = gen
-        self.buf[0] = gen      # ... and published
+        body = np.asarray(payload + extra, dtype=np.int64) if (n or extra) else np.empty(0, dtype=np.int64)
+        room = self.capacity - _HEADER
+        parts = max(1, -(-len(body) // room))
+        self.multipart_messages += parts > 1
+        for k in range(parts):
+            piece = body[k * room:(k + 1) * room]
+            gen = self.generation + 1
+            self._wait_for_slot(gen)
+            b = self.buf[_BASE + (gen % _SLOTS) * self.capacity:]
+            b[0] = 0  # the slot is being rewritten
+            if len(piece):
+                b[_HEADER:_HEADER + len(piece)] = piece
+            b[1] = _METHODS.index(method)
+            b[2] = int(is_prefill)
+            b[3] = len(seqs or ())
+            b[4] = n
+            b[5] = len(extra)
+            b[6] = len(piece)
+            b[7] = int(k + 1 < parts)
+            b[0] = gen             # the slot is complete ...
+            self.generation = gen
+            self.buf[0] = gen      # ... and published
+            self.parts_sent += 1
 
-    def recv(self):
+    def _recv_part(self):
         spins, want = 0, self.generation + 1
         while int(self.buf[0]) < want:
             spins += 1
             if spins > 2000:
                 time.sleep(0)  # yield, keep latency in the microsecond range
         b = self.buf[_BASE + (want % _SLOTS) * self.capacity:]
-        method, is_prefill, n_seqs, n, n_extra = _METHODS[int(b[1])], bool(b[2]), int(b[3]), int(b[4]), int(b[5])
-        data = b[_HEADER:_HEADER + n].copy()
-        extra = [int(v) for v in b[_HEADER + n:_HEADER + n + n_extra]]
-        if int(b[0]) != want:  # rank 0 ran more than _SLOTS - 1 messages ahead of this worker: a protocol error
+        head = [int(v) for v in b[1:_HEADER]]
+        data = b[_HEADER:_HEADER + head[5]].copy()
+        if int(b[0]) != want:  # rank 0 ran more than _SLOTS - 1 parts ahead of this worker: a protocol error
             raise RuntimeError(f"control channel: message {want} was overwritten before rank {self.rank} read it")
         self.generation = want
+        self.buf[self.rank] = want  # acknowledged: the slot may be re-used
+        return head, data
+
+    def recv(self):
+        head, data = self._recv_part()
+        chunks = [data]
+        while head[6]:
+            more, data = self._recv_part()
+            assert more[:5] == head[:5], "control channel: parts of two messages interleaved"
+            head = more
+            chunks.append(data)
+        method, is_prefill, n_seqs, n, n_extra = _METHODS[head[0]], bool(head[1]), head[2], head[3], head[4]
+        body = chunks[0] if len(chunks) == 1 else np.concatenate(chunks)
+        assert len(body) == n + n_extra, "control channel: message length does not match its header"
+        extra = [int(v) for v in body[n:n + n_extra]]
         seqs, pos = [], 0
         for _ in range(n_seqs):
-            s, pos = Sequence.from_wire(data, pos)
+            s, pos = Sequence.from_wire(body, pos)
             seqs.append(s)
         return method, seqs, is_prefill, extra
 

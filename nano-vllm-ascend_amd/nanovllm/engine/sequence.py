@@ -153,11 +153,17 @@ class Sequence:
     # -- rank-RPC wire format -------------------------------------------------------------------
     # header: [seq_id, num_tokens, num_prompt_tokens, num_cached_tokens, block_size, n_blocks,
     #          n_tokens_sent, temperature_bits, greedy, table_gen, num_prefix_tokens]; then block ids; then the token ids the
-    # receiver needs (all of them for a prefill step, only the last one for a decode step).
-    def to_wire(self, is_prefill: bool) -> list[int]:
+    # receiver needs (for a prefill step all of them - or, skip_cached_prefix, the ones behind the cached prefix that
+    # batch_meta.prefill_meta(skip_cached=True) reads; only the last one for a decode step).
+    def to_wire(self, is_prefill: bool, skip_cached_prefix: bool = False) -> list[int]:
         import struct
 
-        toks = self.token_ids if is_prefill else self.token_ids[-1:]
+        if not is_prefill:
+            toks = self.token_ids[-1:]
+        elif skip_cached_prefix and self.num_prefix_tokens:
+            toks = self.token_ids[min(self.num_prefix_tokens, self.num_tokens - 1):]
+        else:
+            toks = self.token_ids
         tbits = struct.unpack("<q", struct.pack("<d", float(self.temperature)))[0]
         return [self.seq_id, self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_size,
                 len(self.block_table), len(toks), tbits, int(self.greedy), self.table_gen,
@@ -177,7 +183,8 @@ class Sequence:
         pos += n_blocks
         toks = [int(v) for v in buf[pos: pos + n_toks]]
         pos += n_toks
-        # a decode step only carries the last token: pad so that indices/len stay right
+        # a decode step only carries the last token, a prefix-aware prefill step the tokens behind the cached prefix:
+        # pad the front so that indices/len stay right
         s.token_ids = toks if n_toks == num_tokens else [0] * (num_tokens - n_toks) + toks
         s.last_token = toks[-1]
         s.num_tokens, s.num_prompt_tokens, s.num_cached_tokens = num_tokens, num_prompt, num_cached

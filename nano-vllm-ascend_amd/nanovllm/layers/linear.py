@@ -16,8 +16,11 @@ from nanovllm.layers.parallel import all_reduce_sum, divide, tp_rank, tp_size
 
 
 def tile_gemm_takes(rows: int, n: int, k: int) -> bool:
-    """mi_gemm_bf16's shape contract (csrc/gemm_tile.hip: K steps of 64, 16-byte output pieces, 32-bit DMA offsets)"""
-    return k % 64 == 0 and n % 4 == 0 and n * k * 2 < (1 << 32) and rows * k * 2 < (1 << 32)
+    """mi_gemm_bf16's shape contract (csrc/gemm_tile.hip: K steps of 64, 16-byte output pieces, 32-bit DMA offsets),
+    asked of the library (mi_gemm_bf16_max_rows) instead of restated here (the restatement had drifted).
+    The row count does not matter as long as one whole tile row fits: ops.gemm_tile walks longer activations through the
+    kernel in whole-tile row pieces."""
+    return ops.tile_gemm_max_rows(n, k) >= min(max(rows, 1), 256)
 
 
 def streaming_gemm_takes(n: int, k: int) -> bool:

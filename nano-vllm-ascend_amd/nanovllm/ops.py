@@ -438,6 +438,12 @@ def gemm_skinny(x, w, bias=None, out=None) -> torch.Tensor:
     return out
 
 
+def tile_gemm_max_rows(n: int, k: int, ldx: int | None = None) -> int:
+    """mi_gemm_bf16's shape contract, asked of the library itself: the most rows one launch takes on a [n][k] weight
+    (activation row stride ldx, default k); 0 = the kernel refuses the weight shape."""
+    return int(lib.mi_gemm_bf16_max_rows(n, k, k if ldx is None else ldx))
+
+
 def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | None = None) -> torch.Tensor:
     """y = x @ w.T (+ bias) for any number of rows on the MFMA tile kernels (mi_gemm_bf16: 256 x 256 tiles, 128 x 128
     for shapes with few of those); silu_mul:
@@ -455,6 +461,14 @@ def gemm_tile(x, w, bias=None, out=None, silu_mul: bool = False, variant: int | 
     if out is None:
         out = torch.empty((M, n_out), dtype=_BF16, device=x.device)
     assert out.dim() == 2 and out.shape == (M, n_out) and out.stride(1) == 1
+    max_rows = tile_gemm_max_rows(N, K, x.stride(0))
+    if M > max_rows >= 256 and variant is None:
+        # more rows than the kernel's 32-bit operand offsets reach (65 536 tokens x K = 25 600): whole-tile
+        # row pieces, each its own launch over the same weight - same bits, every row's K chain is one tile's
+        step = max_rows // 256 * 256
+        for r0 in range(0, M, step):
+            gemm_tile(x[r0:r0 + step], w, bias, out[r0:r0 + step], silu_mul)
+        return out
     if variant is not None:
         assert bias is None and not silu_mul
         check(lib.mi_gemm_bf16_ex(ptr(x), x.stride(0), ptr(w), ptr(out), out.stride(0), M, N, K, variant, stream()),

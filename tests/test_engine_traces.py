@@ -202,6 +202,12 @@ class _TraceRunner:
     def collect_prefill(self, handle):
         return handle
 
+    def prefill_done(self, handle):
+        return False  # (the device is never ahead of the host here: every lookahead opportunity is taken)
+
+    def prefill_device_ms(self, handle):
+        return 0.0
+
     def call(self, name, seqs, *args):
         if name == "launch_decode":  # the engine's RPC entry: a step queued behind the running one
             return self.launch_decode(seqs, *args)
@@ -230,6 +236,9 @@ def test_lookahead_engine_reproduces_the_reference_trace(sc):
     # prefill steps are queued behind one another too, whenever Scheduler.lookahead_prefill can prove the admission
     # (no minimum length of the step in flight here: every opportunity is taken)
     eng._inflight_prefill, eng.prefill_lookahead_min_tokens, eng.prefill_lookahead_launches = None, 0, 0
+    from nanovllm.engine.host_gc import HostGc
+
+    eng.gc, eng.prefill_trace = HostGc(enabled=False), []
     order, index = [], {}
     eng.model_runner = _TraceRunner(sc, index)
     for _, toks, max_tokens, ignore_eos in sorted(sc["arrivals"], key=lambda a: a[0]):

@@ -192,3 +192,25 @@ def test_linear_forward_takes_shapes_the_tile_kernel_cannot(ops, packed):
     with pytest.raises(NotImplementedError):
         linear.check_linear_shape("odd", 1022, 1384)
     linear.check_linear_shape("down_proj shard", N, K)
+
+
+def test_more_rows_than_one_launch_addresses_go_through_in_row_pieces(ops):
+    """the tile kernel addresses its operands with 31-bit byte offsets, so (M + 256) * ldx * 2 must
+    stay below 2^31 - 65 536 tokens x K = 25 600 does not.  ops.gemm_tile asks the library for the limit
+    (mi_gemm_bf16_max_rows) and walks longer activations through the kernel in whole-tile row pieces; the bits are those
+    of one launch.  Here the limit is reached with a wide row stride instead of a wide K: 1500 rows of a [.., 2^20]
+    buffer (max 768 rows per launch)."""
+    from nanovllm.layers import linear
+
+    M, N, K, ld = 1500, 256, 128, 1 << 20
+    g, x, w = _case(M, N, K, seed=9)
+    big = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
+    big[:, :K] = x.to(DEV)
+    xs = big[:, :K]
+    limit = ops.tile_gemm_max_rows(N, K, ld)
+    assert 256 <= limit < M and linear.tile_gemm_takes(M, N, K)
+    wd = w.to(DEV)
+    y = ops.gemm_tile(xs, wd)
+    want = ops.gemm_tile(x.to(DEV), wd)  # contiguous rows: one launch
+    assert torch.equal(y.view(torch.int16), want.view(torch.int16))
+    assert_bf16_close(y, oracle.linear(x, w, None), max_ulp=1, max_frac=2e-2, atol=K * 2.0 ** -22)

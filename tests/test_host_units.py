@@ -241,6 +241,19 @@ def test_c_abi_exports_every_declared_symbol_and_rejects_bad_arguments():
     ws = _C.lib.mi_gemm_bf16_workspace(1024, 1024, 3072, 0)  # 64 tiles of 128 x 128, 48 K steps: summed in K slices
     assert ws % (1024 * 1024 * 4) == 0 and ws // (1024 * 1024 * 4) in (2, 4, 8, 16)
     assert _C.lib.mi_paged_attn_decode_workspace(32, 16) == 32 * 16 * 16 * 130 * 4
+    # the Python side asks the library for mi_gemm_bf16's shape contract instead of restating it.  M = 0
+    # makes mi_gemm_bf16 return its contract check without launching: both must agree on the weight side ...
+    from nanovllm.layers import linear
+
+    for n, k in ((4096, 1024), (1024, 1376), (1022, 1024), (152064, 8192), (151936, 1024), (65536, 16320), (65536, 16384)):
+        rc = _C.lib.mi_gemm_bf16(1 << 20, k, 1 << 20, None, 1 << 20, n, 0, n, k, 0, None, 0, None)
+        assert (rc == 0) == (_C.lib.mi_gemm_bf16_max_rows(n, k, k) > 0) == linear.tile_gemm_takes(1, n, k), (n, k, rc)
+    # ... and the row limit is exactly the 31-bit operand offset of the kernel's DMA descriptors
+    for k in (64, 1024, 25600, 1 << 20):
+        m = _C.lib.mi_gemm_bf16_max_rows(64, k, k)
+        assert (m + 256) * k * 2 < 1 << 31 <= (m + 257) * k * 2
+    assert linear.tile_gemm_takes(65536, 1024, 25600) and _C.lib.mi_gemm_bf16_max_rows(1024, 25600, 25600) < 65536
+    assert not linear.tile_gemm_takes(512, 152064, 8192)  # a weight beyond the offsets: the streaming pieces take it
     assert b"unsupported" in _C.lib.mi_strerror(-2).lower() or b"not supported" in _C.lib.mi_strerror(-2).lower()
     assert _C.lib.mi_kv_elem_offset(0, 5, 1, 37, 2, 16) == 1 * 2048 + (37 // 32) * 512 + (((37 % 32) // 8) * 16 + 5) * 8 + 37 % 8
     with pytest.raises(_C.MiError):
@@ -623,6 +636,12 @@ class _ScriptedRunner:
     def collect_prefill(self, handle):
         return handle
 
+    def prefill_done(self, handle):
+        return False
+
+    def prefill_device_ms(self, handle):
+        return 0.0
+
     def call(self, name, seqs, *args):
         if name == "launch_decode":
             return self.launch_decode(seqs, *args)
@@ -638,12 +657,17 @@ class _ScriptedRunner:
 def _scripted_engine(lookahead, **cfg):
     from nanovllm.engine.llm_engine import LLMEngine
 
+    cfg_gc = cfg.pop("gc_control", False)
+
     eng = object.__new__(LLMEngine)
     eng.scheduler = sched(**cfg)
     eng.model_runner = _ScriptedRunner()
     eng.block_size = eng.scheduler.block_manager.block_size
     eng.tokenizer, eng.ttft, eng.lookahead, eng._inflight = None, {}, lookahead, None
     eng._inflight_prefill, eng.prefill_lookahead_min_tokens, eng.prefill_lookahead_launches = None, 0, 0
+    from nanovllm.engine.host_gc import HostGc
+
+    eng.gc, eng.prefill_trace = HostGc(enabled=cfg_gc), []
     return eng
 
 
@@ -982,3 +1006,82 @@ _FUZZ_PREFILL_AHEAD: list = []
 def test_prefill_lookahead_fuzz_did_queue_steps_ahead():
     """(runs after the parametrised fuzz above) the fuzz exercised the lookahead, not only its refusals"""
     assert sum(_FUZZ_PREFILL_AHEAD) >= 10, _FUZZ_PREFILL_AHEAD
+
+
+# ----------------------------------------------------------------------------- garbage collector placement
+def _run_with_gc_pressure(gc_control):
+    """The scripted engine under a collector that is eager to run full passes (thresholds 20 / 1 / 1: every other
+    young collection escalates to generation 2), with the engine's policy on or off.  Returns HostGc.summary()."""
+    import gc
+
+    old = gc.get_threshold()
+    Sequence.counter = __import__("itertools").count()
+    eng = _scripted_engine(True, eos=-1, num_kvcache_blocks=80, max_num_batched_tokens=48, max_num_seqs=4,
+                           gc_control=gc_control)
+    eng.gc.young_every, eng.gc.mid_every = 4, 16
+    eng.gc.watch()
+    eng.gc.settle()
+    # CPython escalates to a full pass only when the objects pending since the last one exceed a quarter of what that one
+    # left in generation 2: make that generation small (freeze everything, then one full pass over nothing), for both runs
+    gc.freeze()
+    gc.collect()
+    gc.set_threshold(20, 1, 1)
+    try:
+        for i in range(8):
+            eng.add_request([i + 1] * 13, SamplingParams(max_tokens=40, ignore_eos=True, temperature=1.0))
+        done = _drain(eng)
+    finally:
+        gc.set_threshold(*old)
+        summary, stats = eng.gc.summary(), dict(eng.gc.stats)
+        eng.gc.release()
+        gc.unfreeze()
+    assert len(done) == 8
+    return summary, stats
+
+
+def test_no_full_collection_runs_inside_a_step():
+    """a generation-2 pass costs ~100 ms in a process that holds torch + a model, a decode step 1.4 ms.
+    With Config.gc_control the automatic collector is off inside step(); young collections run at the step's slack point,
+    full ones only when the engine has drained.  The control run (policy off, same pressure) does see full passes
+    inside steps - so the assertion is not vacuous."""
+    import gc
+
+    assert gc.isenabled()
+    control, _ = _run_with_gc_pressure(False)
+    assert control["full_in_step"] > 0, control
+    guarded, stats = _run_with_gc_pressure(True)
+    assert guarded["full_in_step"] == 0, guarded
+    assert stats["young"] > 0 and stats["mid"] > 0 and stats["full_idle"] >= 1, stats
+    assert stats["frozen_objects"] > 0
+    assert gc.isenabled() and gc.get_freeze_count() == 0  # release() gave the collector back
+
+
+def test_a_prefill_step_that_already_finished_is_stamped_before_the_next_one_is_launched():
+    """_step_prefill: when the queued step's tokens are already on the host (prefill_done), its first tokens are stamped
+    and postprocessed at once; the next prefill step is NOT queued first (its launch sequence costs the host milliseconds
+    that would land in those requests' TTFT) but scheduled by the following step() call."""
+    Sequence.counter = __import__("itertools").count()
+    eng = _scripted_engine(True, eos=-1, num_kvcache_blocks=60, max_num_batched_tokens=24, max_num_seqs=4)
+    order = []
+    runner = eng.model_runner
+    launch = runner.launch_prefill
+    runner.launch_prefill = lambda seqs: (order.append(("launch", [s.seq_id for s in seqs])), launch(seqs))[1]
+    runner.prefill_done = lambda handle: True
+    stamp = eng._stamp_first_tokens
+    eng._stamp_first_tokens = lambda seqs: (order.append(("stamp", [s.seq_id for s in seqs])), stamp(seqs))[1]
+    for i in range(4):
+        eng.add_request([i + 1] * 11, SamplingParams(max_tokens=3, ignore_eos=True, temperature=1.0))
+    eng.step()
+    eng.step()
+    assert order == [("launch", [0, 1]), ("stamp", [0, 1]), ("launch", [2, 3]), ("stamp", [2, 3])]
+    assert eng.prefill_lookahead_launches == 0 and eng._inflight_prefill is None
+    assert [r["queued_behind_previous"] for r in eng.prefill_trace] == [False, False]
+    assert all(r["stamp"] >= r["launch_end"] >= r["launch_start"] for r in eng.prefill_trace)
+    # ... and with the device still busy the next step IS queued first (the other tests of this section)
+    runner.prefill_done = lambda handle: False
+    order.clear()
+    for i in range(6):  # (six: the queued step must be closed by the token budget, not by the end of the queue)
+        eng.add_request([i + 9] * 11, SamplingParams(max_tokens=3, ignore_eos=True, temperature=1.0))
+    while eng.scheduler.waiting:
+        eng.step()
+    assert [o[0] for o in order[:3]] == ["launch", "launch", "stamp"]

@@ -43,11 +43,23 @@ def _run(fn_name: str, world: int = 2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, fn_name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in procs]
+    results = []
+    try:
+        for _ in procs:
+            results.append(q.get(timeout=240))
+            if results[-1][1] != "ok":
+                break  # the other ranks may wait for this one forever: report now
+    except Exception:  # queue.Empty
+        results.append((-1, "a rank did not report within 240 s"))
+    ok = len(results) == len(procs) and all(msg == "ok" for _, msg in results)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=60 if ok else 2)
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=10)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+    assert ok
 
 
 # ----------------------------------------------------------------------------- bodies (run in the ranks)
@@ -167,6 +179,73 @@ def _body_rpc_channel(rank, world, port):
     ch.close()
 
 
+def _body_rpc_channel_multipart(rank, world, port):
+    """a prefill step with prefix-cache hits can be far larger than a slot (the scheduler's budget
+    counts only the tokens behind the cached ones).  The slot is now the unit of transfer: the message travels in parts,
+    rank 0 waits for the workers' acknowledgements before it re-uses a slot, and a prefix-aware engine ships only the
+    tokens behind each sequence's cached prefix."""
+    from nanovllm.engine.rpc import StepChannel, slot_words
+    from nanovllm.engine.sequence import Sequence
+    from nanovllm.sampling_params import SamplingParams
+
+    def shared_prefix_step(n, length, cached, block):
+        seqs = []
+        for i in range(n):
+            s = Sequence([7] * cached + [1000 * i + j for j in range(length - cached)], SamplingParams(max_tokens=4),
+                         block_size=block)
+            s.block_table = list(range(s.num_blocks))
+            s.num_prefix_tokens = s.num_cached_tokens = cached
+            seqs.append(s)
+        return seqs
+
+    # (a) the ADVICE's case at the engine's own slot size: 57 sequences of 2048 tokens sharing 1792
+    cap = slot_words(16384, 100, 4096, 16)
+    ch = StepChannel(port + 1, world, rank, cap)
+    big = shared_prefix_step(57, 2048, 1792, 16)
+    if rank == 0:
+        assert sum(len(s.to_wire(True)) for s in big) > cap  # did not fit (and used to trip an assert) ...
+        ch.send("run", big, True)                            # ... several parts, all tokens
+        ch.skip_cached_prefix = True
+        ch.send("run", big, True)                            # the prefix-aware form: one part
+        assert ch.multipart_messages == 1 and ch.parts_sent == -(-sum(len(s.to_wire(True)) for s in big) // (cap - 8)) + 1
+        ch.send("run", big[:2], False)
+        dist.barrier()
+    else:
+        for full in (True, False):
+            method, seqs, is_prefill, _ = ch.recv()
+            assert method == "run" and is_prefill and len(seqs) == 57
+            for i, s in enumerate(seqs):
+                assert len(s) == 2048 and s.num_prefix_tokens == 1792 and len(s.block_table) == 128
+                assert s.token_ids[1792:] == [1000 * i + j for j in range(256)]
+                assert s.token_ids[:1792] == ([7] * 1792 if full else [0] * 1792)  # (the cached part is never read)
+        method, seqs, is_prefill, _ = ch.recv()
+        assert not is_prefill and [s.seq_id for s in seqs] == [big[0].seq_id, big[1].seq_id]
+        dist.barrier()
+    ch.close()
+    dist.barrier()
+    # (b) many parts through a tiny slot, the writer far ahead of the reader: flow control, not overwriting
+    ch = StepChannel(port + 2, world, rank, 96)
+    seqs = shared_prefix_step(6, 100, 64, 16)
+    if rank == 0:
+        ch.send("run", seqs, True)
+        ch.send("launch_decode", seqs[:3], False, extra=[2, 1, 0])
+        ch.send("exit")
+        assert ch.multipart_messages == 1 and ch.parts_sent > 2 * 4
+        dist.barrier()
+    else:
+        import time
+
+        time.sleep(0.3)  # rank 0 fills the ring and has to wait for this reader
+        method, got, is_prefill, _ = ch.recv()
+        assert is_prefill and [s.token_ids for s in got] == [s.token_ids for s in seqs]
+        assert [s.block_table for s in got] == [s.block_table for s in seqs]
+        method, got, _, extra = ch.recv()
+        assert method == "launch_decode" and extra == [2, 1, 0] and len(got) == 3
+        assert ch.recv()[0] == "exit"
+        dist.barrier()
+    ch.close()
+
+
 def _body_replicated_scheduling(rank, world, port):
     """Every rank can rebuild identical step metadata from the wire format (the reference's
     multi-rank story: deterministic replicated bookkeeping, ut/test_multi_rank_block_manager.py)."""
@@ -250,6 +329,11 @@ def test_tp4_moe_expert_shards():
 
 def test_tp2_rpc_channel():
     _run("_body_rpc_channel")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rpc_channel_messages_larger_than_a_slot(world):
+    _run("_body_rpc_channel_multipart", world)
 
 
 def test_tp2_replicated_metadata():
