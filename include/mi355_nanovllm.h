@@ -371,6 +371,20 @@ int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* resi
                           const mi_bf16* w, mi_bf16* y, mi_bf16* residual_out, int rows,
                           int cols, float eps, mi_stream stream);
 
+/* Instrumented forms of the decode chain's launches (tools/chain_timeline.py; the same results, separate kernel
+ * instantiations): every wave writes s_memrealtime (the chip-wide 100 MHz clock, comparable between launches) at
+ * entry / loads issued / data arrived / sums in LDS / barrier passed / stores issued / stores acknowledged into
+ * stamps[workgroup][wave][8] (uint64).  Workgroup = blockIdx.x + gridDim.x * blockIdx.y.
+ * mi_gemm_bf16_packed_ex: ksplit 0 = mi_gemm_bf16_packed without bias (epilogue 0 / 1: stamps[N/16 or N/32][16][8]),
+ * ksplit > 0 = mi_gemm_bf16_packed_splitk (stamps[N/16 * ksplit][K / ksplit / 64][8]); 17..32 rows and K-slices of 64
+ * per wave on 8, 12 or 16 waves only (the Qwen3-0.6B decode chain), MI_EUNSUPPORTED otherwise.
+ * mi_add_rmsnorm_splitk_ex: nsplit 4, <= 64 rows of <= 1024 columns (stamps[rows][4][8]). */
+int mi_gemm_bf16_packed_ex(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, float* partials, int M, int N,
+                           int K, int epilogue, int ksplit, uint64_t* stamps, mi_stream stream);
+int mi_add_rmsnorm_splitk_ex(const float* partials, int nsplit, const mi_bf16* residual, const mi_bf16* w,
+                             mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
+                             uint64_t* stamps, mi_stream stream);
+
 
 /* ---- plain-layout attention (csrc/attn_plain.hip) -------------------------
  * The same operators (attention.py:22-93, rotary_embedding.py:6-14) for the head geometries the fragment-native

@@ -6,10 +6,6 @@
 
 #include "mi_common.hpp"
 #include "kv_store.hpp"
-#include "warm_l2.hpp"
-#ifdef MI_EXPERIMENTS
-#include "mi355_nanovllm_experiments.h"
-#endif
 
 namespace mi {
 
@@ -189,19 +185,25 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
 // that every thread of the workgroup has work - PART + 2 loads per lane, all issued before the first use.
 // Same arithmetic and summation order per element; the sum of squares adds the lanes' partial sums in a
 // different grouping than the 8-wide form (both are fp32 sums of the same squares).
-// WARM: see warm_l2.hpp - the workgroups from block `first` on pull the weights of the NEXT launches into L2
-template <int PART, int WPR, bool WARM = false>
+// STAMP (mi_add_rmsnorm_splitk_ex, tools/chain_timeline.py): every wave records s_memrealtime (the chip-wide 100 MHz
+// clock) at seven points - entry / loads issued / data arrived / sum of squares in LDS / barrier passed / stores issued /
+// stores acknowledged - into stamps[row][wave][8].  A separate instantiation; the product kernel carries no stamp code.
+template <int PART, int WPR, bool STAMP = false>
 __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
     const float* __restrict__ part, const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
     uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows, int cols, float eps,
-    WarmArgs wa = WarmArgs{}) {
+    unsigned long long* __restrict__ stamps = nullptr) {
+  unsigned long long ts[8] = {};
+#define MI_NSTAMP(i)                                    \
+  do {                                                  \
+    if constexpr (STAMP) {                              \
+      __builtin_amdgcn_sched_barrier(0);                \
+      ts[i] = __builtin_amdgcn_s_memrealtime();         \
+      __builtin_amdgcn_sched_barrier(0);                \
+    }                                                   \
+  } while (0)
+  MI_NSTAMP(0);
   __shared__ float wave_ss[WPR];
-  __shared__ __attribute__((aligned(1024))) char warm_scratch[WARM ? WPR * 1024 : 16];
-  if (WARM && (int)blockIdx.x >= rows) {
-    static_assert(!WARM || WPR == 4, "a 4 KiB piece per workgroup round");
-    if ((int)blockIdx.x >= wa.first) warm_l2(wa, (int)blockIdx.x - wa.first, (int)gridDim.x - wa.first, threadIdx.x, warm_scratch);
-    return;
-  }
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nvec = cols >> 2;
   const int64_t off = (int64_t)row * cols;
@@ -213,6 +215,11 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
     p[sp] = *reinterpret_cast<const f32x4*>(part + ((int64_t)sp * rows + row) * cols + vec * 4);
   const u32x2 rr = *reinterpret_cast<const u32x2*>(residual + off + vec * 4);
   const u32x2 wr = *reinterpret_cast<const u32x2*>(w + vec * 4);
+  if constexpr (STAMP) {
+    MI_NSTAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI_NSTAMP(2);
+  }
   f32x4 s = p[0];
 #pragma unroll
   for (int sp = 1; sp < PART; ++sp) s += p[sp];
@@ -233,7 +240,9 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
   if (on) *reinterpret_cast<u32x2*>(residual_out + off + vec * 4) = ro;
   ss = wave_sum(on ? ss : 0.f);
   if (lane == 0) wave_ss[wave] = ss;
+  MI_NSTAMP(3);
   __syncthreads();
+  MI_NSTAMP(4);
   float tot = wave_ss[0];
 #pragma unroll
   for (int wv = 1; wv < WPR; ++wv) tot += wave_ss[wv];
@@ -246,6 +255,17 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
     o[j] = pack_bf(a, b);
   }
   if (on) *reinterpret_cast<u32x2*>(y + off + vec * 4) = o;
+  if constexpr (STAMP) {
+    MI_NSTAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI_NSTAMP(6);
+    if (stamps != nullptr && lane == 0) {
+      unsigned long long* dst = stamps + ((int64_t)row * WPR + wave) * 8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[q] = ts[q];
+    }
+  }
+#undef MI_NSTAMP
 }
 
 template <bool ADD, int PART = 0>
@@ -793,74 +813,6 @@ extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const m
                               S(stream));
 }
 
-#ifdef MI_EXPERIMENTS  // include/mi355_nanovllm_experiments.h: measured slower, not in the default build
-// the same as a launch of its own (a forked graph branch beside the tensor-parallel seam, models/qwen3.py)
-static __global__ __launch_bounds__(256) void warm_l2_kernel(const WarmArgs wa) {
-  __shared__ __attribute__((aligned(1024))) char scratch[4096];
-  warm_l2(wa, (int)blockIdx.x, (int)gridDim.x, threadIdx.x, scratch);
-}
-
-extern "C" int mi_warm_l2(const void* warm0, size_t warm0_bytes, int warm0_tile_bytes, const void* warm1,
-                          size_t warm1_bytes, int warm1_tile_bytes, int n_workgroups, mi_stream stream) {
-  const void* wp[2] = {warm0, warm1};
-  const size_t wb[2] = {warm0_bytes, warm1_bytes};
-  const int wt[2] = {warm0_tile_bytes, warm1_tile_bytes};
-  if ((!warm0 && !warm1) || n_workgroups < 8 || n_workgroups % 8) return MI_EINVAL;
-  WarmArgs wa{};
-  for (int r = 0; r < 2; ++r) {
-    if (wp[r] && (!aligned16(wp[r]) || wt[r] <= 0 || wt[r] % 4096 || wb[r] % (size_t)wt[r] || wb[r] >= ((size_t)1 << 32)))
-      return MI_EINVAL;
-    wa.base[r] = static_cast<const char*>(wp[r]);
-    wa.bytes[r] = (uint32_t)wb[r];
-    wa.tile_bytes[r] = (uint32_t)wt[r];
-  }
-  hipLaunchKernelGGL(warm_l2_kernel, dim3(n_workgroups), dim3(256), 0, S(stream), wa);
-  return check_launch();
-}
-
-// mi_add_rmsnorm_splitk for decode-sized inputs with the otherwise idle CUs warming L2 for the launches behind it
-extern "C" int mi_add_rmsnorm_splitk_warm(const float* partials, int nsplit, const mi_bf16* residual, const mi_bf16* w,
-                                          mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
-                                          const void* warm0, size_t warm0_bytes, int warm0_tile_bytes, const void* warm1,
-                                          size_t warm1_bytes, int warm1_tile_bytes, mi_stream stream) {
-  if (!partials || !residual || !w || !y || !residual_out || rows < 0 || cols <= 0 || nsplit < 1) return MI_EINVAL;
-  if (!aligned16(partials) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
-    return MI_EINVAL;
-  const void* wp[2] = {warm0, warm1};
-  const size_t wb[2] = {warm0_bytes, warm1_bytes};
-  const int wt[2] = {warm0_tile_bytes, warm1_tile_bytes};
-  for (int r = 0; r < 2; ++r)
-    if (wp[r] && (!aligned16(wp[r]) || wt[r] <= 0 || wt[r] % 4096 || wb[r] % (size_t)wt[r] || wb[r] >= ((size_t)1 << 32)))
-      return MI_EINVAL;
-  // the shapes of the four-columns-per-thread kernel only (hidden <= 1024, <= 64 rows, the decode chain)
-  if (rows > 64 || cols > 4 * 64 * 4 || cols % 4) return MI_EUNSUPPORTED;
-  if (rows == 0) return MI_OK;
-  WarmArgs wa{};
-  for (int r = 0; r < 2; ++r) {
-    wa.base[r] = static_cast<const char*>(wp[r]);
-    wa.bytes[r] = (uint32_t)wb[r];
-    wa.tile_bytes[r] = (uint32_t)wt[r];
-  }
-  wa.first = (rows + 7) & ~7;
-  const int n_warm = (wp[0] || wp[1]) ? ((256 - wa.first) & ~7) : 0;
-  const int grid = n_warm > 0 ? wa.first + n_warm : rows;
-#define WARM_CASE(NS)                                                                                                 \
-  case NS:                                                                                                            \
-    hipLaunchKernelGGL((add_rmsnorm_splitk_rows4_kernel<NS, 4, true>), dim3(grid), dim3(256), 0, S(stream), partials, \
-                       residual, w, y, residual_out, rows, cols, eps, wa);                                            \
-    return check_launch()
-  switch (nsplit) {
-    WARM_CASE(1);
-    WARM_CASE(2);
-    WARM_CASE(3);
-    WARM_CASE(4);
-    WARM_CASE(6);
-    WARM_CASE(8);
-    default: return MI_EUNSUPPORTED;
-  }
-#undef WARM_CASE
-}
-#endif  // MI_EXPERIMENTS
 
 extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi_bf16* residual, const mi_bf16* w,
                                      mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
@@ -902,6 +854,20 @@ extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi
     default: return MI_EUNSUPPORTED;
   }
 #undef SPLITK_CASE
+}
+
+// Instrumented form of mi_add_rmsnorm_splitk's decode kernel (tools/chain_timeline.py): stamps[rows][4 waves][8]
+extern "C" int mi_add_rmsnorm_splitk_ex(const float* partials, int nsplit, const mi_bf16* residual, const mi_bf16* w,
+                                        mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
+                                        uint64_t* stamps, mi_stream stream) {
+  if (!partials || !residual || !w || !y || !residual_out || !stamps || rows < 0 || cols <= 0) return MI_EINVAL;
+  if (!aligned16(partials) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
+    return MI_EINVAL;
+  if (nsplit != 4 || rows > 64 || cols > 4 * 64 * 4 || cols % 4) return MI_EUNSUPPORTED;  // the decode chain's form only
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL((add_rmsnorm_splitk_rows4_kernel<4, 4, true>), dim3(rows), dim3(256), 0, S(stream), partials, residual,
+                     w, y, residual_out, rows, cols, eps, reinterpret_cast<unsigned long long*>(stamps));
+  return check_launch();
 }
 
 static int heads_grid(int64_t head_slots) { return (int)((head_slots * 8 + 255) / 256); }

@@ -98,6 +98,29 @@ extern "C" int mi_gemm_bf16_packed_splitk(const mi_bf16* x, const mi_bf16* w_pac
   return pick_mt<1, 1, EPI_PARTIAL>(GemmArgs{x, w_packed, nullptr, nullptr, partials, M, N, K, ksplit, S(stream)});
 }
 
+// Instrumented forms of mi_gemm_bf16_packed / mi_gemm_bf16_packed_splitk (tools/chain_timeline.py): the same launch
+// with every wave's s_memrealtime stamps in stamps[workgroups][waves][8].  Only the decode chain's own configurations
+// (17..32 rows, K / ksplit a multiple of 64 up to 1024: 8, 12 or 16 waves) have an instrumented kernel.
+extern "C" int mi_gemm_bf16_packed_ex(const mi_bf16* x, const mi_bf16* w_packed, mi_bf16* y, float* partials, int M,
+                                      int N, int K, int epilogue, int ksplit, uint64_t* stamps, mi_stream stream) {
+  const void* out = ksplit > 0 ? static_cast<const void*>(partials) : static_cast<const void*>(y);
+  int rc = check_gemm(x, w_packed, out, M, N, K);
+  if (rc != MI_OK) return rc;
+  if (!stamps || (epilogue != 0 && epilogue != 1) || (epilogue == 1 && ksplit > 0)) return MI_EINVAL;
+  if (epilogue == 1 && N % 32) return MI_EUNSUPPORTED;
+  auto* st = reinterpret_cast<unsigned long long*>(stamps);
+  bool ok;
+  if (ksplit > 0) {
+    if (ksplit > 16 || K % (32 * ksplit)) return MI_EUNSUPPORTED;
+    ok = launch_stamped<EPI_PARTIAL>(GemmArgs{x, w_packed, nullptr, nullptr, partials, M, N, K, ksplit, S(stream)}, st);
+  } else if (epilogue == 1) {
+    ok = launch_stamped<EPI_SILU>(GemmArgs{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)}, st);
+  } else {
+    ok = launch_stamped<EPI_NONE>(GemmArgs{x, w_packed, nullptr, y, nullptr, M, N, K, 1, S(stream)}, st);
+  }
+  return ok ? check_launch() : MI_EUNSUPPORTED;
+}
+
 // ---- fp8 (e4m3) weights, bf16 activations ----------------------------------------------------------
 namespace mi {
 // dst[((tn * K/64 + tk) * 64 + lane) * 16 + 8 h + e] = src[(16 tn + lane % 16) * K + 64 tk + 32 h + 8 (lane / 16) + e]

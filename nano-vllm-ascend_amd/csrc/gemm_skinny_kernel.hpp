@@ -70,11 +70,25 @@ __device__ __forceinline__ void x_lines_to_frags(const u32x4 (&stage)[(STEPS + 1
 constexpr int x_slab_bytes(int MT) { return MT * 16 * 64 * 2; }
 
 // WF: weight format - 0 row-major bf16, 1 fragment-native bf16, 2 fragment-native fp8 (e4m3) + per-row scale
-template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS>
+// STAMP (mi_gemm_bf16_packed_ex, tools/chain_timeline.py): every wave records s_memrealtime (the chip-wide 100 MHz clock)
+// at seven points of its life into stamps[workgroup][wave][8] - entry / loads issued / data arrived / K-slice sums in
+// LDS / barrier passed / stores issued / stores acknowledged.  A separate instantiation: the product kernels carry
+// no stamp code.
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS, bool STAMP = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
     uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M_all, int N, int K,
-    PickArgs pk) {
+    PickArgs pk, unsigned long long* __restrict__ stamps = nullptr) {
+  unsigned long long ts[8] = {};
+#define MI_GSTAMP(i)                                    \
+  do {                                                  \
+    if constexpr (STAMP) {                              \
+      __builtin_amdgcn_sched_barrier(0);                \
+      ts[i] = __builtin_amdgcn_s_memrealtime();         \
+      __builtin_amdgcn_sched_barrier(0);                \
+    }                                                   \
+  } while (0)
+  MI_GSTAMP(0);  // entry
   // more than 64 activation rows: blockIdx.z walks them in chunks of 64 (the weight stream of the second and
   // later chunks of a row tile is served by L2 / the Infinity Cache: the chunks of a tile are dispatched together)
   const int m0 = (int)blockIdx.z * kSkinnyRows;
@@ -164,6 +178,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
       if (LINES) {
         u32x4 stage[(STEPS + 1) / 2][MT * 2];
         issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, stage);
+        if constexpr (STAMP) {
+          if (k == 0) {
+            MI_GSTAMP(1);  // every load of the first block issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MI_GSTAMP(2);  // ... and arrived
+          }
+        }
         x_lines_to_frags<MT, STEPS>(stage, slab, lane, bfrag);
       } else {
 #pragma unroll
@@ -188,7 +209,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(red) + wave * SLOT + ((t * MT + m) * 64 + lane) * 16) = acc[t][m];
+  MI_GSTAMP(3);  // this wave's K-slice sums are in LDS
   __syncthreads();
+  MI_GSTAMP(4);  // every wave's are
   // each (row tile, m-tile, lane) result is finished by one thread, summing K-slices in wave order
   constexpr int ITEMS = (EPI == EPI_SILU ? 1 : RT) * MT * 64;
   __shared__ float pick_key[EPI == EPI_PICK ? MT * 16 : 1][RT * 4];
@@ -267,6 +290,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
       }
     }
   }
+  if constexpr (STAMP) {
+    MI_GSTAMP(5);  // reduced, stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI_GSTAMP(6);  // stores acknowledged
+    if (stamps != nullptr && lane == 0) {
+      const int64_t wg = (int64_t)blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+      unsigned long long* dst = stamps + (wg * WAVES + wave) * 8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[q] = ts[q];
+    }
+  }
+#undef MI_GSTAMP
   if (EPI == EPI_PICK) {
     __syncthreads();
     if ((int)threadIdx.x < M) {
@@ -597,6 +632,31 @@ struct GemmArgs {
   const float* scale = nullptr;  // fp8 weights: one fp32 factor per weight row
   PickArgs pick = PickArgs{nullptr, nullptr, nullptr, 0};
 };
+
+// The instrumented instantiations (STAMP): the decode chain's own configurations at up to 32 rows only - K-slices of 64
+// per wave, 8 / 12 / 16 waves (tools/chain_timeline.py).  false: no instrumented kernel for this shape.
+template <int EPI>
+static bool launch_stamped(const GemmArgs& a, unsigned long long* stamps) {
+  constexpr int MT = 2, RT = EPI == EPI_SILU ? 2 : 1;
+  if (a.M < 17 || a.M > 32 || a.bias || a.K % a.ksplit) return false;
+  const int kper = a.K / a.ksplit;
+  if (kper % 64) return false;
+  const int waves = kper / 64;
+  const int tiles = a.N / 16;
+  const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit, 1);
+#define MI_STAMPED_GO(W)                                                                                            \
+  do {                                                                                                              \
+    const size_t slot = (size_t)RT * MT * 1024 > (size_t)x_slab_bytes(MT) ? (size_t)RT * MT * 1024 : (size_t)x_slab_bytes(MT); \
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, W, 2, 1, EPI, false, true>), grid, dim3(W * 64), W * slot, a.st, \
+                       a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick, stamps);                      \
+    return true;                                                                                                    \
+  } while (0)
+  if (waves == 16) MI_STAMPED_GO(16);
+  if (EPI == EPI_PARTIAL && waves == 8) MI_STAMPED_GO(8);
+  if (EPI == EPI_PARTIAL && waves == 12) MI_STAMPED_GO(12);
+#undef MI_STAMPED_GO
+  return false;
+}
 
 template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
 static void launch(const GemmArgs& a) {

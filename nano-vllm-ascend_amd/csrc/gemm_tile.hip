@@ -834,20 +834,6 @@ extern "C" int mi_gemm_bf16_ex(const mi_bf16* x, int64_t ldx, const mi_bf16* w, 
     // the same kernel on 32 x 32 x 16 MFMAs
     case kMfma32: return launch_tile<TEPI_NONE, false, kMfma32>(a, st);
     case kMfma32 + kDirectStores: return launch_tile<TEPI_NONE, false, kMfma32 + kDirectStores>(a, st);
-#ifdef MI_EXPERIMENTS  // timing-only ablations and clock stamps (tools/gemm_bench.py GEMM_ABLATE=1, tools/gemm_clock.py):
-                       // y is NOT the product afterwards - an EXPERIMENTS=1 build only
-    case 32: return launch_tile<TEPI_NONE, false, 32>(a, st);
-    case 64: return launch_tile<TEPI_NONE, false, 64>(a, st);
-    case 96: return launch_tile<TEPI_NONE, false, 96>(a, st);
-    case 224: return launch_tile<TEPI_NONE, false, 224>(a, st);
-    case 512: return launch_tile<TEPI_NONE, false, 512>(a, st);
-    case 4096 + 512: return launch_tile<TEPI_NONE, false, 4096 + 512>(a, st);
-    case kMfma32 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 512>(a, st);
-    case kMfma32 + 4096 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 4096 + 512>(a, st);
-    case kMfma32 + 256: return launch_tile<TEPI_NONE, false, kMfma32 + 256>(a, st);    // pieces never waited for
-    case kMfma32 + 1024: return launch_tile<TEPI_NONE, false, kMfma32 + 1024>(a, st);  // feed from 64 KiB of L2
-    case kMfma32 + 1024 + 512: return launch_tile<TEPI_NONE, false, kMfma32 + 1024 + 512>(a, st);
-#endif
     // the eight-wave kernel of rounds 2-3 and its variants
     case kEightWaves: return launch_tile<TEPI_NONE, false, kEightWaves>(a, st);
     case kEightWaves + 2: return launch_tile<TEPI_NONE, false, kEightWaves + 2>(a, st);

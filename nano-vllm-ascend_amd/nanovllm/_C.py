@@ -112,6 +112,8 @@ _SIGNATURES = {
     "mi_pack_weight_rows4": (c_int, [_p, _p, c_int, c_int, _p]),
     "mi_gemm_bf16_rows4": (c_int, [_p, _p, _p, c_int, c_int, c_int, _p]),
     "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
+    "mi_add_rmsnorm_splitk_ex": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, _p]),
+    "mi_gemm_bf16_packed_ex": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p, _p]),
     "mi_moe_shapes_supported": (c_int, [c_int, c_int]),
     "mi_kv_store_plain": (c_int, [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p]),
     "mi_rope_plain": (c_int, [_p, _p, c_int64, _p, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
@@ -162,21 +164,6 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch: fail loudly
     _fn.restype = _res
     _fn.argtypes = _args
-
-# measured-and-lost experiments (include/mi355_nanovllm_experiments.h): present only in a library built with
-# `make EXPERIMENTS=1`; the product path never calls them
-_EXPERIMENT_SIGNATURES = {
-    "mi_warm_l2": (c_int, [_p, c_size_t, c_int, _p, c_size_t, c_int, c_int, _p]),
-    "mi_mlp_half_fused": (c_int, [_p, _p, _p, c_float, _p, _p, _p, _p, _p, _p, _p, c_int, c_int, c_int, _p]),
-    "mi_add_rmsnorm_splitk_warm": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, c_size_t, c_int, _p,
-                                           c_size_t, c_int, _p]),
-}
-HAS_EXPERIMENTS = all(hasattr(lib, _n) for _n in _EXPERIMENT_SIGNATURES)
-if HAS_EXPERIMENTS:
-    for _name, (_res, _args) in _EXPERIMENT_SIGNATURES.items():
-        _fn = getattr(lib, _name)
-        _fn.restype = _res
-        _fn.argtypes = _args
 
 # ---- tuning knobs (include/mi355_nanovllm.h: mi_tuning_knob).  The library never reads the environment; the A/B
 # switches documented in tools/README.md are mapped onto mi_set_tuning() here, once, at import.

@@ -215,17 +215,6 @@ class Qwen3DecoderLayer(nn.Module):
         return hidden_states, residual
 
 
-_SEAM_STREAMS: dict = {}
-
-
-def _seam_stream(device):
-    """one side stream per device for the forked branch of the tensor-parallel seam (MI355_SEAM_OVERLAP)"""
-    st = _SEAM_STREAMS.get(device)
-    if st is None:
-        st = _SEAM_STREAMS[device] = torch.cuda.Stream(device=device)
-    return st
-
-
 class Qwen3Model(nn.Module):
     def __init__(self, config, fused: bool = True, layer_factory=None, **layer_overrides) -> None:
         """layer_factory(layer_idx) -> decoder layer: models whose layers differ (Qwen3-MoE) build ONLY their own
@@ -327,26 +316,10 @@ class Qwen3Model(nn.Module):
                 y = all_reduce_sum(y)
             return y, ("ranks" if fused_seam else False)
 
-        # EXPERIMENT (nanovllm/experiments.py, library built with EXPERIMENTS=1): the norm launch's idle CUs warm L2 with
-        # the next GEMMs' weights.  Measured: 1.52-1.54 ms per decode step with it, 1.50-1.51 without: off unless asked
-        # for ("first": only the column-parallel projection's weights)
-        warm_l2 = os.environ.get("MI355_WARM_L2", "0") != "0"
-        warm_n = 1 if os.environ.get("MI355_WARM_L2") == "first" else 2
-        overlap_env = os.environ.get("MI355_SEAM_OVERLAP", "0") != "0"
-        if warm_l2 or overlap_env:
-            from nanovllm import experiments
-
-            experiments.require()
-
-        def add_norm(y, is_partials, res, ln, warm=()):
+        def add_norm(y, is_partials, res, ln):
             """is_partials: True = fp32 split-K partials of this rank (TP 1); "ranks" = bf16 partial sums that
-            still have to be summed over the TP ranks (fused seam); False = a finished bf16 tensor.
-            warm: the linear layers this norm feeds - the norm launch (rows workgroups on 256 CUs) pulls their
-            packed weights into L2 with its idle CUs."""
+            still have to be summed over the TP ranks (fused seam); False = a finished bf16 tensor."""
             if is_partials is True:
-                if warm_l2:
-                    return experiments.add_rmsnorm_splitk_warm(y, res, ln.weight, ln.eps,
-                                                               [m.weight_packed for m in warm][:warm_n])
                 return ops.add_rmsnorm_splitk(y, res, ln.weight, ln.eps)
             if is_partials == "ranks":  # all-reduce over xGMI + add + RMSNorm in one launch
                 return xgmi.allreduce_add_rmsnorm(y, res, ln.weight, ln.eps)
@@ -362,26 +335,9 @@ class Qwen3Model(nn.Module):
                 return ops.gemm_tile(x, w, silu_mul=silu_mul)
             return ops.gemm_packed(x, lin.weight_packed, silu_mul=silu_mul)
 
-        # SURVEY 8(f)1, the tensor-parallel seam (linear.py:149-153): the only work that can overlap the all-reduce is the
-        # NEXT projections' weight stream (their activations are the all-reduce's result).  MI355_SEAM_OVERLAP=1 forks the
-        # stream - under capture: a parallel graph branch - behind the row-parallel GEMM, queues mi_warm_l2 for those
-        # weights beside mi_allreduce_add_rmsnorm and joins before the column-parallel GEMM.  Off by default: on one GPU
-        # the same warming inside the norm launch measured slower (MI355_WARM_L2); whether the longer seam on links
-        # changes that is for the 8-GPU box to say.
-        overlap = fused_seam and overlap_env
-        side = _seam_stream(h.device) if overlap else None
-
-        def norm_linear(y, is_partials, res, ln, lin, silu_mul=False, then=None):
-            """linear(rmsnorm(y + res)) -> (out, new residual); `then`: the row-parallel projection behind it"""
-            forked = overlap and is_partials == "ranks"
-            if forked:
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    experiments.warm_l2([m.weight_packed for m in ((lin,) if then is None else (lin, then))])
-            x, res = add_norm(y, is_partials, res, ln, warm=(lin,) if then is None else (lin, then))
-            if forked:
-                main.wait_stream(side)
+        def norm_linear(y, is_partials, res, ln, lin, silu_mul=False):
+            """linear(rmsnorm(y + res)) -> (out, new residual)"""
+            x, res = add_norm(y, is_partials, res, ln)
             return column_parallel(x, lin, silu_mul), res
 
         residual, parts, is_partials = None, None, False
@@ -392,15 +348,14 @@ class Qwen3Model(nn.Module):
                 residual = h
                 qkv = column_parallel(ops.rmsnorm(h, ln1.weight, ln1.eps), attn.qkv_proj)
             else:
-                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj, then=attn.o_proj)
+                qkv, residual = norm_linear(parts, is_partials, residual, ln1, attn.qkv_proj)
             o = attend(attn, qkv)
             parts, is_partials = row_parallel(o, attn.o_proj)
             if hasattr(mlp, "experts"):  # sparse block (models/qwen3_moe.py): five launches over expert-sorted pairs
                 x, residual = add_norm(parts, is_partials, residual, ln2)
                 parts, is_partials = mlp(x), False  # summed over the ranks inside the block (before the combine)
             else:
-                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj, silu_mul=True,
-                                            then=mlp.down_proj)
+                act, residual = norm_linear(parts, is_partials, residual, ln2, mlp.gate_up_proj, silu_mul=True)
                 parts, is_partials = row_parallel(act, mlp.down_proj)
         x, _ = add_norm(parts, is_partials, residual, self.norm)
         return x

@@ -817,3 +817,41 @@ def moe_forward(x, router_logits, gate_up_packed, down_packed, top_k: int, all_r
     out = torch.empty((T, H), dtype=_BF16, device=dev)
     check(lib.mi_moe_combine(ptr(y), ptr(w), ptr(out), T, top_k, H, stream()), "mi_moe_combine")
     return out, ids, w
+
+
+# ---- instrumented forms of the decode chain's launches (tools/chain_timeline.py) --------------------------------
+def gemm_packed_stamped(x, w_packed, stamps, silu_mul: bool = False, ksplit: int = 0, out=None):
+    """mi_gemm_bf16_packed_ex: gemm_packed (ksplit 0) / gemm_packed_splitk (ksplit > 0) with every wave's clock stamps
+    in stamps[workgroups][waves][8] (int64).  The decode chain's own configurations only."""
+    require_gpu(x, w_packed, stamps)
+    _bf16(x, w_packed)
+    assert stamps.dtype == torch.int64 and stamps.is_contiguous()
+    M, K = x.shape
+    N = w_packed.shape[0]
+    if ksplit:
+        if out is None:
+            out = torch.empty((ksplit, M, N), dtype=torch.float32, device=x.device)
+        y, part = None, out
+    else:
+        if out is None:
+            out = torch.empty((M, N // 2 if silu_mul else N), dtype=_BF16, device=x.device)
+        y, part = out, None
+    check(lib.mi_gemm_bf16_packed_ex(ptr(x), ptr(w_packed), ptr(y), ptr(part), M, N, K, int(silu_mul), ksplit,
+                                     ptr(stamps), stream()), "mi_gemm_bf16_packed_ex")
+    return out
+
+
+def add_rmsnorm_splitk_stamped(partials, residual, w, eps: float, stamps, out=None, residual_out=None):
+    """mi_add_rmsnorm_splitk_ex: add_rmsnorm_splitk with every wave's clock stamps in stamps[rows][4][8] (int64)."""
+    require_gpu(partials, residual, w, stamps)
+    _bf16(residual, w)
+    assert stamps.dtype == torch.int64 and stamps.is_contiguous()
+    nsplit, cols = partials.shape[0], residual.shape[-1]
+    rows = residual.numel() // cols
+    if out is None:
+        out = torch.empty_like(residual)
+    if residual_out is None:
+        residual_out = torch.empty_like(residual)
+    check(lib.mi_add_rmsnorm_splitk_ex(ptr(partials), nsplit, ptr(residual), ptr(w), ptr(out), ptr(residual_out), rows,
+                                       cols, float(eps), ptr(stamps), stream()), "mi_add_rmsnorm_splitk_ex")
+    return out, residual_out

@@ -10,7 +10,6 @@ import torch
 from conftest import bf16_from_bits as bf
 from model_configs import QWEN3_32B_2L, MID, MID_LLAMA_HD64, TINY, TINY_LLAMA, TINY_LLAMA_HD64, TINY_MOE, TINY_QWEN2_HD64, make_model_dir
 
-from nanovllm._C import HAS_EXPERIMENTS as _HAS_EXPERIMENTS
 
 pytestmark = pytest.mark.gpu
 
@@ -311,6 +310,9 @@ def test_prefill_steps_queued_behind_one_another_keep_the_tokens():
                   decode_lookahead=lookahead)
         try:
             llm.prefill_lookahead_min_tokens = 0  # (the product default only queues behind steps of >= 4096 tokens)
+            # ... and a step whose tokens have already arrived is collected before the next one is launched; these
+            # 256-token steps finish while the host is still launching them: make every step look unfinished
+            llm.model_runner.prefill_done = lambda handle: False
             outs = llm.generate(prompts, sps, use_tqdm=False)
             return [o["token_ids"] for o in outs], [o["cache_tokens"] for o in outs], llm.prefill_lookahead_launches
         finally:
@@ -387,36 +389,6 @@ def test_tp_ranks_on_one_gpu_match_tp1(monkeypatch, model, enforce_eager, tol, w
     assert agree >= 17, (toks1, toks2)  # 18 tokens; allow one near-tie flip
     if agree == 18 or model == "MID":  # the last step's logits: comparable if both runs fed the same tokens
         assert (logits1 - logits2).abs().max().item() <= tol
-
-
-@pytest.mark.skipif(not _HAS_EXPERIMENTS, reason="library built without -DMI_EXPERIMENTS")
-def test_tp_seam_overlap_branch_keeps_the_tokens(monkeypatch):
-    """MI355_SEAM_OVERLAP=1: a forked graph branch warms L2 with the next projections' weights beside
-    the fused all-reduce + add + RMSNorm seam.  Two ranks on one GPU, hipGraph decode: the same tokens as without it."""
-    import socket
-
-    from nanovllm import LLM, SamplingParams
-
-    gen = torch.Generator().manual_seed(8)
-    prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in (9, 33, 70, 5)]
-    sp = SamplingParams(max_tokens=8, ignore_eos=True, greedy=True)
-    monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
-
-    def run(overlap):
-        monkeypatch.setenv("MI355_SEAM_OVERLAP", "1" if overlap else "0")
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
-                  max_model_len=512, num_kvcache_blocks=64, enforce_eager=False, warmup=False, synthetic_seed=3,
-                  tensor_parallel_size=2, hccl_port=port)
-        try:
-            assert llm.model_runner.xgmi is not None and llm.model_runner.graphs
-            return [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
-        finally:
-            llm.exit()
-
-    assert run(True) == run(False)
 
 
 def test_tp_decode_picks_tokens_in_the_graph(monkeypatch):

@@ -46,20 +46,12 @@ def main():
     ]
     E8 = 1 << 20  # the eight-wave ping-pong kernel of rounds 2-3 (kept for comparison)
     variants = {"tile": 0, "xcd_rect": 4, "direct_stores": 1 << 18, "mfma_32x32x16": 1 << 19, "eight_wave_r03": E8}
-    if _C.HAS_EXPERIMENTS:  # timing only (y is not the product): an EXPERIMENTS=1 build
-        variants.update({"no_stores(timing only)": 512, "mfma_32x32x16_no_stores": (1 << 19) + 512})
     if os.environ.get("GEMM_QUICK"):  # the four prefill projections only
         shapes = shapes[:4]
     if os.environ.get("GEMM_MID"):  # the two kernels side by side over the mid-size shapes
         variants = {"tile": 0, "mid128": 65536, "mid128_2stage": 65538, "mid128_3stage": 65539}
         shapes = [(M, N, K, f"{name}@{M}") for M in ((16384,) if os.environ.get("GEMM_MID") == "big" else (128, 256, 512, 1024, 2048, 4096))
                   for N, K, name in ((4096, 1024, "qkv"), (1024, 2048, "o_proj"), (6144, 1024, "gate_up"), (1024, 3072, "down"))]
-    if os.environ.get("GEMM_ABLATE"):  # timing-only variants (wrong results): where the K loop's time goes
-        if not _C.HAS_EXPERIMENTS:
-            sys.exit("GEMM_ABLATE=1 needs a library built with `make -C nano-vllm-ascend_amd/csrc EXPERIMENTS=1`")
-        variants = {"tile": 0, "no_dma": 32, "no_next_step_reads": 64, "no_dma_no_reads": 96, "mfma_only_no_barriers": 224,
-                    "no_stores": 512, "mfma32_pieces_never_waited": (1 << 19) + 256, "mfma32_l2_resident_feed": (1 << 19) + 1024,
-                    "mfma32_l2_resident_feed_no_stores": (1 << 19) + 1536}
     rows = []
     for M, N, K, label in shapes:
         g = torch.Generator().manual_seed(M + N + K)

@@ -104,45 +104,6 @@ def prefill_attention_order():
         print(f"  {k}: {v}   best {flops / best / 1e6:.0f} TFLOP/s")
 
 
-def mlp_half():
-    """the MLP half of a Qwen3-0.6B decode layer (bs 32) as three launches and as ONE persistent
-    launch with in-launch hand-offs (csrc/mlp_half.hip), over 4 rotating layers' weights, alternating rounds."""
-    from nanovllm import experiments  # needs the library built with EXPERIMENTS=1
-
-    experiments.require()
-    B, H, I, L = 32, 1024, 3072, 4
-    gu = [ops.pack_weight((torch.randn(2 * I, H, device=DEV) * 0.02).bfloat16()) for _ in range(L)]
-    dn = [ops.pack_weight((torch.randn(H, I, device=DEV) * 0.02).bfloat16()) for _ in range(L)]
-    nw = torch.ones(H, device=DEV).bfloat16()
-    parts = torch.randn(4, B, H, device=DEV)
-    res_ = torch.randn(B, H, device=DEV).bfloat16()
-    sync = torch.zeros(8, dtype=torch.int32, device=DEV)
-    scratch = (torch.empty_like(res_), torch.empty(B, H, dtype=torch.bfloat16, device=DEV),
-               torch.empty(B, I, dtype=torch.bfloat16, device=DEV), torch.empty(4, B, H, device=DEV))
-
-    def three(l):
-        xn, r = ops.add_rmsnorm_splitk(parts, res_, nw, 1e-6)
-        a = ops.gemm_packed(xn, gu[l], silu_mul=True)
-        return ops.gemm_packed_splitk(a, dn[l], 4), r
-
-    def fused(l):
-        return experiments.mlp_half_fused(parts, res_, nw, 1e-6, gu[l], dn[l], sync, scratch)
-
-    p3, r3 = three(0)
-    pf, rf = fused(0)
-    torch.cuda.synchronize()
-    same = bool(torch.equal(p3, pf) and torch.equal(r3.view(torch.int16), rf.view(torch.int16)))
-    res = {"three launches": [], "one persistent launch": []}
-    for rnd in range(4):
-        res["three launches"].append(round(timeit(three, L, reps=4) * 1e6, 2))
-        res["one persistent launch"].append(round(timeit(fused, L, reps=4) * 1e6, 2))
-    torch.cuda.synchronize()
-    print(f"MLP half of a decode layer (add+RMSNorm -> gate_up+SwiGLU -> down split-K), bs 32, us per layer, four alternating rounds")
-    for k, v in res.items():
-        print(f"  {k}: {v}")
-    print(f"  outputs bit-identical: {same}; hand-off error word: {int(sync[6])}")
-
-
 def plain_attention():
     """The reference README's small-model head geometries (KBENCH_ONLY=plain): decode bs 32 x ctx 1024 (HBM bytes = K + V
     rows of every context token) and prefill 16 x 1024 tokens, on the plain-layout family (csrc/attn_plain.hip, the
@@ -294,8 +255,6 @@ def main():
         return chain_32b_shard()
     if os.environ.get("KBENCH_ONLY") == "plain":
         return plain_attention()
-    if os.environ.get("KBENCH_ONLY") == "mlp_half":
-        return mlp_half()
     if os.environ.get("KBENCH_ONLY") == "prefill_order":
         return prefill_attention_order()
     if os.environ.get("KBENCH_ONLY") == "prefill":
