@@ -271,6 +271,25 @@ def prefill_flops(n_seqs: int, seq_len: int, cfg: dict) -> float:
     return layers * (n_seqs * seq_len * per_token + n_seqs * attn) + 2 * n_seqs * h * cfg["vocab_size"]
 
 
+def one_gpu_reference():
+    """The newest committed one-GPU line of this bench (profiles/r*bench*.json, n_gpus == 1, the same workload): what
+    north_star's ">= 6x aggregate at 8 GPUs" is a multiple of.  -> (tokens/s, file name) or (None, None)."""
+    import glob
+
+    best = (None, None, -1.0)
+    for path in glob.glob(os.path.join(REPO, "profiles", "r*bench*.json")):
+        try:
+            with open(path) as f:
+                line = json.loads(f.read().strip().splitlines()[-1])
+            if line.get("n_gpus") == 1 and line.get("config", {}).get("batch") == BATCH and not line.get("dry_run"):
+                key = (os.path.basename(path)[:3], os.path.getmtime(path))  # round first, then file time
+                if best[0] is None or key > best[2]:
+                    best = (float(line["value"]), os.path.basename(path), key)
+        except (OSError, ValueError, KeyError, IndexError, TypeError):
+            continue
+    return best[0], best[1]
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no torchrun around it: start the N ranks ourselves (the same command
     line the driver uses).  On a box with fewer GPUs than ranks the ranks share devices over gloo - a functional dry
@@ -525,6 +544,14 @@ def main():
                                                             "ttft_p50_ms", "prefill_roofline", "step_roofline", "tp",
                                                             "roofline", "chain_roofline", "error") if k in tp_run}
                 result["tp_run"].setdefault("n_gpus", world)
+        if rank == 0 and result is not None:
+            # north_star: ">= 6x aggregate throughput at TP = 8" - both aggregates as multiples of the one-GPU line
+            ref, ref_file = one_gpu_reference()
+            if ref:
+                result["speedup_vs_1gpu"] = result["value"] / ref
+                result["speedup_reference"] = f"{ref:.0f} tokens/s on one GPU ({ref_file})"
+                if isinstance(result.get("tp_run"), dict) and "value" in result["tp_run"]:
+                    result["tp_run"]["speedup_vs_1gpu"] = result["tp_run"]["value"] / ref
         if rank == 0 and result is not None and shared_gpu:
             result["dry_run"] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over "
                                  f"{os.environ.get('BENCH_DIST_BACKEND', 'nccl')}: functional run of the multi-rank flow, "

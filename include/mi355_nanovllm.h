@@ -80,7 +80,8 @@ enum mi_tuning_knob {
   MI_TUNE_ROPE_BLOCK64 = 3,       /* mi_qknorm_rope_store: one-wave workgroups for <= 64 tokens (default 1)                     */
   MI_TUNE_PLAIN_SPLIT_TARGET = 4, /* mi_paged_attn_decode_plain: workgroups aimed for when contexts are split (default 512)     */
   MI_TUNE_PREFILL_P_SPLIT = 5,    /* prefill attention: probabilities as bf16 hi + lo (1) instead of one bf16 (default 0)       */
-  MI_TUNE_COUNT = 6
+  MI_TUNE_GEMM_PIPE = 6,          /* streaming GEMMs: double-buffered K loop for K-slices of two or more blocks (default 1)     */
+  MI_TUNE_COUNT = 7
 };
 int mi_set_tuning(int knob, int value);
 /* current value, or INT32_MIN for an unknown knob */

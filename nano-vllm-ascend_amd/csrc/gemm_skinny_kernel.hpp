@@ -74,7 +74,12 @@ constexpr int x_slab_bytes(int MT) { return MT * 16 * 64 * 2; }
 // at seven points of its life into stamps[workgroup][wave][8] - entry / loads issued / data arrived / K-slice sums in
 // LDS / barrier passed / stores issued / stores acknowledged.  A separate instantiation: the product kernels carry
 // no stamp code.
-template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS, bool STAMP = false>
+// PIPE (long K-slices: hidden 5120 / 4096 models, TP shards of them): the K loop double-buffered - the loads of block
+// i + 1 (weight fragments and x lines) are issued BEFORE block i is consumed, so a wave always has one or two blocks in
+// flight instead of paying one full memory round trip per block (a Qwen3-32B TP-8 rank's qkv GEMM: five dependent
+// round trips of ~2 us each).  Written as two named register sets over a loop unrolled by two with the tail peeled, so
+// that no load is conditional and hipcc's wait counts stay exact (vmcnt = the loads of the newer block).
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool BIAS, bool STAMP = false, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
     uint16_t* __restrict__ y, float* __restrict__ part, const float* __restrict__ scale, int M_all, int N, int K,
@@ -146,6 +151,49 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(
 #pragma unroll
   for (int m = 0; m < MT; ++m) xp[m] = x + (int64_t)min(16 * m + r, M - 1) * K + kbeg + 8 * g;
 
+  if constexpr (PIPE) {
+    static_assert(!PIPE || (WF == 1 && STEPS % 2 == 0 && !STAMP), "double-buffered loop: packed bf16 weights, x in lines");
+    constexpr int BS = 32 * STEPS;
+    u32x4 aA[RT][STEPS], aB[RT][STEPS], stA[(STEPS + 1) / 2][MT * 2], stB[(STEPS + 1) / 2][MT * 2];
+    auto issue = [&](u32x4(&a)[RT][STEPS], u32x4(&st)[(STEPS + 1) / 2][MT * 2], int k) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+          a[t][s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + ((k >> 5) + s) * WSTEP));
+      issue_x_lines<MT, STEPS>(x, M, K, kbeg + k, lane, st);
+      // nothing of the block being consumed may be scheduled above these loads: left alone, hipcc sinks them behind the
+      // current block's waits and LDS staging, and the loop is back to one block in flight per round trip
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto consume = [&](const u32x4(&a)[RT][STEPS], const u32x4(&st)[(STEPS + 1) / 2][MT * 2]) {
+      u32x4 bfrag[MT][STEPS];
+      x_lines_to_frags<MT, STEPS>(st, slab, lane, bfrag);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[t][s]), as_frag(bfrag[m][s]), acc[t][m], 0, 0, 0);
+    };
+    const int n = kslice / BS;
+    issue(aA, stA, 0);
+    int it = 0;
+    for (; it + 2 < n; it += 2) {
+      issue(aB, stB, (it + 1) * BS);
+      consume(aA, stA);
+      issue(aA, stA, (it + 2) * BS);
+      consume(aB, stB);
+    }
+    if (it + 1 < n) {
+      issue(aB, stB, (it + 1) * BS);
+      consume(aA, stA);
+      consume(aB, stB);
+    } else {
+      consume(aA, stA);
+    }
+  } else
   for (int k = 0; k < kslice; k += 32 * STEPS) {
     u32x4 a[RT][STEPS], bfrag[MT][STEPS];
     // every load of the block is issued before the first MFMA: no branches, no waits in between
@@ -658,18 +706,18 @@ static bool launch_stamped(const GemmArgs& a, unsigned long long* stamps) {
   return false;
 }
 
-template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI>
+template <int MT, int RT, int WAVES, int STEPS, int WF, int EPI, bool PIPE = false>
 static void launch(const GemmArgs& a) {
   const size_t slot = (size_t)RT * MT * 1024 > (size_t)x_slab_bytes(MT) ? (size_t)RT * MT * 1024 : (size_t)x_slab_bytes(MT);
   const size_t lds = (size_t)WAVES * slot;
   const int tiles = a.N / 16;
   const dim3 grid(EPI == EPI_SILU ? tiles / 2 : tiles / RT, a.ksplit, (a.M + kSkinnyRows - 1) / kSkinnyRows);
   if (a.bias && EPI == EPI_NONE)
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true>), grid, dim3(WAVES * 64), lds,
-                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, true, false, PIPE>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick, nullptr);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false>), grid, dim3(WAVES * 64), lds,
-                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, RT, WAVES, STEPS, WF, EPI, false, false, PIPE>), grid, dim3(WAVES * 64), lds,
+                       a.st, a.x, a.w, a.bias, a.y, a.part, a.scale, a.M, a.N, a.K, a.pick, nullptr);
 }
 
 // choose STEPS (k-steps in flight per wave and iteration) from the K-slice and the register budget
@@ -681,6 +729,14 @@ static bool try_waves(const GemmArgs& a) {
   // k-steps in flight per wave and iteration, bounded by the 128-register budget of a 16-wave workgroup
   // (x is staged as whole lines: its registers are live twice for a moment)
   constexpr int MAXS = FRAGS <= 3 ? 8 : (FRAGS <= 5 ? 4 : 2);
+  // a K-slice that would take two or more dependent blocks: the double-buffered loop on blocks of 64 (PIPE; two register
+  // sets of RT + MT fragments per k-step: up to 32 activation rows, the many-waves geometries)
+  if constexpr (WF == 1 && MT <= 2 && WAVES >= 8) {
+    if (kslice % 64 == 0 && tuning(MI_TUNE_GEMM_PIPE)) {
+      const int steps = (MAXS >= 8 && kslice % 256 == 0) ? 8 : ((MAXS >= 4 && kslice % 128 == 0) ? 4 : 2);
+      if (kslice / (32 * steps) >= 2) return launch<MT, RT, WAVES, 2, WF, EPI, true>(a), true;
+    }
+  }
   if constexpr (MAXS >= 8) {
     if (kslice % 256 == 0) return launch<MT, RT, WAVES, 8, WF, EPI>(a), true;
   }

@@ -248,7 +248,9 @@ class LLMEngine:
     def _stamp_first_tokens(self, seqs) -> float:
         now = perf_counter()
         for s in seqs:
-            if s.num_completion_tokens == 0 and s.seq_id not in self.ttft:
+            # (a first token is the sequence's only completion token; it may already be counted as pending when the
+            # first decode step was queued behind the prefill step, _queue_decode_behind_prefill)
+            if s.num_completion_tokens == int(s.token_pending) and s.seq_id not in self.ttft:
                 s.first_token_time = now
                 self.ttft[s.seq_id] = now - s.arrival_time
         return now
@@ -261,22 +263,52 @@ class LLMEngine:
         following step() call."""
         handle, rec = launched
         runner, sched = self.model_runner, self.scheduler
+        num_tokens = sum(len(s) for s in seqs)
+        decode_plan = None
         if not runner.prefill_done(handle):
             nxt = sched.lookahead_prefill(seqs, self.prefill_lookahead_min_tokens)
             if nxt:
                 self._inflight_prefill = (self._launch_prefill(nxt, behind_previous=True), nxt)
                 self.prefill_lookahead_launches += 1
+            elif self.lookahead and self._inflight is None and not sched.waiting:
+                decode_plan = self._queue_decode_behind_prefill(seqs)
             self.gc.slack()
         tokens = runner.collect_prefill(handle)
         rec["device_ms"] = runner.prefill_device_ms(handle)
-        num_tokens = sum(len(s) for s in seqs)
-        live = [(s, t) for s, t in zip(seqs, tokens) if not s.is_finished]  # (aborted while the step was queued)
-        seqs, tokens = [s for s, _ in live], [t for _, t in live]
-        rec["stamp"] = self._stamp_first_tokens(seqs)
-        sched.postprocess(seqs, tokens)
+        if decode_plan is not None:  # (no row of this step was aborted: checked when the decode step was queued)
+            queued, deferred = decode_plan
+            rec["stamp"] = self._stamp_first_tokens(seqs)
+            for s in sched.resolve(seqs, tokens, deferred, queued[1]):
+                queued[2].add(id(s))  # ended on EOS with its first token: its row of the queued step is dropped
+            self._inflight = queued
+        else:
+            live = [(s, t) for s, t in zip(seqs, tokens) if not s.is_finished]  # (aborted while the step was queued)
+            seqs, tokens = [s for s, _ in live], [t for _, t in live]
+            rec["stamp"] = self._stamp_first_tokens(seqs)
+            sched.postprocess(seqs, tokens)
         outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
                    for s in seqs if s.is_finished]
         return outputs, num_tokens
+
+    def _queue_decode_behind_prefill(self, seqs):
+        """The LAST prefill step of a burst is running and nothing is waiting: the step after it is a decode step over
+        every running sequence, and which one follows from lengths alone (Scheduler.lookahead - the same decisions
+        postprocess() + schedule() would take when the first tokens are in).  Queue it now: the rows of this prefill
+        step take their input ids on the device from the step's token buffer (the sampler of launch_prefill writes the
+        buffer the decode graphs read), the device goes from the prefill step into the first decode step without the
+        0.4 ms of host work in between (profiles/r04_final2_prefill_step_edges.txt).
+        -> ((runner handle, sequences, dropped rows), sequences with a seal outstanding) or None: decide synchronously."""
+        runner, sched = self.model_runner, self.scheduler
+        if any(s.is_finished for s in seqs):  # a request of this step was aborted while it was queued
+            return None
+        plan = sched.lookahead(seqs, runner.max_launch_rows)
+        if plan is None:
+            return None
+        nxt, deferred = plan
+        row_of = {id(s): i for i, s in enumerate(seqs)}
+        src = [row_of[id(s)] if s.token_pending else -1 for s in nxt]
+        self.decode_behind_prefill_launches = getattr(self, "decode_behind_prefill_launches", 0) + 1
+        return (runner.call("launch_decode", nxt, src), nxt, set()), deferred
 
     def _step_lookahead(self, handle, seqs, dropped):
         """One decode step whose launch is already queued (`handle`): decide and queue the NEXT step first

@@ -1085,3 +1085,38 @@ def test_a_prefill_step_that_already_finished_is_stamped_before_the_next_one_is_
     while eng.scheduler.waiting:
         eng.step()
     assert [o[0] for o in order[:3]] == ["launch", "launch", "stamp"]
+
+
+@pytest.mark.parametrize("eos", [-1, 5])
+def test_first_decode_step_is_queued_behind_the_last_prefill_step(eos):
+    """Round 5: when the last prefill step of a burst is in flight and nothing is waiting, the first decode step is
+    scheduled from lengths alone and queued behind it (LLMEngine._queue_decode_behind_prefill) - the prefill step's rows
+    read their input ids from its token buffer on the device.  Against the synchronous engine on the scripted model:
+    the same decode steps (sequences, positions, input ids, block tables), token streams, TTFT stamps for every
+    request, allocator state; a request whose FIRST token is its last (max_tokens 1, or EOS) never gets a decode row
+    that counts."""
+    rng = np.random.default_rng(11)
+    prompts = [[int(t) for t in rng.integers(0, 23, n)] for n in (5, 8, 12, 3, 9, 16)]
+    lens = (6, 1, 9, 4, 1, 7)
+    outs, engines = [], []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=eos, num_kvcache_blocks=60, max_num_batched_tokens=32, max_num_seqs=8)
+        for p, n in zip(prompts, lens):
+            eng.add_request(p, SamplingParams(max_tokens=n, ignore_eos=False, temperature=1.0))
+        outs.append(_drain(eng))
+        engines.append(eng)
+    sync, look = outs
+    assert sync == look and sorted(look) == list(range(6))
+    e_sync, e_look = engines
+    assert getattr(e_sync, "decode_behind_prefill_launches", 0) == 0
+    assert getattr(e_look, "decode_behind_prefill_launches", 0) == 1  # one burst: its last prefill step
+    assert sorted(e_look.ttft) == sorted(e_sync.ttft) == list(range(6))
+    if eos < 0:
+        assert e_sync.model_runner.steps == e_look.model_runner.steps
+        assert all(len(look[i]) == lens[i] for i in range(6))
+    assert e_sync.model_runner.prefills == e_look.model_runner.prefills
+    a, b = e_sync.scheduler.block_manager, e_look.scheduler.block_manager
+    assert not a.used_block_ids and not b.used_block_ids
+    if eos < 0:  # (an EOS ending is known one step later under lookahead: the freed blocks return in another order)
+        assert list(a.free_block_ids) == list(b.free_block_ids)

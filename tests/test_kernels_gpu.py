@@ -396,6 +396,65 @@ def test_gemm_packed_qwen3_32b_tp8_shapes(ops, N, K):
                           max_ulp=2, max_frac=3e-2, atol=32 * atol)
 
 
+@pytest.mark.parametrize("M", [5, 32])
+@pytest.mark.parametrize("N,K,silu", [(1280, 5120, False), (6400, 5120, True), (5120, 3200, False), (4096, 4096, False),
+                                      (256, 8192, False), (1024, 12288, False)])
+def test_gemm_packed_double_buffered_k_loop_is_the_same_sum(ops, M, N, K, silu):
+    """Round 5: K-slices of two or more blocks run the double-buffered loop (gemm_skinny_kernel PIPE: the next block's
+    loads issued before the current one is consumed).  One MFMA chain per wave over ascending k either way, so the
+    results are the SAME BITS as with the one-block-at-a-time loop (tuning knob MI_TUNE_GEMM_PIPE = 0), plain, SwiGLU
+    and split-K partials, and within the GEMM bound of the oracle."""
+    from nanovllm import _C
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16()
+    wp = ops.pack_weight(w.to(DEV))
+    got = {}
+    try:
+        for pipe in (1, 0):
+            _C.set_tuning(_C.TUNE_GEMM_PIPE, pipe)
+            got[pipe] = (ops.gemm_packed(x, wp, silu_mul=silu), ops.gemm_packed_splitk(x, wp, 2))
+    finally:
+        _C.set_tuning(_C.TUNE_GEMM_PIPE, 1)
+    assert torch.equal(got[1][0].view(torch.int16), got[0][0].view(torch.int16))
+    assert torch.equal(got[1][1], got[0][1])
+    want = oracle.linear(x.cpu(), w)
+    atol = K * 2.0 ** -22
+    if silu:
+        assert_bf16_close(got[1][0], oracle.silu_and_mul(want), max_ulp=2, max_frac=3e-2, atol=32 * atol)
+    else:
+        assert_bf16_close(got[1][0], want, max_frac=2e-2, atol=atol)
+    assert_bf16_close(got[1][1].sum(0).bfloat16(), want, max_frac=2e-2, atol=atol)
+
+
+def test_instrumented_chain_launches_compute_the_product(ops):
+    """mi_gemm_bf16_packed_ex / mi_add_rmsnorm_splitk_ex (tools/chain_timeline.py) are the product kernels plus clock
+    stamps: same bits, and every wave's seven stamps are monotonic."""
+    g = torch.Generator().manual_seed(12)
+    B, H = 32, 1024
+    x = torch.randn(B, H, generator=g).bfloat16().to(DEV)
+    w_qkv = ops.pack_weight((torch.randn(4096, H, generator=g) * 0.03).bfloat16().to(DEV))
+    w_gu = ops.pack_weight((torch.randn(6144, H, generator=g) * 0.03).bfloat16().to(DEV))
+    w_dn = ops.pack_weight((torch.randn(H, 3072, generator=g) * 0.03).bfloat16().to(DEV))
+    st = lambda wg, wv: torch.zeros(wg, wv, 8, dtype=torch.int64, device=DEV)  # noqa: E731
+    s1, s2, s3, s4 = st(256, 16), st(192, 16), st(256, 12), st(B, 4)
+    y = ops.gemm_packed_stamped(x, w_qkv, s1)
+    assert torch.equal(y.view(torch.int16), ops.gemm_packed(x, w_qkv).view(torch.int16))
+    a = ops.gemm_packed_stamped(x, w_gu, s2, silu_mul=True)
+    assert torch.equal(a.view(torch.int16), ops.gemm_packed(x, w_gu, silu_mul=True).view(torch.int16))
+    p = ops.gemm_packed_stamped(a, w_dn, s3, ksplit=4)
+    assert torch.equal(p, ops.gemm_packed_splitk(a, w_dn, 4))
+    nw = torch.ones(H, device=DEV).bfloat16()
+    n1 = ops.add_rmsnorm_splitk_stamped(p, x, nw, 1e-6, s4)
+    n0 = ops.add_rmsnorm_splitk(p, x, nw, 1e-6)
+    assert all(torch.equal(u.view(torch.int16), v.view(torch.int16)) for u, v in zip(n1, n0))
+    for s in (s1, s2, s3, s4):
+        t = s.cpu()[..., :7]
+        assert (t > 0).all() and (t[..., 1:] >= t[..., :-1]).all()
+        assert (t.max() - t.min()).item() < 100 * 1000  # one launch: well under a millisecond of the 100 MHz clock
+
+
 def _pack_rows4_ref(w):
     """host model of mi_pack_weight_rows4: [N/4][K/32][4 (g)][4 (n)][8]"""
     N, K = w.shape

@@ -8,6 +8,7 @@ SEL="gpu"; [ -n "$SLOW" ] && SEL="gpu or gpu_slow"
 timeout 1500 python -m pytest tests -q -m "$SEL" --durations=15 2>&1 | tail -24 > gpurun_out/final/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > gpurun_out/final/smoke.txt
 timeout 600 python bench.py 2>&1 | grep '^{"metric"' > gpurun_out/final/bench.json
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep '^{"metric"' > gpurun_out/final/bench_driver_cmd.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $R/bench.py --no-cpu-baseline > /tmp/log_kt 2>&1
 grep '^{"metric"' /tmp/log_kt > $R/gpurun_out/final/bench_under_kernel_trace.json
@@ -16,6 +17,7 @@ python $R/tools/prof_db.py $db 40 > $R/gpurun_out/final/kernel_trace.txt
 python $R/tools/prof_db.py $db --last paged_attn_decode_kernel 560 >> $R/gpurun_out/final/kernel_trace.txt
 python $R/tools/prof_db.py $db --window paged_attn_prefill_kernel 28 "prefill step, 16 x 1024 tokens" > $R/gpurun_out/final/prefill_step_breakdown.txt
 python $R/tools/prof_db.py $db --edges paged_attn_prefill_kernel 28 > $R/gpurun_out/final/prefill_step_edges.txt
+python $R/tools/prof_db.py $db --layers paged_attn_prefill_kernel 28 2 > $R/gpurun_out/final/prefill_steps_layer_by_layer.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/prof_$c -- python $R/bench.py --no-cpu-baseline > /tmp/log_$c 2>&1
   db=$(find /tmp/prof_$c -name "*.db" | head -1)

@@ -86,7 +86,34 @@ def edges(path, anchor_substr, n_anchor, around=14):
             print(f"   {(st - t0) / 1000.0:10.1f}  {(en - st) / 1000.0:8.1f} us  gap {gap:8.1f}  {name[:90]}")
 
 
+def layers(path, anchor_substr, n_anchor, groups=2):
+    """The last `groups` runs of n_anchor dispatches of the anchor kernel (the bench's prefill steps, newest last) side by
+    side: start-to-start interval of consecutive anchors, i.e. the time of each layer, and the anchor's own duration -
+    where a step that is slower than its successor loses its time (round 5: the first step behind an idle device)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = list(cur.execute(f"""select d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id
+                                where s.kernel_name like ? order by d.start""", (f"%{anchor_substr}%",)))
+    runs = [rows[len(rows) - (g + 1) * n_anchor: len(rows) - g * n_anchor] for g in range(groups)][::-1]
+    print(f"layer by layer, the last {groups} runs of {n_anchor} x *{anchor_substr}* (oldest first): "
+          "anchor-to-anchor interval us / anchor duration us")
+    for i in range(n_anchor):
+        cells = []
+        for r in runs:
+            iv = (r[i + 1][0] - r[i][0]) / 1000.0 if i + 1 < n_anchor else float("nan")
+            cells.append(f"{iv:8.1f} / {(r[i][1] - r[i][0]) / 1000.0:6.1f}")
+        print(f"   layer {i:2d}   " + "      ".join(cells))
+    for r in runs:
+        print(f"   run: first anchor start -> last anchor end {(r[-1][1] - r[0][0]) / 1000.0:9.1f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 4 and sys.argv[2] == "--layers":
+        layers(sys.argv[1], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 2)
+        sys.exit(0)
     if len(sys.argv) > 4 and sys.argv[2] == "--edges":
         edges(sys.argv[1], sys.argv[3], int(sys.argv[4]))
         sys.exit(0)
