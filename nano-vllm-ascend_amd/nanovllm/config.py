@@ -49,6 +49,7 @@ class Config:
     sampling_seed: int | None = None  # seed of the temperature sampler; None: drawn from os.urandom per engine
     quantization: str | None = None  # "fp8": e4m3 weights + per-row scales for the decode GEMMs (no reference counterpart)
     prefix_aware_prefill: bool = True  # skip the tokens of cache-hit prefix blocks in prefill (False: recompute, as the reference)
+    prefill_graphs: bool = True  # prefill steps of up to 4 sequences / 4096 tokens replay bucketed hipGraphs (engine/model_runner.py)
     gc_control: bool = True  # engine/host_gc.py: freeze after warm-up, no automatic collection inside step(), full passes only when idle
     # a prefill step at least this many tokens long has the next one queued behind it (engine/llm_engine.py); < 0: derived
     # after warm-up from this host's launch time and this device's time per token

@@ -44,6 +44,11 @@ def _torch_dtype_of(hf_config) -> torch.dtype:
     return dt or torch.bfloat16
 
 
+# token / sequence buckets of the captured PREFILL steps (capture_prefill_graphs)
+PREFILL_GRAPH_TOKENS = (64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096)
+PREFILL_GRAPH_SEQS = (1, 2, 4)
+
+
 def graph_buckets(max_num_seqs: int) -> list[int]:
     b, out = 1, []
     while b < max_num_seqs:
@@ -169,6 +174,20 @@ class ModelRunner:
                 self.graphs.clear()
                 self.graph_logits.clear()
                 reset_context()
+        self.prefill_graphs: dict[tuple[int, int], torch.cuda.CUDAGraph] = {}
+        self.prefill_graph_logits: dict[tuple[int, int], torch.Tensor] = {}
+        self.prefill_graph_replays = 0
+        if (config.use_graphs and config.prefill_graphs and self.graph_samples and self.can_launch_prefill
+                and os.environ.get("MI355_PREFILL_GRAPHS", "1") != "0"):
+            try:
+                self.capture_prefill_graphs()
+            except Exception as e:
+                import warnings
+
+                warnings.warn(f"hipGraph capture of the prefill buckets failed ({e!r}); prefill steps are launched eagerly")
+                self.prefill_graphs.clear()
+                self.prefill_graph_logits.clear()
+                reset_context()
         if self.collective:
             dist.barrier()
 
@@ -209,6 +228,8 @@ class ModelRunner:
         parallel.set_force_collectives(False)
         self.graphs.clear()
         self.graph_logits.clear()
+        self.prefill_graphs.clear()
+        self.prefill_graph_logits.clear()
         torch.cuda.synchronize()
         if self.channel is not None:
             if not abort:
@@ -352,6 +373,34 @@ class ModelRunner:
         # gives the step's device time to the engine's prefill trace
         self.prefill_starts = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self.prefill_events = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        # captured prefill steps (capture_prefill_graphs) read their metadata at FIXED addresses: one static device buffer
+        # [ids i64 T][pos i64 T][slots i32 T][cu_q i32 S+1][cu_k i32 S+1][kv_lens i32 S][temps f32 S][rng u64 2][tables i32 S*W]
+        # for the largest bucket, of which a graph uses the leading T_b / S_b entries; two pinned mirrors, alternating
+        tmax = max([t for t in PREFILL_GRAPH_TOKENS if t <= cfg.max_num_batched_tokens] or [0])
+        smax = max([n for n in PREFILL_GRAPH_SEQS if n <= cfg.max_num_seqs] or [0])
+        self._pg_tmax, self._pg_smax = tmax, smax
+        if tmax and smax:
+            off, sp = 0, {}
+            for name, nb in (("ids", 8 * tmax), ("pos", 8 * tmax), ("slots", 4 * tmax), ("cu_q", 4 * (smax + 1)),
+                             ("cu_k", 4 * (smax + 1)), ("kv_lens", 4 * smax), ("temps", 4 * smax), ("rng", 16),
+                             ("tables", 4 * smax * W)):
+                sp[name] = (off, nb)
+                off += (nb + 15) // 16 * 16
+
+            def pviews(buf):
+                def v(name, dtype, shape):
+                    o, n = sp[name]
+                    return buf[o:o + n].view(dtype).view(shape)
+                return {"ids": v("ids", torch.int64, (tmax,)), "pos": v("pos", torch.int64, (tmax,)),
+                        "slots": v("slots", torch.int32, (tmax,)), "cu_q": v("cu_q", torch.int32, (smax + 1,)),
+                        "cu_k": v("cu_k", torch.int32, (smax + 1,)), "kv_lens": v("kv_lens", torch.int32, (smax,)),
+                        "temps": v("temps", torch.float32, (smax,)), "rng": v("rng", torch.int64, (2,)),
+                        "tables": v("tables", torch.int32, (smax, W))}
+
+            self.pg_dev_buf = torch.zeros(off, dtype=torch.uint8, device=self.device)
+            self.pg_dev = pviews(self.pg_dev_buf)
+            self.pg_host_bufs = [torch.zeros(off, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self.pg_hosts = [{k: t.numpy() for k, t in pviews(b).items()} for b in self.pg_host_bufs]
 
     def _fill_decode_stage(self, seqs: list[Sequence], bucket: int, src_rows=None) -> int:
         """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the next pinned
@@ -467,6 +516,99 @@ class ModelRunner:
         reset_context()
         torch.cuda.synchronize()
 
+    # ------------------------------------------------------------------ captured prefill steps
+    @torch.inference_mode()
+    def capture_prefill_graphs(self):
+        """Prefill steps of up to PREFILL_GRAPH_SEQS sequences and PREFILL_GRAPH_TOKENS tokens as hipGraphs, one per
+        (token bucket, sequence bucket) - what a serving engine runs for almost every arrival.  An eager prefill step is
+        ~250 launches = 3.6 ms of host time whatever its size, which for a 500-token prompt is four times its device time
+        and most of an open-loop request's TTFT; a replay costs the host 0.1 ms.  (The reference keeps prefill eager:
+        model_runner.py:393 bypasses its compiled graph for everything but decode.)
+        A step is padded to its bucket: pad tokens are id 0 at position 0 with slot -1 (the store kernels skip them), pad
+        sequences have length 0 (the attention kernel's workgroups for them exit on their query length), so the real rows
+        are computed exactly as in an eager step of T_b rows; the step's last-token rows go through the head GEMM with the
+        pick epilogue (the sampler's keys, {seed, step} read from the static buffer), as the decode graphs do."""
+        cfg, d = self.config, self.pg_dev
+        text = getattr(self.hf_config, "text_config", self.hf_config)
+        if not self._pg_tmax or getattr(text, "num_experts", 0):
+            return  # (the sparse block's routing over pad tokens is not worth a graph: eager)
+        pool = None
+        for tb in sorted((t for t in PREFILL_GRAPH_TOKENS if t <= self._pg_tmax), reverse=True):
+            for sb in sorted((n for n in PREFILL_GRAPH_SEQS if n <= self._pg_smax and n <= tb), reverse=True):
+                if -(-tb // sb) > cfg.max_model_len:
+                    continue  # no step of sb sequences has that many tokens (a sequence is at most max_model_len long)
+                self._stage_prefill_static([], tb, sb)
+                set_context(True, cu_seqlens_q=d["cu_q"][:sb + 1], cu_seqlens_k=d["cu_k"][:sb + 1], max_seqlen_q=tb,
+                            max_seqlen_k=tb, slot_mapping=d["slots"][:tb], block_tables=d["tables"][:sb],
+                            block_size=self.block_size, kv_lens=d["kv_lens"][:sb])
+
+                def body(tb=tb, sb=sb):
+                    hidden = self.model(d["ids"][:tb], d["pos"][:tb])
+                    x = ops.gather_last_tokens(hidden, d["cu_q"][:sb + 1])
+                    logits, _ = ops.gemm_packed_pick(x, self.model.lm_head.weight_packed, d["temps"][:sb], d["rng"],
+                                                     self.tokens_dev[:sb])
+                    return logits
+
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    body()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=pool):
+                    logits = body()
+                pool = pool or graph.pool()
+                self.prefill_graphs[(tb, sb)] = graph
+                self.prefill_graph_logits[(tb, sb)] = logits
+        reset_context()
+        torch.cuda.synchronize()
+
+    def _prefill_bucket(self, seqs: list[Sequence]) -> tuple[int, int] | None:
+        if not self.prefill_graphs or len(seqs) > self._pg_smax:
+            return None
+        skip = self.config.prefix_aware_prefill
+        tokens = sum(len(s) - (min(s.num_prefix_tokens, len(s) - 1) if skip else 0) for s in seqs)
+        if tokens > self._pg_tmax or max(len(s.block_table) for s in seqs) > self.table_cols:
+            return None
+        tb = next(t for t in PREFILL_GRAPH_TOKENS if t >= tokens)
+        sb = next(n for n in PREFILL_GRAPH_SEQS if n >= len(seqs))
+        return (tb, sb) if (tb, sb) in self.prefill_graphs else None
+
+    def _stage_prefill_static(self, seqs: list[Sequence], tb: int, sb: int) -> int:
+        """prefill_meta(seqs) at the static buffer's fixed offsets, padded to the bucket (pad tokens: id 0, position 0,
+        slot -1; pad sequences: empty), the sampler's temperatures and {seed, step}; ONE async copy.  Returns the index
+        of the pinned buffer (= of the token landing buffer and events) used."""
+        self._pflip ^= 1
+        h = self.pg_hosts[self._pflip]
+        real_t = 0
+        if seqs:
+            m = batch_meta.prefill_meta(seqs, self.block_size, skip_cached=self.config.prefix_aware_prefill)
+            real_t, n = int(m.cu_seqlens_q[-1]), len(seqs)
+            h["ids"][:real_t], h["pos"][:real_t], h["slots"][:real_t] = m.input_ids, m.positions, m.slot_mapping
+            h["cu_q"][:n + 1], h["cu_k"][:n + 1], h["kv_lens"][:n] = m.cu_seqlens_q, m.cu_seqlens_k, m.kv_lens
+            h["cu_q"][n + 1:sb + 1], h["cu_k"][n + 1:sb + 1], h["kv_lens"][n:sb] = real_t, int(m.cu_seqlens_k[-1]), 0
+            h["tables"][:sb] = -1
+            h["tables"][:n, :m.block_tables.shape[1]] = m.block_tables
+            h["temps"][:n] = [0.0 if s.greedy else s.temperature for s in seqs]
+            h["temps"][n:sb] = 0.0
+        else:
+            # capture / its warm-up run: sb sequences sharing the tb tokens evenly that store nothing (slots -1) and
+            # attend the reserved dummy block (the decode graphs' pad slot) - every kernel runs over mapped memory,
+            # nothing is written.  (capture_prefill_graphs skips buckets whose share exceeds max_model_len.)
+            edges = [tb * i // sb for i in range(sb + 1)]
+            h["cu_q"][:sb + 1] = h["cu_k"][:sb + 1] = edges
+            h["kv_lens"][:sb] = np.diff(edges)
+            h["temps"][:sb] = 0.0
+            h["tables"][:sb] = -1
+            h["tables"][:sb, :-(-max(np.diff(edges)) // self.block_size)] = self.config.num_kvcache_blocks - 1
+        h["ids"][real_t:tb], h["pos"][real_t:tb], h["slots"][real_t:tb] = 0, 0, -1
+        rng = h["rng"].view(np.uint64)
+        rng[0] = self.sampler.seed & 0xFFFFFFFFFFFFFFFF
+        rng[1] = (self.sampler.step + 1) & 0xFFFFFFFFFFFFFFFF
+        self.pg_dev_buf.copy_(self.pg_host_bufs[self._pflip], non_blocking=True)
+        return self._pflip
+
     def _bucket_for(self, n: int) -> int | None:
         for b in sorted(self.graphs):
             if b >= n:
@@ -568,7 +710,18 @@ class ModelRunner:
         step between the two (Scheduler.lookahead_prefill) - `last_logits` (the parity hook) then names the logits of
         the step launched LAST, not of the step just collected."""
         real = len(seqs)
-        self.prefill_starts[self._pflip ^ 1].record()  # (prepare_prefill flips to this buffer)
+        self.prefill_starts[self._pflip ^ 1].record()  # (prepare_prefill / _stage_prefill_static flip to this buffer)
+        bucket = self._prefill_bucket(seqs)
+        if bucket is not None:  # a captured step: stage at the fixed addresses, replay, the tokens are picked in the graph
+            b = self._stage_prefill_static(seqs, *bucket)
+            self.prefill_graphs[bucket].replay()
+            self.sampler.step += 1  # the graph sampled with this step (see _stage_prefill_static)
+            self.prefill_graph_replays += 1
+            self.last_logits = self.prefill_graph_logits[bucket][:real]
+            self.prefill_tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+            self.prefill_events[b].record()
+            self._steps_run += 1
+            return (b, real)
         input_ids, positions = self.prepare_prefill(seqs)
         b = self._pflip
         temps = self.prepare_sample(seqs)
