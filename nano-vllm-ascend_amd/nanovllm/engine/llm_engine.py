@@ -181,7 +181,10 @@ class LLMEngine:
             raise ValueError(f"prompt of {len(prompt)} tokens exceeds max_model_len = {self.scheduler.max_model_len} "
                              "(Config.max_model_len, clamped to the model's max_position_embeddings)")
         seq = Sequence(prompt, sampling_params, request_id=request_id, block_size=self.block_size)
-        seq.prompt_hashes(self.block_size)  # request preprocessing (with the token array built by Sequence): before the clock
+        # request preprocessing (the token array built by Sequence, the chained hashes of the prompt's full blocks) runs
+        # BEFORE the clock starts: the reference's serving benchmark stamps a request's submission after add_request has
+        # returned (bench/serving_bench.py:100-105), i.e. its TTFT excludes add_request as well
+        seq.prompt_hashes(self.block_size)
         seq.arrival_time = perf_counter()
         self.scheduler.add(seq)
         return seq
@@ -317,13 +320,21 @@ class LLMEngine:
         goes from one step to the next without waiting for the host's scheduling, metadata upload and launch."""
         runner, sched = self.model_runner, self.scheduler
         live = [s for s in seqs if id(s) not in dropped]
-        plan = sched.lookahead(live, runner.max_launch_rows)
+        # (a prefill step already queued behind this decode step: the step after it is decided when it is collected)
+        plan = sched.lookahead(live, runner.max_launch_rows) if self._inflight_prefill is None else None
         queued = None
         if plan is not None:
             nxt, deferred = plan
             row_of = {id(s): i for i, s in enumerate(seqs)}
             src = [row_of[id(s)] if s.token_pending else -1 for s in nxt]
             queued = (runner.call("launch_decode", nxt, src), nxt, set())
+        elif self._inflight_prefill is None and sched.waiting and getattr(runner, "prefill_graph_takes", None) is not None:
+            # requests arrived while this decode step was queued: their prefill step - a graph replay, 0.1 ms of host
+            # time - goes behind it NOW, not after its tokens have come back (Scheduler.lookahead_prefill_behind_decode)
+            arrivals = sched.lookahead_prefill_behind_decode(live, runner.prefill_graph_takes)
+            if arrivals:
+                self._inflight_prefill = (self._launch_prefill(arrivals, behind_previous=True), arrivals)
+                self.prefill_behind_decode_launches = getattr(self, "prefill_behind_decode_launches", 0) + 1
         self.gc.slack()  # the device has the next step: the host's only idle time in a step
         tokens = runner.collect(handle)
         if len(live) != len(seqs):
@@ -346,6 +357,14 @@ class LLMEngine:
             pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True)
         if not isinstance(sampling_params, list):
             sampling_params = [sampling_params] * len(prompts)
+        # every prompt is checked before any is queued: one over-long prompt must not leave the others behind in the
+        # scheduler as orphans of a call that raised
+        if self.tokenizer is not None:
+            prompts = [self.tokenizer.encode(p) if isinstance(p, str) else p for p in prompts]
+        for prompt in prompts:
+            if not isinstance(prompt, str) and len(prompt) > self.scheduler.max_model_len:
+                raise ValueError(f"prompt of {len(prompt)} tokens exceeds max_model_len = {self.scheduler.max_model_len} "
+                                 "(Config.max_model_len, clamped to the model's max_position_embeddings)")
         for prompt, sp in zip(prompts, sampling_params):
             self.add_request(prompt, sp)
         done = {}

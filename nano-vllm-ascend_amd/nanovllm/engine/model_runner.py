@@ -564,6 +564,15 @@ class ModelRunner:
         reset_context()
         torch.cuda.synchronize()
 
+    def prefill_graph_takes(self, n_seqs: int, n_tokens: int) -> bool:
+        """Is a prefill step of n_seqs sequences and at most n_tokens tokens a graph replay (engine: may it be queued
+        behind a running decode step without holding that step's tokens back by an eager launch sequence)?"""
+        if not self.prefill_graphs or n_seqs > self._pg_smax or n_tokens > self._pg_tmax:
+            return False
+        tb = next(t for t in PREFILL_GRAPH_TOKENS if t >= n_tokens)
+        sb = next(n for n in PREFILL_GRAPH_SEQS if n >= n_seqs)
+        return (tb, sb) in self.prefill_graphs
+
     def _prefill_bucket(self, seqs: list[Sequence]) -> tuple[int, int] | None:
         if not self.prefill_graphs or len(seqs) > self._pg_smax:
             return None
@@ -630,6 +639,8 @@ class ModelRunner:
         if not seqs:  # everything got preempted this step (reference would crash)
             return []
         real = len(seqs)
+        if is_prefill and self.prefill_graphs and self._prefill_bucket(seqs) is not None:
+            return self.collect_prefill(self.launch_prefill(seqs))  # (the synchronous loop replays the captured steps too)
         if is_prefill:
             input_ids, positions = self.prepare_prefill(seqs)
             bucket = None

@@ -148,7 +148,11 @@ class Scheduler:
           blocks the step in flight may free - appended behind the ones taken here - change neither who is admitted
           nor any block id;
         * the step would be closed by the token budget or the sequence count, not by the end of the queue: a request
-          arriving while the step in flight runs could not have joined it either (admission never skips);
+          arriving while the step in flight runs could not have joined it either (admission never skips).  (Judged on
+          the prompts' full lengths; the real admission charges only the tokens behind cache hits and may then reach
+          the end of the queue after all - such a step is the same for the requests in it, but a request arriving
+          meanwhile joins the NEXT step instead of this one: batching under arrivals, not block ids or tokens, may
+          differ from the synchronous engine there - ADVICE r04);
         * the step in flight is long enough (min_inflight_tokens) for the next one's launch sequence to hide behind it -
           queueing a step behind a short one would only delay the short one's tokens.
 
@@ -171,6 +175,41 @@ class Scheduler:
         if not (closed or count == self.max_num_seqs or tokens == self.max_num_batched_tokens):
             return None
         return self._admit_prefill() or None
+
+    def lookahead_prefill_behind_decode(self, inflight: list[Sequence], takes) -> list[Sequence] | None:
+        """Requests are waiting while a DECODE step is in flight: admit them now and let their prefill step be queued
+        behind that step, instead of after its tokens have come back - an open-loop arrival then waits for the running
+        step on the device only, not for the host's round trip around it.  `takes(n_seqs, n_tokens)`: the runner can
+        launch such a step cheaply (a captured graph: an eager launch sequence would hold back the running step's tokens).
+        Taken only when the admission is the one schedule() would make after this step's postprocess():
+
+        * everything waiting fits ONE step that `takes` (count, token budget) - nothing is left for a second decision;
+        * the free list covers every candidate, so blocks freed by this step - appended behind the ones taken now - change
+          neither who is admitted nor any block id;
+        * no sequence of the step in flight ends by length or completes a block with this step's token (a block sealed or
+          freed by it could be hit / revived by the new prompts' prefix lookup: allocate() must see the same table).
+        (An EOS ending is not knowable here: as for decode lookahead, token streams are unaffected, the order of the free
+        list behind such an ending may differ from the synchronous engine's.)  Returns the admitted sequences or None."""
+        if not self.waiting or not inflight:
+            return None
+        bs = self.block_manager.block_size
+        for s in inflight:
+            if s.is_finished:
+                continue  # (left by length when this step was planned: its blocks are already free)
+            n = s.num_tokens if s.token_pending else s.num_tokens + 1  # its length once this step's token is in
+            if n % bs == 0 or (not s.token_pending and self._ends_by_length(s)):
+                return None
+        blocks = tokens = 0
+        for count, seq in enumerate(self.waiting, 1):
+            tokens += len(seq)
+            blocks += seq.num_blocks
+            if count > self.max_num_seqs or tokens > self.max_num_batched_tokens or not takes(count, tokens):
+                return None
+        if blocks > len(self.block_manager.free_block_ids):
+            return None
+        picked = self._admit_prefill()
+        assert picked and not self.waiting
+        return picked
 
     def resolve(self, seqs: list[Sequence], token_ids: list[int], deferred: list[Sequence],
                 queued: list[Sequence] | None) -> list[Sequence]:

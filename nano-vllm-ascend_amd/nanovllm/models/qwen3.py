@@ -226,8 +226,15 @@ class Qwen3Model(nn.Module):
         self.layers = nn.ModuleList([make(i) for i in range(config.num_hidden_layers)])
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
+    # prefill steps up to this many tokens take the seven-launch streaming path of the decode step, longer ones the
+    # module-by-module path on the tile GEMMs.  Measured on the captured prefill steps of a Qwen3-0.6B-shaped engine
+    # (profiles/r05_prefill_bucket_times.txt; ms per step with the switch at 512 / 128 tokens): 192 tokens 2.11 / 1.98,
+    # 256: 2.32 / 2.05, 384: 2.77 / 2.57, 512: 3.19 / 2.63; at 128 tokens the streaming path wins (1.73 vs 1.93).
+    PREFILL_STREAM_MAX = int(os.environ.get("MI355_PREFILL_STREAM_MAX", "128"))
+
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
-        if self.fused and input_ids.numel() <= ops.SKINNY_MAX_M and self._can_stream():
+        limit = min(ops.SKINNY_MAX_M, self.PREFILL_STREAM_MAX) if get_context().is_prefill else ops.SKINNY_MAX_M
+        if self.fused and input_ids.numel() <= limit and self._can_stream():
             return self._forward_streaming(input_ids, positions)
         hidden_states = self.embed_tokens(input_ids)
         residual = None

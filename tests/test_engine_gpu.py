@@ -781,9 +781,11 @@ def test_prefill_steps_replay_bucketed_graphs_with_the_eager_tokens():
                for i, n in enumerate(lens)]
     sps = [SamplingParams(max_tokens=5, ignore_eos=True, greedy=(i % 3 != 2), temperature=0.8) for i in range(len(lens))]
 
-    def run(graphs):
+    def run(graphs, lookahead=False):
+        # (synchronous loop for the logits comparison: under lookahead `last_logits` names the step launched last)
         llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=4, max_num_batched_tokens=1024,
-                  max_model_len=1024, num_kvcache_blocks=400, warmup=False, sampling_seed=9, prefill_graphs=graphs)
+                  max_model_len=1024, num_kvcache_blocks=400, warmup=False, sampling_seed=9, prefill_graphs=graphs,
+                  decode_lookahead=lookahead)
         try:
             first_logits = []
             for p, sp in zip(prompts, sps):
@@ -812,3 +814,8 @@ def test_prefill_steps_replay_bucketed_graphs_with_the_eager_tokens():
         assert (a - b).abs().max().item() <= 6e-2, (a - b).abs().max().item()
     same = sum(e[0] == g[0] for e, g in zip(eager, graph))
     assert same >= len(eager) - 1, (eager, graph)  # (one near-tie may flip a stream)
+    # ... and the lookahead engine (steps queued behind one another, the first decode step behind the prefill step): the
+    # same streams as its synchronous twin with graphs
+    ahead, _, na, _ = run(True, lookahead=True)
+    ahead = [ahead[k] for k in sorted(ahead)]
+    assert na >= 3 and sum(a[0] == g[0] for a, g in zip(ahead, graph)) >= len(graph) - 1, (ahead, graph)

@@ -1120,3 +1120,73 @@ def test_first_decode_step_is_queued_behind_the_last_prefill_step(eos):
     assert not a.used_block_ids and not b.used_block_ids
     if eos < 0:  # (an EOS ending is known one step later under lookahead: the freed blocks return in another order)
         assert list(a.free_block_ids) == list(b.free_block_ids)
+
+
+_FUZZ_PREFILL_BEHIND_DECODE: list[int] = []
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_arrivals_are_prefilled_behind_the_running_decode_step(seed):
+    """Round 5: a request that arrives while a decode step is queued is admitted at once and its prefill step - a graph
+    replay on the device runner (`prefill_graph_takes`) - queued BEHIND that decode step, before the step's tokens have
+    come back (Scheduler.lookahead_prefill_behind_decode).  Seeded streams of arrivals into a decoding engine, EOS on
+    in half of the seeds, aborts in some, against the synchronous engine: every never-aborted request's token stream is
+    equal, every request is prefilled exactly once per admission, nothing stays allocated."""
+    import random
+
+    rng = random.Random(900 + seed)
+    eos = 5 if seed % 2 else -1
+    n_req = rng.randrange(6, 14)
+    reqs = [([rng.randrange(0, 23) for _ in range(rng.randrange(2, 20))], rng.randrange(2, 14)) for _ in range(n_req)]
+    arrive = [0 if i < 2 else rng.randrange(1, 25) for i in range(n_req)]
+    aborts = {rng.randrange(2, 20): f"r{rng.randrange(n_req)}" for _ in range(rng.randrange(0, 2))} if seed % 3 == 0 else {}
+    outs = []
+    for look in (False, True):
+        Sequence.counter = __import__("itertools").count()
+        eng = _scripted_engine(look, eos=eos, num_kvcache_blocks=120, max_num_batched_tokens=64, max_num_seqs=6,
+                               max_model_len=48)
+        if look:
+            eng.model_runner.prefill_graph_takes = lambda n, t: n <= 2 and t <= 40
+        pending = sorted(((a, i) for i, a in enumerate(arrive)), key=lambda t: (t[0], t[1]))
+        ids, done, step = {}, {}, 0
+        while pending or not eng.is_finished():
+            while pending and pending[0][0] <= step:
+                _, i = pending.pop(0)
+                p, m = reqs[i]
+                ids[i] = eng.add_request(p, SamplingParams(max_tokens=m, ignore_eos=False, temperature=1.0),
+                                         request_id=f"r{i}").seq_id
+            if step in aborts:
+                eng.abort_request(aborts[step])
+            if not eng.is_finished():
+                for seq_id, toks, _, _ in eng.step()[0]:
+                    assert seq_id not in done
+                    done[seq_id] = list(toks)
+            step += 1
+            assert step < 4000
+        bm = eng.scheduler.block_manager
+        assert not bm.used_block_ids and eng._inflight is None and eng._inflight_prefill is None
+        flat = [s for step_ids in eng.model_runner.prefills for s in step_ids]
+        assert len(flat) == len(set(flat))  # (no preemption here: every request is prefilled once)
+        outs.append(({i: done.get(s) for i, s in ids.items()}, getattr(eng, "prefill_behind_decode_launches", 0)))
+    (d0, n0), (d1, n1) = outs
+    assert n0 == 0
+    never_aborted = [i for i in d0 if f"r{i}" not in aborts.values()]
+    assert all(d0[i] == d1[i] and d0[i] is not None for i in never_aborted), (d0, d1)
+    _FUZZ_PREFILL_BEHIND_DECODE.append(n1)
+
+
+def test_some_arrivals_were_prefilled_behind_a_decode_step():
+    """(runs after the fuzz above) the new admission path was taken, not only declined"""
+    assert _FUZZ_PREFILL_BEHIND_DECODE and sum(_FUZZ_PREFILL_BEHIND_DECODE) >= 6, _FUZZ_PREFILL_BEHIND_DECODE
+
+
+def test_generate_checks_every_prompt_before_queueing_any():
+    """generate() with one over-long prompt in the batch used to raise after the earlier prompts were
+    already queued - the next generate() call then ran and reported those orphans."""
+    eng = _scripted_engine(True, eos=-1, num_kvcache_blocks=40, max_num_batched_tokens=64, max_model_len=24)
+    sp = SamplingParams(max_tokens=2, ignore_eos=True, temperature=1.0)
+    with pytest.raises(ValueError, match="max_model_len"):
+        eng.generate([[1, 2, 3], list(range(30)), [4, 5]], sp, use_tqdm=False)
+    assert eng.is_finished() and not eng.scheduler.waiting
+    out = eng.generate([[1, 2, 3], [4, 5]], sp, use_tqdm=False)
+    assert [o["prompt_len"] for o in out] == [3, 2]

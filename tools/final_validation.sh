@@ -24,4 +24,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python $R/tools/prof_pmc.py $db 12 > $R/gpurun_out/final/pmc_$c.txt
   python $R/tools/prof_pmc.py $db --last paged_attn_decode_kernel 560 >> $R/gpurun_out/final/pmc_$c.txt
 done
-cd $R; ls -la gpurun_out/final; cat gpurun_out/final/pytest_gpu.txt gpurun_out/final/smoke.txt; head -c 700 gpurun_out/final/bench.json; cat gpurun_out/final/prefill_step_breakdown.txt; tail -2 gpurun_out/final/pmc_FETCH_SIZE.txt; tail -1 gpurun_out/final/pmc_WRITE_SIZE.txt
+cd $R
+python tools/attn_traffic_json.py gpurun_out/final/pmc_FETCH_SIZE.txt gpurun_out/final/pmc_WRITE_SIZE.txt \
+  gpurun_out/final/bench_under_kernel_trace.json gpurun_out/final/attn_traffic.json > /dev/null
+ls -la gpurun_out/final; cat gpurun_out/final/pytest_gpu.txt gpurun_out/final/smoke.txt; head -c 700 gpurun_out/final/bench.json; cat gpurun_out/final/prefill_step_breakdown.txt; tail -2 gpurun_out/final/pmc_FETCH_SIZE.txt; tail -1 gpurun_out/final/pmc_WRITE_SIZE.txt
