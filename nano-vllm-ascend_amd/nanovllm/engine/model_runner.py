@@ -362,7 +362,7 @@ class ModelRunner:
         self.step_events = [torch.cuda.Event() for _ in range(2)]
         self._events_recorded = [False, False]
         # prefill metadata staging: ids + positions (8 B) + slots (4 B) per token, per-sequence vectors, tables
-        nbytes = cfg.max_num_batched_tokens * 20 + B * (W + 4) * 4 + 4096
+        nbytes = cfg.max_num_batched_tokens * 20 + B * (W + 5) * 4 + 4096
         # (two pinned buffers, alternating: launch_prefill queues a step behind the one whose upload may not have run;
         # ONE device buffer - the uploads are ordered on the stream behind the kernels that read the previous contents)
         self.prefill_hosts = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
@@ -431,8 +431,11 @@ class ModelRunner:
         alternate: the upload of the step before last is done (its tokens were collected) when one is reused."""
         m = batch_meta.prefill_meta(seqs, self.block_size, skip_cached=self.config.prefix_aware_prefill)
         self._pflip ^= 1
+        # (the sampler's temperatures travel in the same staging buffer: a pinned allocation per step - the reference's
+        # prepare_sample, model_runner.py:368-372 - is a first-use cost in every new size class, i.e. in a request's TTFT)
+        temps = np.fromiter((0.0 if s.greedy else s.temperature for s in seqs), dtype=np.float32, count=len(seqs))
         arrays = (m.input_ids, m.positions, m.slot_mapping, m.cu_seqlens_q, m.cu_seqlens_k, m.kv_lens,
-                  np.ascontiguousarray(m.block_tables))
+                  np.ascontiguousarray(m.block_tables), temps)
         offs, off = [], 0
         for a in arrays:
             offs.append(off)
@@ -456,6 +459,7 @@ class ModelRunner:
                     max_seqlen_q=m.max_seqlen_q, max_seqlen_k=m.max_seqlen_k, slot_mapping=dev(2, torch.int32),
                     context_lens=None, block_tables=dev(6, torch.int32, tuple(m.block_tables.shape)),
                     block_size=self.block_size, kv_lens=dev(5, torch.int32))
+        self._prefill_temps = dev(7, torch.float32)
         return dev(0, torch.int64), dev(1, torch.int64)
 
     def prepare_decode(self, seqs: list[Sequence], bucket: int | None = None):
@@ -470,8 +474,9 @@ class ModelRunner:
         return d["ids"][:bucket], d["pos"][:bucket]
 
     def prepare_sample(self, seqs: list[Sequence]):
-        t = torch.tensor([0.0 if s.greedy else s.temperature for s in seqs], dtype=torch.float32).pin_memory()
-        return t.to(self.device, non_blocking=True)
+        """The temperatures of the prefill step just staged (prepare_prefill uploaded them with the step's metadata)."""
+        assert self._prefill_temps.numel() == len(seqs)
+        return self._prefill_temps
 
     # ------------------------------------------------------------------ graphs
     @torch.inference_mode()
