@@ -31,8 +31,9 @@ when the timed region starts.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   prefill_roofline  MFMA flops of one prefill step (16 x 1024 tokens: projections, causal attention, head) / the wall
-                time of the whole prefill phase (host included; the engine queues the second step behind the first)
-                divided by its steps, vs the 2.5 PFLOP/s dense bf16 peak - the TTFT half of the metric;
+                time of the whole prefill phase (host included: first step() call -> the last step's first tokens on
+                the host; the engine queues the second step behind the first) divided by its steps, vs the 2.5 PFLOP/s
+                dense bf16 peak - the TTFT half of the metric;
   roofline      the dominant kernel (paged_attn_decode, the fused step form the engine runs) timed live
                 with HIP events on its launch stream over the engine's real KV cache: algorithmic KV
                 bytes per launch / average duration vs the 8 TB/s HBM peak; `traffic` = those bytes x
@@ -356,6 +357,12 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
     t_p_end = time.perf_counter()
     prefill_phase_ms = (t_p_end - t_p) * 1e3
     prefill_trace = [dict(r) for r in llm.prefill_trace]
+    # the phase ends when the LAST prefill step's tokens are on the host (its first-token stamp): since round 5 the engine
+    # queues the first decode step behind that step, and the synchronize above waits for it as well - a decode step is
+    # not prefill time
+    stamps = [r["stamp"] for r in prefill_trace if r["stamp"] is not None]
+    if len(stamps) == prefill_steps:
+        prefill_phase_ms = (max(stamps) - t_p) * 1e3
     ttft = sorted(llm.ttft[s.seq_id] for s in seqs)
     for _ in range(args.warmup):
         llm.step()
@@ -430,7 +437,8 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
                              "unit": "TFLOP/s", "frac": pf / (pf_ms * 1e-3) / (PREFILL_MFMA_PEAK * tp),
                              "flops_per_step": pf, "ms_per_step": pf_ms, "tokens_per_step": per_step * PROMPT_LEN,
                              "what": "the engine's prefill steps (projections + causal attention + head): wall time of the "
-                                     "whole prefill phase incl. host / its steps"},
+                                     "whole prefill phase incl. host (first step() call -> the last step's tokens on the "
+                                     "host) / its steps"},
         "step_roofline": {"bound": "hbm", "achieved": algo / elapsed / 1e9, "peak": HBM_PEAK / 1e9 * n_dev,
                           "unit": "GB/s", "frac": algo / elapsed / (HBM_PEAK * n_dev),
                           "bytes_per_step": algo / args.steps},
