@@ -45,7 +45,8 @@ def _torch_dtype_of(hf_config) -> torch.dtype:
 
 
 # token / sequence buckets of the captured PREFILL steps (capture_prefill_graphs)
-PREFILL_GRAPH_TOKENS = (64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096)
+# (steps of ~1/8 above 256 tokens: a step is padded to its bucket, and these steps are device-bound)
+PREFILL_GRAPH_TOKENS = (64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560, 3072, 3584, 4096)
 PREFILL_GRAPH_SEQS = (1, 2, 4)
 
 

@@ -8,7 +8,11 @@ SEL="gpu"; [ -n "$SLOW" ] && SEL="gpu or gpu_slow"
 timeout 1500 python -m pytest tests -q -m "$SEL" --durations=15 2>&1 | tail -24 > gpurun_out/final/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > gpurun_out/final/smoke.txt
 timeout 600 python bench.py 2>&1 | grep '^{"metric"' > gpurun_out/final/bench.json
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep '^{"metric"' > gpurun_out/final/bench_driver_cmd.json
+for i in 1 2 3 4 5; do  # the driver's exact command, five fresh processes (the first with the CPU baseline, as the driver runs it)
+  extra="--no-cpu-baseline"; [ "$i" = 1 ] && extra=""
+  timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 $extra 2>/dev/null | grep '^{"metric"' > gpurun_out/final/bench_driver_cmd_$i.json
+done
+bash tools/serving_round.sh final > gpurun_out/final/serving_summary.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $R/bench.py --no-cpu-baseline > /tmp/log_kt 2>&1
 grep '^{"metric"' /tmp/log_kt > $R/gpurun_out/final/bench_under_kernel_trace.json
