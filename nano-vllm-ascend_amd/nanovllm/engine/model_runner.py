@@ -250,6 +250,13 @@ class ModelRunner:
 
     def loop(self):
         """TP worker main loop (rank > 0): execute whatever rank 0 publishes."""
+        if self.config.gc_control:
+            # a full collection on ONE worker stalls every rank at the next exchange for as long as it takes (~100 ms with
+            # torch + the model alive); everything alive now is permanent: out of the collector's sight (engine/host_gc.py)
+            import gc
+
+            gc.collect()
+            gc.freeze()
         while True:
             method, seqs, is_prefill, extra = self.channel.recv()
             if method == "exit":
