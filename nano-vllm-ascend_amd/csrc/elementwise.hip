@@ -108,10 +108,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
 // has 1/WPR of the partial loads in flight (a row of 1024 columns with 4 splits is 16 fragment loads per
 // lane for one wave, 4 for four).  Sum of squares: lane partials -> wave shuffle tree -> the WPR wave
 // sums added in wave order through LDS.
+// PART = 0: x is a finished bf16 tensor (`xb`: mi_add_rmsnorm for a few rows of many columns - hidden 4096 / 5120 models,
+// whose rows one wave per row walks in ten dependent-looking 16-byte loads per operand).
 template <int PART, int WPR>
 __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
     const float* __restrict__ part, const uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
-    uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows, int cols, float eps) {
+    uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows, int cols, float eps,
+    const uint16_t* __restrict__ xb = nullptr) {
   __shared__ float wave_ss[WPR];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nvec = cols >> 3;
@@ -124,22 +127,30 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows_kernel(
   for (int i = 0; i < MAXV; ++i) {
     const int vec = tid + i * WPR * 64;
     if (vec < nvec) {
-      f32x4 plo[PART], phi[PART];
+      u32x4 raw;
+      u32x4 rr;
+      if constexpr (PART == 0) {
+        raw = *reinterpret_cast<const u32x4*>(xb + off + vec * 8);
+        rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
+        wr[i] = *reinterpret_cast<const u32x4*>(w + vec * 8);
+      } else {
+        f32x4 plo[PART > 0 ? PART : 1], phi[PART > 0 ? PART : 1];
 #pragma unroll
-      for (int sp = 0; sp < PART; ++sp) {
-        const float* pp = part + ((int64_t)sp * rows + row) * cols + vec * 8;
-        plo[sp] = *reinterpret_cast<const f32x4*>(pp);
-        phi[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
-      }
-      const u32x4 rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
-      wr[i] = *reinterpret_cast<const u32x4*>(w + vec * 8);
-      f32x4 lo = plo[0], hi = phi[0];
+        for (int sp = 0; sp < PART; ++sp) {
+          const float* pp = part + ((int64_t)sp * rows + row) * cols + vec * 8;
+          plo[sp] = *reinterpret_cast<const f32x4*>(pp);
+          phi[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+        rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
+        wr[i] = *reinterpret_cast<const u32x4*>(w + vec * 8);
+        f32x4 lo = plo[0], hi = phi[0];
 #pragma unroll
-      for (int sp = 1; sp < PART; ++sp) {
-        lo += plo[sp];
-        hi += phi[sp];
+        for (int sp = 1; sp < PART; ++sp) {
+          lo += plo[sp];
+          hi += phi[sp];
+        }
+        raw = u32x4{pack_bf(lo[0], lo[1]), pack_bf(lo[2], lo[3]), pack_bf(hi[0], hi[1]), pack_bf(hi[2], hi[3])};
       }
-      const u32x4 raw = {pack_bf(lo[0], lo[1]), pack_bf(lo[2], lo[3]), pack_bf(hi[0], hi[1]), pack_bf(hi[2], hi[3])};
       u32x4 ro;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -809,6 +820,18 @@ extern "C" int mi_add_rmsnorm(const mi_bf16* x, const mi_bf16* residual, const m
   if (!aligned16(x) || !aligned16(residual) || !aligned16(w) || !aligned16(y) || !aligned16(residual_out))
     return MI_EINVAL;
   if (rows == 0) return MI_OK;
+  // a few rows of many columns (decode steps of hidden 2048 ... 8192 models whose row-parallel projections deliver
+  // finished rows): four or eight waves per row instead of one (a Qwen3-32B TP-8 rank's two norms: 6.7 -> ... us each,
+  // profiles/r05_kbench_32b_norm.txt); the same arithmetic and rounding points, another grouping of the fp32 sum of squares
+  if (rows <= 64 && cols > 1024 && cols <= 8 * 64 * 8 * 2 && tuning(MI_TUNE_NORM_WPR) == 4) {
+    if (cols <= 4 * 64 * 8 * 2)
+      hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<0, 4>), dim3(rows), dim3(256), 0, S(stream), nullptr, residual, w, y,
+                         residual_out, rows, cols, eps, x);
+    else
+      hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<0, 8>), dim3(rows), dim3(512), 0, S(stream), nullptr, residual, w, y,
+                         residual_out, rows, cols, eps, x);
+    return check_launch();
+  }
   return launch_rmsnorm<true>(x, nullptr, 0, (int64_t)cols, 1, residual, w, y, residual_out, rows, cols, eps,
                               S(stream));
 }
@@ -834,6 +857,11 @@ extern "C" int mi_add_rmsnorm_splitk(const float* partials, int nsplit, const mi
     }                                                                                                         \
     if (rows <= 64 && wpr == 4 && cols <= 4 * 64 * 8 * 2) {                                                   \
       hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<NS, 4>), dim3(rows), dim3(256), 0, S(stream),         \
+                         partials, residual, w, y, residual_out, rows, cols, eps);                            \
+      return check_launch();                                                                                  \
+    }                                                                                                         \
+    if (rows <= 64 && wpr == 4 && cols <= 8 * 64 * 8 * 2) {                                                   \
+      hipLaunchKernelGGL((add_rmsnorm_splitk_rows_kernel<NS, 8>), dim3(rows), dim3(512), 0, S(stream),         \
                          partials, residual, w, y, residual_out, rows, cols, eps);                            \
       return check_launch();                                                                                  \
     }                                                                                                         \

@@ -263,6 +263,10 @@ class Qwen3Model(nn.Module):
         """Split K over enough workgroups that a small-N projection still covers the 256 CUs."""
         n, k = weight.shape
         want = max(1, 256 // max(1, n // 16))  # 512 workgroups measured slower (1.70 vs 1.68 ms per step)
+        if want == 1 and k >= 8192:
+            # plenty of row tiles but a long K (hidden 5120 models on one GPU: o_proj 5120 x 8192, down 5120 x 25600): four K
+            # slices measured 21.8 vs 28.5 us and 71 vs 87 us (profiles/r05_kbench_32b_pipe.txt), the norm sums them
+            want = 4
         ks = 1
         while ks * 2 <= min(want, 16) and k % (ks * 2 * 128) == 0:
             ks *= 2

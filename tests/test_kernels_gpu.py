@@ -105,6 +105,28 @@ def test_rmsnorm_random(ops, rows, cols):
     assert torch.equal(rd.cpu().view(torch.int16), ro.view(torch.int16))
 
 
+@pytest.mark.parametrize("rows,cols", [(32, 4096), (64, 5120), (16, 2048), (1, 8192), (5, 4104), (32, 1032), (64, 8192)])
+def test_add_rmsnorm_few_wide_rows(ops, rows, cols):
+    """Round 5: up to 64 rows of 1032 ... 8192 columns (decode steps of hidden 2048 ... 8192 models) run four or eight
+    waves per row (add_rmsnorm_splitk_rows_kernel<0 | NS, 4 | 8>), for finished bf16 rows and for split-K partials:
+    the reference's arithmetic (layernorm.py:27-38: variance of the un-rounded sum), residual bit-exact."""
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2).bfloat16()
+    r = torch.randn(rows, cols, generator=g).bfloat16()
+    w = (1 + 0.2 * torch.randn(cols, generator=g)).bfloat16()
+    yo, ro = oracle.add_rms_norm(x, r, w, 1e-6)
+    y, r2 = ops.add_rmsnorm(x.to(DEV), r.to(DEV), w.to(DEV), 1e-6)
+    assert_bf16_close(y, yo)
+    assert torch.equal(r2.cpu().view(torch.int16), ro.view(torch.int16))
+    for ns in (2, 4):  # the same rows as fp32 partials whose sum rounds to x exactly (x + tiny, -tiny, 0 ...)
+        parts = torch.zeros(ns, rows, cols)
+        parts[0] = x.float() + 2.0 ** -20
+        parts[1] = -(2.0 ** -20)
+        y2, r3 = ops.add_rmsnorm_splitk(parts.to(DEV), r.to(DEV), w.to(DEV), 1e-6)
+        assert_bf16_close(y2, yo)
+        assert torch.equal(r3.cpu().view(torch.int16), ro.view(torch.int16))
+
+
 def test_rmsnorm_strided_heads(ops):
     """per-head q/k norm on strided views of a packed qkv row (qwen3.py:79-85)"""
     g = torch.Generator().manual_seed(5)

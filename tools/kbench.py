@@ -215,6 +215,50 @@ def chain_32b_shard():
         "us": t * 1e6, "MB": byt / 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}}, indent=1))
 
 
+def chain_32b_one_gpu():
+    """The six non-attention launches of a decode layer of the UNSHARDED Qwen3-32B (hidden 5120, 64 q / 8 kv heads,
+    intermediate 25600) on one GPU, bs 32, over 2 rotating layers: the row-parallel projections as complete rows +
+    add_rmsnorm, and as split-K 4 partials + add_rmsnorm_splitk (models/qwen3.py::_ksplit for long K)."""
+    H, hq, hkv, inter, B, L = 5120, 64, 8, 25600, 32, 2
+    mk = lambda n, k: ops.pack_weight((torch.randn(n, k, device=DEV) * 0.02).bfloat16())  # noqa: E731
+    qkv = [mk((hq + 2 * hkv) * 128, H) for _ in range(L)]
+    o = [mk(H, hq * 128) for _ in range(L)]
+    gu = [mk(2 * inter, H) for _ in range(L)]
+    dn = [mk(H, inter) for _ in range(L)]
+    wn = torch.ones(H, device=DEV).bfloat16()
+    x = torch.randn(B, H, device=DEV).bfloat16()
+    attn_out = torch.randn(B, hq * 128, device=DEV).bfloat16()
+    res_ = torch.randn(B, H, device=DEV).bfloat16()
+    parts0 = torch.randn(4, B, H, device=DEV) * 0.1
+
+    def rows(l):
+        xn, r = ops.add_rmsnorm(x, res_, wn, 1e-6)
+        ops.gemm_packed(xn, qkv[l])
+        y = ops.gemm_packed(attn_out, o[l])
+        xn, r = ops.add_rmsnorm(y, r, wn, 1e-6)
+        a = ops.gemm_packed(xn, gu[l], silu_mul=True)
+        ops.gemm_packed(a, dn[l])
+
+    def splitk(l):
+        xn, r = ops.add_rmsnorm_splitk(parts0, res_, wn, 1e-6)
+        ops.gemm_packed(xn, qkv[l])
+        p = ops.gemm_packed_splitk(attn_out, o[l], 4)
+        xn, r = ops.add_rmsnorm_splitk(p, r, wn, 1e-6)
+        a = ops.gemm_packed(xn, gu[l], silu_mul=True)
+        ops.gemm_packed_splitk(a, dn[l], 4)
+
+    byt = ((hq + 2 * hkv) * 128 * H + H * hq * 128 + 2 * inter * H + H * inter) * 2
+    out = {}
+    for name, fn in (("complete rows + add_rmsnorm", rows), ("split-K 4 + add_rmsnorm_splitk", splitk)):
+        t = min(timeit(fn, L, reps=3) for _ in range(3))
+        out[name] = {"us": t * 1e6, "MB": byt / 1e6, "GB/s": byt / t / 1e9, "frac": byt / t / PEAK}
+    t = min(timeit(lambda l: ops.add_rmsnorm(x, res_, wn, 1e-6), 1, reps=28) for _ in range(3))
+    out["add_rmsnorm 32 x 5120 alone"] = {"us": t * 1e6}
+    t = min(timeit(lambda l: ops.add_rmsnorm_splitk(parts0, res_, wn, 1e-6), 1, reps=28) for _ in range(3))
+    out["add_rmsnorm_splitk 4 x 32 x 5120 alone"] = {"us": t * 1e6}
+    print(json.dumps({"Qwen3-32B on one GPU, 6 launches per layer": out}, indent=1))
+
+
 def gemms_32b_shard():
     """Each projection of a Qwen3-32B TP 8 rank (and of the unsharded 32B layer) alone, bs 32: packed / split-K /
     complete-row variants, 4 rotating weight copies."""
@@ -253,6 +297,8 @@ def main():
         return moe_block()
     if os.environ.get("KBENCH_ONLY") == "32b":
         return chain_32b_shard()
+    if os.environ.get("KBENCH_ONLY") == "32b_tp1":
+        return chain_32b_one_gpu()
     if os.environ.get("KBENCH_ONLY") == "plain":
         return plain_attention()
     if os.environ.get("KBENCH_ONLY") == "prefill_order":
