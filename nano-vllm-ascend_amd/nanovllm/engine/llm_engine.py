@@ -88,7 +88,7 @@ class LLMEngine:
         self.prefill_lookahead_min_tokens = (config.prefill_lookahead_min_tokens
                                              if config.prefill_lookahead_min_tokens >= 0 else 4096)
         self.prefill_lookahead_launches = 0
-        self.prefill_trace: list[dict] = []  # one record per prefill step (see _trace_prefill)
+        self.prefill_trace: list[dict] = []  # one record per prefill step (see _launch_prefill)
         self.gc = HostGc(enabled=config.gc_control and os.environ.get("MI355_GC_CONTROL", "1") != "0")
         self._exited = False
         if kwargs.get("warmup", True):
@@ -359,10 +359,12 @@ class LLMEngine:
             sampling_params = [sampling_params] * len(prompts)
         # every prompt is checked before any is queued: one over-long prompt must not leave the others behind in the
         # scheduler as orphans of a call that raised
-        if self.tokenizer is not None:
+        if any(isinstance(p, str) for p in prompts):
+            if self.tokenizer is None:
+                raise ValueError("this model directory has no tokenizer: pass token ids")
             prompts = [self.tokenizer.encode(p) if isinstance(p, str) else p for p in prompts]
         for prompt in prompts:
-            if not isinstance(prompt, str) and len(prompt) > self.scheduler.max_model_len:
+            if len(prompt) > self.scheduler.max_model_len:
                 raise ValueError(f"prompt of {len(prompt)} tokens exceeds max_model_len = {self.scheduler.max_model_len} "
                                  "(Config.max_model_len, clamped to the model's max_position_embeddings)")
         for prompt, sp in zip(prompts, sampling_params):
