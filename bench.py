@@ -41,7 +41,13 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   chain_roofline the six non-attention launches of a layer over all layers' weights;
   step_roofline the whole decode step against BASELINE.md's bytes(B, ctx) model;
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's arithmetic) timed on
-                this host on a bounded sample of the same workload.
+                this host on a bounded sample of the same workload;
+  prefill_steps_ms  per prefill step: when its launch sequence started, the host's launch time, the device time (HIP
+                events around the step on the launch stream), when its first tokens were stamped - the line can say
+                where a TTFT went;
+  gc            the garbage collector during the run (engine/host_gc.py): collections inside the prefill phase and
+                the timed region with their generation and duration - no full pass may run inside a step;
+  speedup_vs_1gpu (N > 1)  `value` (and `tp_run.value`) as a multiple of the newest committed one-GPU line.
 """
 from __future__ import annotations
 

@@ -246,6 +246,28 @@ def _body_rpc_channel_multipart(rank, world, port):
     ch.close()
 
 
+def _body_rpc_channel_reader_gone(rank, world, port):
+    """A worker that stops reading: rank 0 must fail loudly when the ring is full, never overwrite an unread part."""
+    from nanovllm.engine import rpc
+    from nanovllm.engine.sequence import Sequence
+    from nanovllm.sampling_params import SamplingParams
+
+    rpc.ACK_TIMEOUT_S = 1.0
+    ch = rpc.StepChannel(port + 1, world, rank, 96)
+    if rank == 0:
+        s = Sequence(list(range(900)), SamplingParams(max_tokens=4), block_size=16)
+        s.block_table = list(range(s.num_blocks))
+        try:
+            ch.send("run", [s], True)  # eleven parts for a ring of four slots; nobody reads
+            raise AssertionError("send() returned although no part was acknowledged")
+        except RuntimeError as e:
+            assert "has not read part" in str(e)
+        dist.barrier()
+    else:
+        dist.barrier()  # (never calls recv)
+    ch.close()
+
+
 def _body_replicated_scheduling(rank, world, port):
     """Every rank can rebuild identical step metadata from the wire format (the reference's
     multi-rank story: deterministic replicated bookkeeping, ut/test_multi_rank_block_manager.py)."""
@@ -334,6 +356,10 @@ def test_tp2_rpc_channel():
 @pytest.mark.parametrize("world", [2, 4])
 def test_rpc_channel_messages_larger_than_a_slot(world):
     _run("_body_rpc_channel_multipart", world)
+
+
+def test_rpc_channel_fails_loudly_when_a_worker_stops_reading():
+    _run("_body_rpc_channel_reader_gone", 2)
 
 
 def test_tp2_replicated_metadata():
