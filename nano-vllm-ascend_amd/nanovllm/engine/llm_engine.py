@@ -250,6 +250,9 @@ class LLMEngine:
 
     def _stamp_first_tokens(self, seqs) -> float:
         now = perf_counter()
+        if len(self.ttft) >= 1 << 16:  # a serving engine runs for days: keep the newer half (dicts keep insertion order)
+            for key in list(self.ttft)[: 1 << 15]:
+                del self.ttft[key]
         for s in seqs:
             # (a first token is the sequence's only completion token; it may already be counted as pending when the
             # first decode step was queued behind the prefill step, _queue_decode_behind_prefill)
