@@ -386,6 +386,39 @@ int mi_add_rmsnorm_splitk_ex(const float* partials, int nsplit, const mi_bf16* r
                              mi_bf16* y, mi_bf16* residual_out, int rows, int cols, float eps,
                              uint64_t* stamps, mi_stream stream);
 
+/* ---- the decode chain in five launches per layer (csrc/gemm_chain5_kernel.hpp) ----------------------------
+ * RowParallelLinear.forward (linear.py:149-153) + the residual add and the variance of RMSNorm.add_rms_forward
+ * (layernorm.py:27-33) in ONE launch, and the rest of add_rms_forward (layernorm.py:34-38) in the operand load of the
+ * NEXT projection (linear.py:72-73): the two mi_add_rmsnorm_splitk launches of a layer disappear.
+ *
+ * mi_gemm_bf16_rowstat: y = bf16(x[M][K] @ w[N][K]^T) (packed weights, as mi_gemm_bf16_packed);
+ *   s_out[M][N] fp32 = float(y) + float(residual)   (the un-rounded sum the reference normalises),
+ *   residual_out[M][N] = bf16(s_out),
+ *   stat[M][N/16]: per 16-feature tile the sum of s_out^2 in fixed order.
+ *   A workgroup owns 16 features of 8 rows over the whole K: nothing is summed across workgroups.
+ *   ksplit names the split-K geometry (mi_gemm_bf16_packed_splitk) whose fp32 summation order is reproduced - K / 64
+ *   wave slices of 64 in ksplit runs - so that y has that path's bits.  K % 64 == 0, N % 16 == 0, (K / 64) % ksplit == 0,
+ *   1 <= ksplit <= 16.
+ * mi_gemm_bf16_normed: y = x @ w^T (epilogue 0) or SiluAndMul(x @ w^T) (epilogue 1) as mi_gemm_bf16_packed, with
+ *   x[M][K] = bf16(bf16(s * rstd) * norm_w), rstd = 1 / sqrt(sum(stat row) / K + eps) - never written to memory: every
+ *   wave builds its own K-slice in LDS.  nstat = K / 16 partials per row, summed in the order of the decode-sized
+ *   mi_add_rmsnorm_splitk kernel at K = 1024 (the two chains then agree bit for bit).  Up to 32 rows on sixteen
+ *   waves (K a multiple of 1024, or K / 64 in {12, 16}), up to 64 on eight / four; MI_EUNSUPPORTED otherwise.
+ * mi_norm_from_stat: the model's final norm y[rows][cols] from (s, stat).
+ * _ex: instrumented forms (stamps[workgroup][wave][8] as above; the Qwen3-0.6B decode chain's geometries only). */
+int mi_gemm_bf16_rowstat(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16* residual, mi_bf16* residual_out,
+                         float* s_out, float* stat, int M, int N, int K, int ksplit, mi_stream stream);
+int mi_gemm_bf16_normed(const float* s, const float* stat, int nstat, const mi_bf16* norm_w, float eps,
+                        const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K, int epilogue, mi_stream stream);
+int mi_norm_from_stat(const float* s, const float* stat, int nstat, const mi_bf16* norm_w, float eps, mi_bf16* y,
+                      int rows, int cols, mi_stream stream);
+int mi_gemm_bf16_rowstat_ex(const mi_bf16* x, const mi_bf16* w_packed, const mi_bf16* residual, mi_bf16* residual_out,
+                            float* s_out, float* stat, int M, int N, int K, int ksplit, uint64_t* stamps,
+                            mi_stream stream);
+int mi_gemm_bf16_normed_ex(const float* s, const float* stat, int nstat, const mi_bf16* norm_w, float eps,
+                           const mi_bf16* w_packed, mi_bf16* y, int M, int N, int K, int epilogue, uint64_t* stamps,
+                           mi_stream stream);
+
 
 /* ---- plain-layout attention (csrc/attn_plain.hip) -------------------------
  * The same operators (attention.py:22-93, rotary_embedding.py:6-14) for the head geometries the fragment-native

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(WPR * 64) void add_rmsnorm_splitk_rows4_kernel(
     ss += b * b;
   }
   if (on) *reinterpret_cast<u32x2*>(residual_out + off + vec * 4) = ro;
-  ss = wave_sum(on ? ss : 0.f);
+  // nearest partners first: a 16-column tile's four threads add up before anything else, which is the partial sum the
+  // five-launch chain's projections emit per tile (gemm_chain5_kernel.hpp: the two chains agree bit for bit)
+  ss = wave_sum_up(on ? ss : 0.f);
   if (lane == 0) wave_ss[wave] = ss;
   MI_NSTAMP(3);
   __syncthreads();

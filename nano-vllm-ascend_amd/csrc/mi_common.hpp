@@ -92,6 +92,16 @@ __device__ __forceinline__ float wave_sum(float v) {  // the butterfly 32, 16, 8
   v = xor_sum<2>(v);
   return xor_sum<1>(v);
 }
+// the same sum as a tree that starts with the NEAREST partners (1, 2, ..., 32): lanes 4 j .. 4 j + 3 add up first - the
+// grouping the five-launch decode chain's producers can deliver per 16-feature tile (gemm_chain5_kernel.hpp)
+__device__ __forceinline__ float wave_sum_up(float v) {
+  v = xor_sum<1>(v);
+  v = xor_sum<2>(v);
+  v = xor_sum<4>(v);
+  v = xor_sum<8>(v);
+  v = xor_sum<16>(v);
+  return xor_sum<32>(v);
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = xor_max<32>(v);
   v = xor_max<16>(v);

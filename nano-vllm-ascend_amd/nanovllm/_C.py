@@ -114,6 +114,11 @@ _SIGNATURES = {
     "mi_add_rmsnorm_splitk": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_add_rmsnorm_splitk_ex": (c_int, [_p, c_int, _p, _p, _p, _p, c_int, c_int, c_float, _p, _p]),
     "mi_gemm_bf16_packed_ex": (c_int, [_p, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p, _p]),
+    "mi_gemm_bf16_rowstat": (c_int, [_p, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_gemm_bf16_normed": (c_int, [_p, _p, c_int, _p, c_float, _p, _p, c_int, c_int, c_int, c_int, _p]),
+    "mi_norm_from_stat": (c_int, [_p, _p, c_int, _p, c_float, _p, c_int, c_int, _p]),
+    "mi_gemm_bf16_rowstat_ex": (c_int, [_p, _p, _p, _p, _p, _p, c_int, c_int, c_int, c_int, _p, _p]),
+    "mi_gemm_bf16_normed_ex": (c_int, [_p, _p, c_int, _p, c_float, _p, _p, c_int, c_int, c_int, c_int, _p, _p]),
     "mi_moe_shapes_supported": (c_int, [c_int, c_int]),
     "mi_kv_store_plain": (c_int, [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, c_int, _p]),
     "mi_rope_plain": (c_int, [_p, _p, c_int64, _p, c_int64, _p, _p, _p, c_int, c_int, c_int, c_int, _p]),

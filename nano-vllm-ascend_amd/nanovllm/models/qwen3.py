@@ -272,6 +272,23 @@ class Qwen3Model(nn.Module):
             ks *= 2
         return ks
 
+    # the decode chain in five launches per layer (csrc/gemm_chain5_kernel.hpp); MI355_CHAIN5=0: the seven-launch chain
+    CHAIN5 = os.environ.get("MI355_CHAIN5", "0") != "0"
+
+    def _chain5(self, rows: int, hidden: int, tp: int, exchange: bool) -> bool:
+        """One GPU, dense bf16 layers, a batch of at most 32 rows: the shapes the five-launch chain is built for."""
+        if not self.CHAIN5 or tp != 1 or exchange:
+            return False
+        for layer in self.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            if hasattr(mlp, "experts"):
+                return False
+            lins = (attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj)
+            if any(isinstance(l.weight_packed, ops.Fp8Weight) for l in lins):
+                return False
+        l0 = self.layers[0]
+        return ops.chain5_takes(rows, hidden, (l0.self_attn.o_proj.weight.shape[1], l0.mlp.down_proj.weight.shape[1]))
+
     def _forward_streaming(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
         """<= ops.SKINNY_MAX_M (512) tokens - every decode step, and short prefills - in chunks of 64 rows inside the
         kernels: SEVEN launches per layer (the reference's eager decode layer
@@ -350,6 +367,25 @@ class Qwen3Model(nn.Module):
             """linear(rmsnorm(y + res)) -> (out, new residual)"""
             x, res = add_norm(y, is_partials, res, ln)
             return column_parallel(x, lin, silu_mul), res
+
+        if self._chain5(rows, h.shape[1], tp, exchange):
+            # FIVE launches per layer: the row-parallel projections add the residual and emit the norm statistic, the
+            # column-parallel ones normalise on load (csrc/gemm_chain5_kernel.hpp) - the bits of the seven-launch chain
+            residual = s = stat = None
+            for layer in self.layers:
+                attn, mlp = layer.self_attn, layer.mlp
+                ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
+                if residual is None:
+                    residual = h
+                    qkv = ops.gemm_packed(ops.rmsnorm(h, ln1.weight, ln1.eps), attn.qkv_proj.weight_packed)
+                else:
+                    qkv = ops.gemm_normed(s, stat, ln1.weight, ln1.eps, attn.qkv_proj.weight_packed)
+                o = attend(attn, qkv)
+                s, residual, stat = ops.gemm_rowstat(o, attn.o_proj.weight_packed, residual, self._ksplit(attn.o_proj.weight))
+                act = ops.gemm_normed(s, stat, ln2.weight, ln2.eps, mlp.gate_up_proj.weight_packed, silu_mul=True)
+                s, residual, stat = ops.gemm_rowstat(act, mlp.down_proj.weight_packed, residual,
+                                                     self._ksplit(mlp.down_proj.weight))
+            return ops.norm_from_stat(s, stat, self.norm.weight, self.norm.eps)
 
         residual, parts, is_partials = None, None, False
         for layer in self.layers:

@@ -665,6 +665,69 @@ def add_rmsnorm_splitk(partials, residual, w, eps: float, out=None, residual_out
     return out, residual_out
 
 
+# ---- the decode chain in five launches per layer (csrc/gemm_chain5_kernel.hpp) ------------------------------
+def chain5_takes(rows: int, hidden: int, ks: tuple) -> bool:
+    """Shapes the five-launch chain is built for: a decode-sized batch, consumers (qkv, gate_up; K = hidden) on sixteen
+    waves, producers (o_proj, down; K in `ks`) in 64-deep wave slices."""
+    return (1 <= rows <= 32 and hidden % 1024 == 0 and hidden // 16 <= 512
+            and all(k % 64 == 0 and any((k // 64) % w == 0 and (k // 64) // w in (1, 2, 3, 4, 5, 6, 8) for w in (16, 12, 8, 4))
+                    for k in ks))
+
+
+def gemm_rowstat(x, w_packed, residual, ksplit: int, stamps=None):
+    """RowParallelLinear + residual add + RMSNorm statistic in one launch (mi_gemm_bf16_rowstat):
+    -> (s fp32 [M, N] = float(bf16(x @ w.T)) + float(residual), residual_out bf16 [M, N], stat fp32 [M, N / 16])."""
+    require_gpu(x, w_packed, residual)
+    _bf16(x, w_packed, residual)
+    assert x.is_contiguous() and residual.is_contiguous() and w_packed.is_contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w_packed.shape[0]
+    assert w_packed.shape[1] == K and residual.numel() == M * N
+    s = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    res = torch.empty_like(residual)
+    stat = torch.empty((M, N // 16), dtype=torch.float32, device=x.device)
+    if stamps is None:
+        check(lib.mi_gemm_bf16_rowstat(ptr(x), ptr(w_packed), ptr(residual), ptr(res), ptr(s), ptr(stat), M, N, K,
+                                       ksplit, stream()), "mi_gemm_bf16_rowstat")
+    else:
+        check(lib.mi_gemm_bf16_rowstat_ex(ptr(x), ptr(w_packed), ptr(residual), ptr(res), ptr(s), ptr(stat), M, N, K,
+                                          ksplit, ptr(stamps), stream()), "mi_gemm_bf16_rowstat_ex")
+    return s, res, stat
+
+
+def gemm_normed(s, stat, norm_w, eps: float, w_packed, silu_mul: bool = False, out=None, stamps=None) -> torch.Tensor:
+    """linear(rmsnorm(s)) with the norm applied in the operand load (mi_gemm_bf16_normed); (s, stat) from gemm_rowstat."""
+    require_gpu(s, stat, norm_w, w_packed)
+    _bf16(norm_w, w_packed)
+    assert s.dtype == torch.float32 and stat.dtype == torch.float32 and s.is_contiguous() and stat.is_contiguous()
+    M, K = s.shape
+    N = w_packed.shape[0]
+    assert w_packed.shape[1] == K and stat.shape[0] == M and norm_w.numel() == K
+    if out is None:
+        out = torch.empty((M, N // 2 if silu_mul else N), dtype=_BF16, device=s.device)
+    if stamps is None:
+        check(lib.mi_gemm_bf16_normed(ptr(s), ptr(stat), stat.shape[1], ptr(norm_w), float(eps), ptr(w_packed), ptr(out),
+                                      M, N, K, int(silu_mul), stream()), "mi_gemm_bf16_normed")
+    else:
+        check(lib.mi_gemm_bf16_normed_ex(ptr(s), ptr(stat), stat.shape[1], ptr(norm_w), float(eps), ptr(w_packed),
+                                         ptr(out), M, N, K, int(silu_mul), ptr(stamps), stream()), "mi_gemm_bf16_normed_ex")
+    return out
+
+
+def norm_from_stat(s, stat, norm_w, eps: float, out=None) -> torch.Tensor:
+    """rmsnorm(s) from gemm_rowstat's (s, stat): the model's final norm in the five-launch chain."""
+    require_gpu(s, stat, norm_w)
+    _bf16(norm_w)
+    assert s.dtype == torch.float32 and stat.dtype == torch.float32 and s.is_contiguous() and stat.is_contiguous()
+    rows, cols = s.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=_BF16, device=s.device)
+    check(lib.mi_norm_from_stat(ptr(s), ptr(stat), stat.shape[1], ptr(norm_w), float(eps), ptr(out), rows, cols,
+                                stream()), "mi_norm_from_stat")
+    return out
+
+
 def embedding(ids, w, vocab_start: int = 0, out=None) -> torch.Tensor:
     require_gpu(ids, w)
     _bf16(w)
