@@ -432,7 +432,8 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
                               "launch_start_ms": (r["launch_start"] - t_p) * 1e3, "host_launch_ms": r["host_launch_ms"],
                               "device_ms": r["device_ms"],
                               "stamp_ms": (r["stamp"] - t_p) * 1e3 if r["stamp"] is not None else None,
-                              "queued_behind_previous": r["queued_behind_previous"]} for r in prefill_trace],
+                              "queued_behind_previous": r["queued_behind_previous"],
+                              "graph_replay": bool(r.get("graph"))} for r in prefill_trace],
         "prefill_lookahead_min_tokens": llm.prefill_lookahead_min_tokens,
         # the garbage collector during the run (engine/host_gc.py): nothing may run a full pass inside a step
         "gc": {"control": llm.gc.enabled, "settle_ms": llm.gc.stats["settle_ms"],

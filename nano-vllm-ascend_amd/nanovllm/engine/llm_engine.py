@@ -138,6 +138,12 @@ class LLMEngine:
         if (cfg.max_num_seqs >= 2 and per_seq >= 16 and blocks <= len(self.scheduler.block_manager.free_block_ids)
                 and os.environ.get("MI355_WARMUP_FULL_HOUSE", "1") != "0"):  # (the switch exists for A/B runs)
             prompts = [[randint(0, 10000) % self._vocab() for _ in range(per_seq)] for _ in range(cfg.max_num_seqs)]
+            k = min(cfg.max_num_seqs, cfg.max_num_batched_tokens // per_seq)
+            if self.model_runner.can_launch_prefill and k >= 1:
+                # a full house arrives as steps of k sequences of per_seq tokens: captured now, so that both warm-up steps -
+                # and every full-house step after them - replay a graph (ModelRunner._prefill_bucket; other large shapes
+                # are captured when they come by the second time)
+                self.model_runner.ensure_prefill_graph(k * per_seq, k, per_seq)
             self.generate(prompts, SamplingParams(ignore_eos=True, max_tokens=2, greedy=True), use_tqdm=False)
         self.ttft.clear()
 
@@ -145,10 +151,11 @@ class LLMEngine:
         """Queueing step k + 1 behind step k pays when k's device time covers k + 1's launch sequence on the host.  Both
         were just measured by the warm-up's prefill steps (prefill_trace): the host's launch time per step (it does not
         depend on the token count: one launch sequence per layer) and the device's time per token of the longest step."""
-        steps = [t for t in self.prefill_trace if t.get("device_ms") and t["tokens"] >= 1024]
-        if not steps:
+        steps = [t for t in self.prefill_trace if t.get("device_ms") and t["tokens"] >= 1024 and not t.get("captured")]
+        eager = [t for t in steps if not t.get("graph")]  # (the step queued next may be one no graph exists for)
+        if not steps or not eager:
             return
-        launch_ms = sorted(t["host_launch_ms"] for t in steps)[len(steps) // 2]
+        launch_ms = sorted(t["host_launch_ms"] for t in eager)[len(eager) // 2]
         big = max(steps, key=lambda t: t["tokens"])
         per_token_ms = big["device_ms"] / big["tokens"]
         want = int(1.25 * launch_ms / per_token_ms)
@@ -237,12 +244,16 @@ class LLMEngine:
 
     def _launch_prefill(self, seqs, behind_previous: bool = False):
         """Queue a prefill step; the handle carries the step's trace record."""
+        runner = self.model_runner
+        counters = lambda: (getattr(runner, "prefill_graph_replays", 0), getattr(runner, "prefill_graph_lazy_captures", 0))  # noqa: E731
+        replays, captures = counters()
         t0 = perf_counter()
-        handle = self.model_runner.call("launch_prefill", seqs)
+        handle = runner.call("launch_prefill", seqs)
         t1 = perf_counter()
         rec = {"tokens": sum(len(s) - s.num_prefix_tokens for s in seqs), "seqs": len(seqs), "launch_start": t0,
                "launch_end": t1, "host_launch_ms": (t1 - t0) * 1e3, "device_ms": None, "stamp": None,
-               "queued_behind_previous": behind_previous}
+               "queued_behind_previous": behind_previous, "graph": counters()[0] > replays,
+               "captured": counters()[1] > captures}
         if len(self.prefill_trace) >= 4096:  # a serving engine runs for days: keep the tail
             del self.prefill_trace[:2048]
         self.prefill_trace.append(rec)

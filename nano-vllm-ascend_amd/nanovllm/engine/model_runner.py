@@ -48,6 +48,12 @@ def _torch_dtype_of(hf_config) -> torch.dtype:
 # (steps of ~1/8 above 256 tokens: a step is padded to its bucket, and these steps are device-bound)
 PREFILL_GRAPH_TOKENS = (64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048, 2560, 3072, 3584, 4096)
 PREFILL_GRAPH_SEQS = (1, 2, 4)
+# Steps beyond that table (a full house: 16 x 1024 tokens) get a graph LAZILY, keyed by (tokens up to a multiple of 256,
+# sequences up to a power of two, longest query up to a power of two >= 256): captured when a key comes by the second
+# time (or is announced: ensure_prefill_graph), at most PREFILL_LAZY_GRAPHS of them alive, the least recently replayed
+# one evicted; a step that would be padded by more than 1/16 of its tokens stays eager (these steps are device-bound).
+PREFILL_LAZY_GRAPHS = 8
+PREFILL_LAZY_SEQS_CAP = 64  # rows of the static metadata buffer's block table (it is uploaded whole with every step)
 
 
 def graph_buckets(max_num_seqs: int) -> list[int]:
@@ -175,13 +181,19 @@ class ModelRunner:
                 self.graphs.clear()
                 self.graph_logits.clear()
                 reset_context()
-        self.prefill_graphs: dict[tuple[int, int], torch.cuda.CUDAGraph] = {}
-        self.prefill_graph_logits: dict[tuple[int, int], torch.Tensor] = {}
+        self.prefill_graphs: dict[tuple, torch.cuda.CUDAGraph] = {}  # (tb, sb): start-up table; (tb, sb, mq): lazy
+        self.prefill_graph_logits: dict[tuple, torch.Tensor] = {}
         self.prefill_graph_replays = 0
+        self.prefill_graph_lazy_captures = 0
+        self._pg_pool = None
+        self._pg_lazy_seen: dict[tuple, int] = {}   # sightings of keys without a graph (bounded, see _prefill_bucket)
+        self._pg_lazy_lru: list[tuple] = []         # lazily captured keys, least recently replayed first
+        self._pg_lazy_on = False
         if (config.use_graphs and config.prefill_graphs and self.graph_samples and self.can_launch_prefill
                 and os.environ.get("MI355_PREFILL_GRAPHS", "1") != "0"):
             try:
                 self.capture_prefill_graphs()
+                self._pg_lazy_on = bool(self.prefill_graphs) and os.environ.get("MI355_PREFILL_GRAPHS_LAZY", "1") != "0"
             except Exception as e:
                 import warnings
 
@@ -384,9 +396,12 @@ class ModelRunner:
         # captured prefill steps (capture_prefill_graphs) read their metadata at FIXED addresses: one static device buffer
         # [ids i64 T][pos i64 T][slots i32 T][cu_q i32 S+1][cu_k i32 S+1][kv_lens i32 S][temps f32 S][rng u64 2][tables i32 S*W]
         # for the largest bucket, of which a graph uses the leading T_b / S_b entries; two pinned mirrors, alternating
-        tmax = max([t for t in PREFILL_GRAPH_TOKENS if t <= cfg.max_num_batched_tokens] or [0])
-        smax = max([n for n in PREFILL_GRAPH_SEQS if n <= cfg.max_num_seqs] or [0])
-        self._pg_tmax, self._pg_smax = tmax, smax
+        self._pg_tmax = max([t for t in PREFILL_GRAPH_TOKENS if t <= cfg.max_num_batched_tokens] or [0])
+        self._pg_smax = max([n for n in PREFILL_GRAPH_SEQS if n <= cfg.max_num_seqs] or [0])
+        # (the buffer itself holds the largest step there is: the lazily captured large steps read it too)
+        tmax = cfg.max_num_batched_tokens if self._pg_tmax else 0
+        smax = min(cfg.max_num_seqs, PREFILL_LAZY_SEQS_CAP) if self._pg_smax else 0
+        self._pg_tcap, self._pg_scap = tmax, smax
         if tmax and smax:
             off, sp = 0, {}
             for name, nb in (("ids", 8 * tmax), ("pos", 8 * tmax), ("slots", 4 * tmax), ("cu_q", 4 * (smax + 1)),
@@ -541,41 +556,81 @@ class ModelRunner:
         sequences have length 0 (the attention kernel's workgroups for them exit on their query length), so the real rows
         are computed exactly as in an eager step of T_b rows; the step's last-token rows go through the head GEMM with the
         pick epilogue (the sampler's keys, {seed, step} read from the static buffer), as the decode graphs do."""
-        cfg, d = self.config, self.pg_dev
+        cfg = self.config
         text = getattr(self.hf_config, "text_config", self.hf_config)
         if not self._pg_tmax or getattr(text, "num_experts", 0):
             return  # (the sparse block's routing over pad tokens is not worth a graph: eager)
-        pool = None
         for tb in sorted((t for t in PREFILL_GRAPH_TOKENS if t <= self._pg_tmax), reverse=True):
             for sb in sorted((n for n in PREFILL_GRAPH_SEQS if n <= self._pg_smax and n <= tb), reverse=True):
                 if -(-tb // sb) > cfg.max_model_len:
                     continue  # no step of sb sequences has that many tokens (a sequence is at most max_model_len long)
-                self._stage_prefill_static([], tb, sb)
-                set_context(True, cu_seqlens_q=d["cu_q"][:sb + 1], cu_seqlens_k=d["cu_k"][:sb + 1], max_seqlen_q=tb,
-                            max_seqlen_k=tb, slot_mapping=d["slots"][:tb], block_tables=d["tables"][:sb],
-                            block_size=self.block_size, kv_lens=d["kv_lens"][:sb])
-
-                def body(tb=tb, sb=sb):
-                    hidden = self.model(d["ids"][:tb], d["pos"][:tb])
-                    x = ops.gather_last_tokens(hidden, d["cu_q"][:sb + 1])
-                    logits, _ = ops.gemm_packed_pick(x, self.model.lm_head.weight_packed, d["temps"][:sb], d["rng"],
-                                                     self.tokens_dev[:sb])
-                    return logits
-
-                side = torch.cuda.Stream(device=self.device)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    body()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, pool=pool):
-                    logits = body()
-                pool = pool or graph.pool()
-                self.prefill_graphs[(tb, sb)] = graph
-                self.prefill_graph_logits[(tb, sb)] = logits
+                self._capture_prefill_graph((tb, sb))
         reset_context()
         torch.cuda.synchronize()
+
+    def _capture_prefill_graph(self, key: tuple):
+        """One captured prefill step: key (tb, sb) of the start-up table (the attention grid covers queries of up to tb
+        tokens) or (tb, sb, mq) of a lazily captured large step (queries of up to mq tokens).  Leaves the alternation
+        of the pinned staging buffers as it found it (a queued step's handle names its buffer)."""
+        tb, sb = key[0], key[1]
+        mq = key[2] if len(key) > 2 else tb
+        d, flip = self.pg_dev, self._pflip
+        self._stage_prefill_static([], tb, sb)
+        set_context(True, cu_seqlens_q=d["cu_q"][:sb + 1], cu_seqlens_k=d["cu_k"][:sb + 1], max_seqlen_q=mq,
+                    max_seqlen_k=mq, slot_mapping=d["slots"][:tb], block_tables=d["tables"][:sb],
+                    block_size=self.block_size, kv_lens=d["kv_lens"][:sb])
+
+        def body():
+            hidden = self.model(d["ids"][:tb], d["pos"][:tb])
+            x = ops.gather_last_tokens(hidden, d["cu_q"][:sb + 1])
+            logits, _ = ops.gemm_packed_pick(x, self.model.lm_head.weight_packed, d["temps"][:sb], d["rng"],
+                                             self.tokens_dev[:sb])
+            return logits
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self._pg_pool):
+            logits = body()
+        self._pg_pool = self._pg_pool or graph.pool()
+        self.prefill_graphs[key] = graph
+        self.prefill_graph_logits[key] = logits
+        self._pflip = flip
+
+    @staticmethod
+    def _lazy_prefill_key(tokens: int, n_seqs: int, max_q: int) -> tuple[int, int, int] | None:
+        tb = -(-tokens // 256) * 256
+        if (tb - tokens) * 16 > tokens:
+            return None  # padded by more than 1/16: a device-bound step is better off eager
+        sb = 1 << max(0, n_seqs - 1).bit_length()
+        mq = max(256, 1 << max(0, max_q - 1).bit_length())
+        return (tb, sb, mq)
+
+    @torch.inference_mode()
+    def ensure_prefill_graph(self, tokens: int, n_seqs: int, max_q: int) -> bool:
+        """Capture the large-step graph of this shape now (the warm-up announces the full-house shape with it)."""
+        key = self._lazy_prefill_key(tokens, n_seqs, max_q) if self._pg_lazy_on else None
+        if key is None or key[0] > self._pg_tcap or key[1] > self._pg_scap:
+            return False
+        if key not in self.prefill_graphs:
+            self._capture_lazy(key)
+        return True
+
+    def _capture_lazy(self, key: tuple):
+        while len(self._pg_lazy_lru) >= PREFILL_LAZY_GRAPHS:
+            old = self._pg_lazy_lru.pop(0)
+            self.prefill_graphs.pop(old, None)
+            self.prefill_graph_logits.pop(old, None)
+        self._capture_prefill_graph(key)
+        reset_context()
+        torch.cuda.synchronize()
+        self._pg_lazy_lru.append(key)
+        self._pg_lazy_seen.pop(key, None)
+        self.prefill_graph_lazy_captures += 1
 
     def prefill_graph_takes(self, n_seqs: int, n_tokens: int) -> bool:
         """Is a prefill step of n_seqs sequences and at most n_tokens tokens a graph replay (engine: may it be queued
@@ -586,16 +641,41 @@ class ModelRunner:
         sb = next(n for n in PREFILL_GRAPH_SEQS if n >= n_seqs)
         return (tb, sb) in self.prefill_graphs
 
-    def _prefill_bucket(self, seqs: list[Sequence]) -> tuple[int, int] | None:
-        if not self.prefill_graphs or len(seqs) > self._pg_smax:
+    def _prefill_bucket(self, seqs: list[Sequence], note: bool = False) -> tuple | None:
+        """The captured step this prefill step replays, or None (eager).  note=True (once per step, by launch_prefill /
+        run): a large step without a graph is counted, and captured when its key has come by before."""
+        if not self.prefill_graphs or len(seqs) > self._pg_scap:
             return None
         skip = self.config.prefix_aware_prefill
-        tokens = sum(len(s) - (min(s.num_prefix_tokens, len(s) - 1) if skip else 0) for s in seqs)
-        if tokens > self._pg_tmax or max(len(s.block_table) for s in seqs) > self.table_cols:
+        q_lens = [len(s) - (min(s.num_prefix_tokens, len(s) - 1) if skip else 0) for s in seqs]
+        tokens = sum(q_lens)
+        if tokens > self._pg_tcap or max(len(s.block_table) for s in seqs) > self.table_cols:
             return None
-        tb = next(t for t in PREFILL_GRAPH_TOKENS if t >= tokens)
-        sb = next(n for n in PREFILL_GRAPH_SEQS if n >= len(seqs))
-        return (tb, sb) if (tb, sb) in self.prefill_graphs else None
+        if tokens <= self._pg_tmax and len(seqs) <= self._pg_smax:
+            tb = next(t for t in PREFILL_GRAPH_TOKENS if t >= tokens)
+            sb = next(n for n in PREFILL_GRAPH_SEQS if n >= len(seqs))
+            if (tb, sb) in self.prefill_graphs:
+                return (tb, sb)
+        if not self._pg_lazy_on:
+            return None
+        key = self._lazy_prefill_key(tokens, len(seqs), max(q_lens))
+        if key is None or key[0] > self._pg_tcap or key[1] > self._pg_scap:
+            return None
+        if key in self.prefill_graphs:
+            if note:
+                self._pg_lazy_lru.remove(key)
+                self._pg_lazy_lru.append(key)
+            return key
+        if note:
+            seen = self._pg_lazy_seen.get(key, 0) + 1
+            if seen >= 2:
+                self._capture_lazy(key)
+                return key
+            if len(self._pg_lazy_seen) >= 256:  # a serving engine runs for days: forget the oldest sightings
+                for k in list(self._pg_lazy_seen)[:128]:
+                    del self._pg_lazy_seen[k]
+            self._pg_lazy_seen[key] = seen
+        return None
 
     def _stage_prefill_static(self, seqs: list[Sequence], tb: int, sb: int) -> int:
         """prefill_meta(seqs) at the static buffer's fixed offsets, padded to the bucket (pad tokens: id 0, position 0,
@@ -652,8 +732,10 @@ class ModelRunner:
         if not seqs:  # everything got preempted this step (reference would crash)
             return []
         real = len(seqs)
-        if is_prefill and self.prefill_graphs and self._prefill_bucket(seqs) is not None:
-            return self.collect_prefill(self.launch_prefill(seqs))  # (the synchronous loop replays the captured steps too)
+        if is_prefill and self.prefill_graphs:
+            bucket = self._prefill_bucket(seqs, note=True)
+            if bucket is not None:  # (the synchronous loop replays the captured steps too)
+                return self.collect_prefill(self.launch_prefill(seqs, bucket))
         if is_prefill:
             input_ids, positions = self.prepare_prefill(seqs)
             bucket = None
@@ -728,16 +810,17 @@ class ModelRunner:
         return self.world_size == 1 and not self.collective
 
     @torch.inference_mode()
-    def launch_prefill(self, seqs: list[Sequence]):
+    def launch_prefill(self, seqs: list[Sequence], bucket=False):
         """run(seqs, True) without its last step: metadata upload, the model, the sampler and the token copy are queued
         on the stream, an event marks their end; collect_prefill() waits for it.  The engine queues the NEXT prefill
         step between the two (Scheduler.lookahead_prefill) - `last_logits` (the parity hook) then names the logits of
         the step launched LAST, not of the step just collected."""
         real = len(seqs)
+        if bucket is False:  # (a large step may be captured here, on its key's second sighting: before the clock starts)
+            bucket = self._prefill_bucket(seqs, note=True)
         self.prefill_starts[self._pflip ^ 1].record()  # (prepare_prefill / _stage_prefill_static flip to this buffer)
-        bucket = self._prefill_bucket(seqs)
         if bucket is not None:  # a captured step: stage at the fixed addresses, replay, the tokens are picked in the graph
-            b = self._stage_prefill_static(seqs, *bucket)
+            b = self._stage_prefill_static(seqs, bucket[0], bucket[1])
             self.prefill_graphs[bucket].replay()
             self.sampler.step += 1  # the graph sampled with this step (see _stage_prefill_static)
             self.prefill_graph_replays += 1

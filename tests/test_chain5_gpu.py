@@ -70,8 +70,10 @@ def test_rowstat_and_normed_are_the_seven_launch_chain_bit_for_bit(ops, M, K, ks
                        _bits(ops.gemm_packed(xn5, wg, silu_mul=True)))
     # ... and the oracle: RowParallelLinear -> add_rms_forward
     want_x, want_res = oracle.add_rms_norm(oracle.linear(x, w), res, nw, EPS)
+    # (the normalised row: where the projection's bf16 rounding falls on the other side of a tie than the oracle's - fp32
+    # summation order - the sum s moves by one ulp of y and the row by up to two of its own: two stacked roundings)
     assert_bf16_close(res5, want_res, max_frac=2e-2, atol=K * 2.0 ** -22)
-    assert_bf16_close(xn5, want_x, max_frac=2e-2, atol=K * 2.0 ** -20)
+    assert_bf16_close(xn5, want_x, max_ulp=2, max_frac=2e-2, atol=K * 2.0 ** -20)
 
 
 @pytest.mark.parametrize("M,H,K", [(32, 2048, 8192), (5, 2048, 2048), (32, 4096, 4096), (24, 5120, 3200), (16, 1024, 768),
@@ -91,7 +93,7 @@ def test_chain5_other_widths_against_the_oracle(ops, M, H, K):
     want_x, want_res = oracle.add_rms_norm(oracle.linear(x, w), res, nw, EPS)
     assert_bf16_close(res5, want_res, max_frac=2e-2, atol=K * 2.0 ** -22)
     xn = ops.norm_from_stat(s, stat, nw.to(DEV), EPS)
-    assert_bf16_close(xn, want_x, max_frac=2e-2, atol=K * 2.0 ** -20)
+    assert_bf16_close(xn, want_x, max_ulp=2, max_frac=2e-2, atol=K * 2.0 ** -20)
     w2p = ops.pack_weight(w2.to(DEV))
     for silu in (False, True):
         got = ops.gemm_normed(s, stat, nw.to(DEV), EPS, w2p, silu_mul=silu)

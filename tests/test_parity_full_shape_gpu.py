@@ -95,6 +95,44 @@ def test_bench_workload_bs32_paging_invariance_and_decode_equals_reprefill():
         llm.exit()
 
 
+def test_full_house_prefill_steps_replay_a_graph_with_the_eager_steps_bits():
+    """The shape BASELINE.json's TTFT is quoted on: 32 prompts x 1024 tokens under a 16 384-token budget = two prefill
+    steps of 16 x 1024 tokens.  Such a step gets a hipGraph lazily (ModelRunner._prefill_bucket: key (16384, 16, 1024);
+    the engine's warm-up announces the shape, here it is captured on its second sighting): the replayed step must leave
+    the eager step's first-token logits in every bit, and the K / V it stores must give the same decode logits."""
+    from nanovllm import LLM, SamplingParams
+
+    gen = torch.Generator().manual_seed(16)
+    prompts = [torch.randint(0, 10000, (1024,), generator=gen).tolist() for _ in range(32)]
+    sp = SamplingParams(max_tokens=2, ignore_eos=True, greedy=True)
+    llm = LLM(make_model_dir(QWEN3_0_6B), kvcache_block_size=16, max_num_seqs=32, max_num_batched_tokens=16384,
+              max_model_len=4096, num_kvcache_blocks=32 * 66 + 100, warmup=False, synthetic_seed=0, decode_lookahead=False)
+    try:
+        mr = llm.model_runner
+
+        def run():
+            for p in prompts:
+                llm.add_request(p, sp)
+            logits, kinds = [], []
+            while not llm.is_finished():
+                before = (mr.prefill_graph_replays, mr.prefill_graph_lazy_captures)
+                llm.step()
+                logits.append(mr.last_logits[:32].clone())
+                kinds.append((mr.prefill_graph_replays - before[0], mr.prefill_graph_lazy_captures - before[1]))
+            llm.scheduler.block_manager.hash_to_block_id.clear()  # no prefix hits: the same work is redone
+            return logits, kinds
+
+        a_logits, a_kinds = run()
+        b_logits, b_kinds = run()
+        assert a_kinds[:2] == [(0, 0), (1, 1)] and b_kinds[:2] == [(1, 0), (1, 0)], (a_kinds, b_kinds)
+        assert (16384, 16, 1024) in mr.prefill_graphs
+        assert len(a_logits) == len(b_logits) == 3
+        for x, y in zip(a_logits, b_logits):  # step 1: eager vs replay; step 2: replay vs replay; then the decode step
+            assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    finally:
+        llm.exit()
+
+
 def test_teacher_forced_layers_and_fp32_logits_full_qwen3_0p6b():
     """The full-shape model (28 layers, hidden 1024, 16/8 heads, intermediate 3072) against the CPU oracle for
     one decode step of 8 sequences, through exactly the launches the engine's decode step uses (split-K
