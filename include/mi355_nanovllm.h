@@ -226,7 +226,12 @@ int mi_paged_attn_prefill_fused(const mi_bf16* qkv, int64_t qkv_row_stride, cons
  * n_q_heads / n_kv_heads == 2 only (the bench model; MI_EUNSUPPORTED otherwise), same results as variant 0 bit for
  * bit (tests): 1 = the first two K/V chunks requested ahead of the Q preparation; 2 = one workgroup barrier per two
  * chunks; 8 = round 3's V operand reads (ds_read2st64_b64: LDS bank conflicts); 16 = round 3's request path (table
- * read + divisions in front of every chunk request); 24 = 8 + 16; 28 = the round-3 kernel as a whole (4 + 8 + 16). */
+ * read + divisions in front of every chunk request); 24 = 8 + 16; 28 = the round-3 kernel as a whole (4 + 8 + 16);
+ * 32 = round 5's softmax (the chunk maximum BEFORE the exponentials; the product tests the lane's sum of exponentials
+ * instead and computes a maximum only when the reference point has to move: the same results wherever both rescale in
+ * the same chunks); 64 = round 5's request addressing (per-lane 64-bit pointers + global_load_lds; the product keeps the
+ * tile address on the scalar unit: buffer_load ... lds); 96 = the round-5 kernel as a whole.  The round-3 forms
+ * (8, 16, 24, 28) include 96: they are the kernels that were measured then. */
 int mi_paged_attn_prefill_fused_ex(const mi_bf16* qkv, int64_t qkv_row_stride, const mi_bf16* q_w, float eps,
                                    const int64_t* positions, const float* cos_sin, const mi_bf16* k_cache,
                                    const mi_bf16* v_cache, const int32_t* block_table, int table_stride,

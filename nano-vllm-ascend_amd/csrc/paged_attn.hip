@@ -729,7 +729,18 @@ struct QPrep {
 //              (32-lane groups on 64 banks: the same addresses are conflict-free, 2 cycles each).
 //   PV_NOPREF  round 3's block-table read: s_load + s_waitcnt right in front of every chunk request.  Default now: the
 //              block id of the NEXT request is read one chunk ahead, so the wait finds it landed.
-enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16 };
+//   PV_MAXTREE round 5's softmax: the chunk's maximum (a v_max3 tree over the sixteen scores, one v_permlane32_swap) BEFORE
+//              the exponentials, to decide whether the reference point has to move.  Default now: the exponentials are
+//              taken against the current reference point at once and the lane's sum of them - which the running sum needs
+//              anyway - is the test: a sum <= 2^8 bounds every probability by 2^8, the invariant the deferred rescale
+//              keeps; only when some lane's sum exceeds it (the first chunk, a maximum that ran away) is the maximum
+//              computed, the state rescaled and the chunk's exponentials redone.  ~22 VALU instructions per chunk less
+//              in a loop that is bound by its VALU issue (profiles/r05_prefill_attention_pmc.txt).
+//   PV_VADDR   round 5's request addressing: a per-lane 64-bit pointer (five v_lshl_add_u64 + the block-table index kept
+//              in a VGPR: ~13 VALU per chunk) and global_load_lds.  Default now: the tile's address stays on the scalar
+//              unit - a buffer descriptor whose base is the cache block, lane * 16 as the only vector offset - and the
+//              request is buffer_load_dwordx4 ... lds.
+enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16, PV_MAXTREE = 32, PV_VADDR = 64 };
 
 // DB = head_dim / 32 (4, or 2 for head_dim 64: plain q rows only).  G = 7 (Qwen2-0.5B, Qwen2.5-7B) runs as a group
 // of 8 columns per query token whose eighth column is masked out: 4 tokens x 7 heads per wave.
@@ -741,6 +752,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     int n_q_heads, int n_kv_heads, int tpb, int tpb_shift, float scale_log2e, int n_qblocks, int n_pairs, QPrep qp) {
   constexpr bool EARLY = (VAR & PV_EARLY) != 0, PAIR = (VAR & PV_PAIR) != 0, SPLIT_P = (VAR & PV_SPLIT_P) != 0;
   constexpr bool READ2 = (VAR & PV_READ2) != 0, PREF = !(VAR & PV_NOPREF) && !PAIR;
+  constexpr bool MAXTREE = (VAR & PV_MAXTREE) != 0, VADDR = (VAR & PV_VADDR) != 0;
   static_assert(DB == 4 || (!FUSE_Q && VAR == 0), "head_dim 64: the default schedule over prepared q rows");
   constexpr int D = 32 * DB, TILE = 512 * DB;  // head_dim; elements of a 16-token cache tile
   constexpr int GP = G == 7 ? 8 : G;  // columns per query token (a power of two)
@@ -817,7 +829,9 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   // this wave's cache (K or V) at this kv head; the tile of a chunk is then one scalar load + one 64-bit multiply-add
   // away (tiles per block are a power of two for every block size but 48, 80, ...: shifts, not divisions - the
   // request of a chunk is ~40 scalar instructions shorter, and the loop is issue-bound)
-  const uint16_t* const cache_h = ((piece & 2) ? vc : kc) + (int64_t)h * st.head + lane * 8;
+  const uint16_t* const cache_hs = ((piece & 2) ? vc : kc) + (int64_t)h * st.head;  // (wave-uniform)
+  const uint16_t* const cache_h = cache_hs + lane * 8;
+  const uint32_t lane16 = lane * 16;
   // the cache tile this wave fetches for chunk c (past the end: the last chunk again, into a buffer nobody reads -
   // keeps the vmcnt arithmetic uniform), and the block-table entry that holds it
   auto tile_of = [&](int c) {
@@ -883,18 +897,15 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         for (int i = 0; i < 16; ++i)
           if (tok0 + (i & 3) + 8 * (i >> 2) >= limit) s[i] = -INFINITY;
       }
-      // sixteen scores -> one maximum: nested pairs that the compiler folds into v_max3_f32 (8 instead of 15)
-      float mc = fmaxf(fmaxf(fmaxf(fmaxf(s[0], s[1]), s[2]), fmaxf(fmaxf(s[3], s[4]), s[5])),
-                       fmaxf(fmaxf(fmaxf(s[6], s[7]), s[8]), fmaxf(fmaxf(s[9], s[10]), s[11])));
-      mc = fmaxf(mc, fmaxf(fmaxf(fmaxf(s[12], s[13]), s[14]), s[15]));
-      mc = xor32_max(mc) * scale_log2e;  // scale > 0: the max commutes with it
-      const float mn = fmaxf(m, mc);     // finite from chunk 0 on: key 0 is visible to every column
-      // The reference point m of the exponentials only has to stay within kDeferMax (log2 units) of the true running
-      // maximum: probabilities then reach at most 2^kDeferMax, which P - carried as bf16 hi + lo, 16 significant bits at
-      // any magnitude - and the fp32 sums hold without loss.  On random scores some column's maximum moves in most
-      // chunks (the rescale below then ran in ~85 % of them: 64 multiplies + the exp, in an issue-bound loop); it
-      // moves by more than 2^8 practically once, at the first chunk.
-      if (__any(mc > m + kDeferMax)) {  // some column's maximum ran away from the reference: rescale
+      float p[16];
+      auto chunk_max = [&]() __attribute__((always_inline)) {
+        // sixteen scores -> one maximum: nested pairs that the compiler folds into v_max3_f32 (8 instead of 15)
+        float mc = fmaxf(fmaxf(fmaxf(fmaxf(s[0], s[1]), s[2]), fmaxf(fmaxf(s[3], s[4]), s[5])),
+                         fmaxf(fmaxf(fmaxf(s[6], s[7]), s[8]), fmaxf(fmaxf(s[9], s[10]), s[11])));
+        mc = fmaxf(mc, fmaxf(fmaxf(fmaxf(s[12], s[13]), s[14]), s[15]));
+        return xor32_max(mc) * scale_log2e;  // scale > 0: the max commutes with it
+      };
+      auto rescale_to = [&](float mn) __attribute__((always_inline)) {
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         l *= alpha;
 #pragma unroll
@@ -902,13 +913,35 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[j][i] *= alpha;
         m = mn;
-      }
-      float p[16];
+      };
+      auto exps = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], scale_log2e, -m));
-      // four independent partial sums instead of one 16-deep dependent add chain
-      l += ((p[0] + p[4]) + (p[8] + p[12])) + ((p[1] + p[5]) + (p[9] + p[13])) +
-           (((p[2] + p[6]) + (p[10] + p[14])) + ((p[3] + p[7]) + (p[11] + p[15])));
+        for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], scale_log2e, -m));
+        // four independent partial sums instead of one 16-deep dependent add chain
+        return ((p[0] + p[4]) + (p[8] + p[12])) + ((p[1] + p[5]) + (p[9] + p[13])) +
+               (((p[2] + p[6]) + (p[10] + p[14])) + ((p[3] + p[7]) + (p[11] + p[15])));
+      };
+      // The reference point m of the exponentials only has to stay within kDeferMax (log2 units) of the true running
+      // maximum: probabilities then reach at most 2^kDeferMax, which P - carried as bf16 (hi + lo), 8 (16) significant
+      // bits at any magnitude - and the fp32 sums hold without loss.  On random scores some column's maximum moves in
+      // most chunks (a rescale in every such chunk ran in ~85 % of them: 64 multiplies + the exp, in an issue-bound
+      // loop); it moves by more than 2^8 practically once, at the first chunk.
+      float lc;
+      if constexpr (MAXTREE) {
+        const float mc = chunk_max();
+        if (__any(mc > m + kDeferMax)) rescale_to(fmaxf(m, mc));  // (finite from chunk 0 on: key 0 is visible to every column)
+        lc = exps();
+      } else {
+        // no maximum in the common case: a lane's sixteen exponentials against the current reference point add up to at
+        // most 2^kDeferMax exactly when none of them is larger - the same invariant.  (m = -inf at the first chunk: the
+        // exponentials are inf or NaN, the comparison fails, the slow path sets the reference point.)
+        lc = exps();
+        if (__any(!(lc <= 256.0f))) {
+          rescale_to(fmaxf(m, chunk_max()));
+          lc = exps();
+        }
+      }
+      l += lc;
       u32x4 ph[2], pl[2];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -1012,7 +1045,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
       // (every wave requests DB pieces of 1 KiB per chunk: "all but my newest DB" = chunk c has landed)
       if constexpr (DB == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-      {
+      if constexpr (VADDR) {
         // (a block is n_kv_heads x tpb tiles: its element stride fits 32 bits, one s_mul_i32 + s_mul_hi_i32)
         const uint16_t* src = cache_h + (int64_t)rq_blk * (int)st.block + rq_in * TILE;
         uint16_t* dst = &stage[0][piece][0] + rq_slot * (4 * TILE);
@@ -1020,6 +1053,23 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
         for (int i = 0; i < DB; ++i)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 512 * i),
                                            (__attribute__((address_space(3))) void*)(dst + 512 * i), 16, 0, 0);
+      } else {
+        // the tile's address on the scalar unit: descriptor base = this head's tile of cache block rq_blk (64-bit scalar
+        // arithmetic: a cache may be larger than 4 GiB), the lane's 16 bytes as the vector offset, the tile's DB pieces
+        // of 1 KiB as SCALAR offsets (an instruction's immediate offset would move the LDS destination as well)
+        const uint16_t* base = cache_hs + (int64_t)rq_blk * (int)st.block + rq_in * TILE;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base), 0, 2 * TILE, 0x00020000);
+        uint16_t* dst = &stage[0][piece][0] + rq_slot * (4 * TILE);
+#define MI_REQ_PIECE(I)                                                                                                \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 512 * (I)), 16, lane16,   \
+                                           1024 * (I), 0, 0)
+        MI_REQ_PIECE(0);
+        MI_REQ_PIECE(1);
+        if constexpr (DB == 4) {
+          MI_REQ_PIECE(2);
+          MI_REQ_PIECE(3);
+        }
+#undef MI_REQ_PIECE
       }
       if (rq < r_last) {  // advance the request state to chunk rq + 1 (wave-uniform)
         ++rq;
@@ -1035,6 +1085,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
           rq_in -= tpb;
           ++rq_bi;
         }
+        if constexpr (!VADDR) rq_bi = __builtin_amdgcn_readfirstlane(rq_bi);  // (wave-uniform: keep the index scalar)
         rq_blk = table_row[rq_bi];  // used by the NEXT iteration: a whole chunk of compute to land in
       }
       attend(c, rd_slot);
@@ -1300,10 +1351,20 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
     switch (variant) {
       case PV_EARLY: LAUNCH_PRE_AS(2, true, PV_EARLY); break;
       case PV_PAIR: LAUNCH_PRE_AS(2, true, PV_PAIR); break;
-      case PV_READ2: LAUNCH_PRE_AS(2, true, PV_READ2); break;
-      case PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_NOPREF); break;
-      case PV_READ2 | PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_READ2 | PV_NOPREF); break;
-      case PV_SPLIT_P | PV_READ2 | PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_SPLIT_P | PV_READ2 | PV_NOPREF); break;  // round 3
+      // the round-3 forms are the round-3 kernels: with the maximum before the exponentials and per-lane request
+      // pointers (PV_MAXTREE | PV_VADDR), as they were measured.  (Merged V reads + P as hi + lo on top of the
+      // sum-checked softmax gave wrong, run-to-run different results with this compiler - tools/debug/
+      // prefill_variant_determinism.py, variants 12 / 28 of a test build; every form offered here reproduces itself
+      // bit for bit, tests/test_kernels_gpu.py::test_prefill_attention_chunk_pipeline_stress.)
+      case PV_READ2: LAUNCH_PRE_AS(2, true, PV_READ2 | PV_MAXTREE | PV_VADDR); break;
+      case PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_NOPREF | PV_MAXTREE | PV_VADDR); break;
+      case PV_READ2 | PV_NOPREF: LAUNCH_PRE_AS(2, true, PV_READ2 | PV_NOPREF | PV_MAXTREE | PV_VADDR); break;
+      case PV_SPLIT_P | PV_READ2 | PV_NOPREF:  // round 3
+        LAUNCH_PRE_AS(2, true, PV_SPLIT_P | PV_READ2 | PV_NOPREF | PV_MAXTREE | PV_VADDR);
+        break;
+      case PV_MAXTREE: LAUNCH_PRE_AS(2, true, PV_MAXTREE); break;
+      case PV_VADDR: LAUNCH_PRE_AS(2, true, PV_VADDR); break;
+      case PV_MAXTREE | PV_VADDR: LAUNCH_PRE_AS(2, true, PV_MAXTREE | PV_VADDR); break;  // round 5
       default: return MI_EUNSUPPORTED;
     }
     return check_launch();

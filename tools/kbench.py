@@ -83,7 +83,10 @@ def prefill_attention_order():
     cu = (torch.arange(n + 1, dtype=torch.int32) * T).to(DEV)
     kvl = torch.full((n,), T, dtype=torch.int32, device=DEV)
     # variant bits of mi_paged_attn_prefill_fused_ex (include/mi355_nanovllm.h)
-    variants = (("default (P bf16, un-merged V reads, running request state)", 0),
+    variants = (("default (round 6: sum-checked softmax, scalar request addressing)", 0),
+                ("round-5 softmax: chunk maximum before the exponentials (32)", 32),
+                ("round-5 request addressing: 64-bit VALU pointers + global_load_lds (64)", 64),
+                ("the round-5 kernel as a whole (96)", 96),
                 ("P as bf16 hi + lo (4)", 4),
                 ("round-3 V reads: ds_read2st64_b64 (8)", 8),
                 ("round-3 request path: table read + divisions per chunk (16)", 16),
