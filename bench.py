@@ -190,13 +190,14 @@ def _attention_roofline(llm, seqs, iters):
     # read correction) of this same loop, committed under profiles/, give measured / algorithmic bytes for
     # this kernel; the ratio is a property of the access pattern (every K/V tile of the context read once),
     # so it is applied to this run's algorithmic bytes whatever --steps made the contexts
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_ctx_sum = None, None, None
     try:
         import glob
         newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_attn_traffic.json")))[-1]
         with open(newest) as f:
             pmc = json.load(f)
         traffic = pmc["traffic_over_algorithmic"] * algo
+        traffic_ctx_sum = pmc["ctx_sum"]
         traffic_src = f"{os.path.basename(newest)}: measured/algorithmic = {pmc['traffic_over_algorithmic']:.4f} at ctx_sum {pmc['ctx_sum']}"
     except (OSError, KeyError, ValueError, IndexError):
         pass
@@ -206,6 +207,9 @@ def _attention_roofline(llm, seqs, iters):
             "traffic_kind": "derived: this run's algorithmic bytes x the PMC-measured traffic ratio of the committed "
                             "profile (not a counter of this run)",
             "traffic_source": traffic_src,
+            # the contexts the counters were collected at, next to this run's: `traffic` is the profile's ratio applied to
+            # this run's bytes - two different ctx_sums here say so at a glance
+            "traffic_ctx_sum": traffic_ctx_sum, "ctx_sum": ctx_sum,
             "bytes_per_launch": algo, "avg_launch_us": dur * 1e6, "launches_timed": iters * len(attn_mods)}
 
 
@@ -283,15 +287,18 @@ def one_gpu_reference():
     north_star's ">= 6x aggregate at 8 GPUs" is a multiple of.  -> (tokens/s, file name) or (None, None)."""
     import glob
 
-    best = (None, None, -1.0)
-    for path in glob.glob(os.path.join(REPO, "profiles", "r*bench*.json")):
+    best = (None, None, None)
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*bench*.json"))):
         try:
             with open(path) as f:
                 line = json.loads(f.read().strip().splitlines()[-1])
             if line.get("n_gpus") == 1 and line.get("config", {}).get("batch") == BATCH and not line.get("dry_run"):
-                key = (os.path.basename(path)[:3], os.path.getmtime(path))  # round first, then file time
+                # newest round first; within a round the file the round calls final (then by name) - never the file
+                # time, which is arbitrary after a checkout (ADVICE r05)
+                name = os.path.basename(path)
+                key = (name[:3], "final" in name, name)
                 if best[0] is None or key > best[2]:
-                    best = (float(line["value"]), os.path.basename(path), key)
+                    best = (float(line["value"]), name, key)
         except (OSError, ValueError, KeyError, IndexError, TypeError):
             continue
     return best[0], best[1]
@@ -366,6 +373,7 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
     # the phase ends when the LAST prefill step's tokens are on the host (its first-token stamp): since round 5 the engine
     # queues the first decode step behind that step, and the synchronize above waits for it as well - a decode step is
     # not prefill time
+    prefill_phase_to_sync_ms = prefill_phase_ms  # (rounds 1-4's definition: reported beside the other)
     stamps = [r["stamp"] for r in prefill_trace if r["stamp"] is not None]
     if len(stamps) == prefill_steps:
         prefill_phase_ms = (max(stamps) - t_p) * 1e3
@@ -443,6 +451,10 @@ def run_phase(args, mode: str, rank: int, world: int, port: int, model_dir: str)
         "prefill_roofline": {"bound": "mfma", "achieved": pf / (pf_ms * 1e-3) / 1e12, "peak": PREFILL_MFMA_PEAK * tp / 1e12,
                              "unit": "TFLOP/s", "frac": pf / (pf_ms * 1e-3) / (PREFILL_MFMA_PEAK * tp),
                              "flops_per_step": pf, "ms_per_step": pf_ms, "tokens_per_step": per_step * PROMPT_LEN,
+                             # the phase on both clocks: to the last first-token stamp (the definition above, rounds 5+)
+                             # and to the device synchronisation behind it (rounds 1-4; since round 5 that also waits
+                             # for the first decode step queued behind the last prefill step)
+                             "phase_ms_to_last_stamp": prefill_phase_ms, "phase_ms_to_sync": prefill_phase_to_sync_ms,
                              "what": "the engine's prefill steps (projections + causal attention + head): wall time of the "
                                      "whole prefill phase incl. host (first step() call -> the last step's tokens on the "
                                      "host) / its steps"},

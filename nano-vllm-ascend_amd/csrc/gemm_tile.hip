@@ -69,7 +69,8 @@ struct TileArgs {
 
 // Tuning variants of the eight-wave kernel below (mi_gemm_bf16_ex instantiates the combinations it lists - the staggered
 // start V & 1024 and the never-waited DMA V & 256 measured no effect and are not instantiated any more; the timing-only
-// ablations exist in an EXPERIMENTS=1 build; the product entry point uses kDefaultV on the four-wave kernels):
+// ablations lived in round 4's EXPERIMENTS=1 build flavour, removed in round 5 - their numbers are in
+// profiles/r04_gemm_ablation.txt; the product entry point uses kDefaultV on the four-wave kernels):
 //   V & 2    both waves of a SIMD in lockstep (no one-barrier stagger)
 //   V & 4    XCD-rectangle tile order instead of the plain one (tile_of_block; measured equal or slower)
 //   V & 8    8-byte stores in the epilogue (no v_permlane32_swap widening)

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w16_kernel(const TileArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < 16; ++q) read1(0, q);
-  // V & 4096 (measurement, tools/gemm_clock.py): shader cycles and 100 MHz reference ticks of the whole tile loop of
+  // V & 4096 (measurement; round 4 read it with tools/gemm_clock.py, numbers in profiles/r04_gemm_clock.txt): shader cycles and 100 MHz reference ticks of the whole tile loop of
   // every workgroup, written over the first output bytes when everything else is done
   unsigned long long clk0 = 0, ref0 = 0;
   if (V & 4096) {

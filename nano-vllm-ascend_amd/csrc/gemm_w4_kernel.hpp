@@ -363,10 +363,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
       if (BIAS) o += bf2f(a.bias[n0 + fw * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
       return o;
     };
-#ifdef MI_QKV_ABLATE  // timing experiments (tools/sessions): 1 = K heads skipped, 2 = V heads skipped, 3 = both
-    if ((MI_QKV_ABLATE & 1) && !is_v) return;
-    if ((MI_QKV_ABLATE & 2) && is_v) return;
-#endif
     if (!is_v) {
       // The table rows are two dependent global loads away (position, then its cos / sin row) with ONE wave per SIMD to
       // hide them: positions and slots of all four token blocks are requested first, the row of block j + 1 as soon
@@ -506,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const TileArgs a) {
     }
   };
   read_first_groups();
-  // V & 4096 (measurement, tools/gemm_clock.py): shader cycles and 100 MHz reference ticks of the whole tile loop of
+  // V & 4096 (measurement; round 4 read it with tools/gemm_clock.py, numbers in profiles/r04_gemm_clock.txt): shader cycles and 100 MHz reference ticks of the whole tile loop of
   // every workgroup, written over the first output bytes when everything else is done
   unsigned long long clk0 = 0, ref0 = 0;
   if (V & 4096) {

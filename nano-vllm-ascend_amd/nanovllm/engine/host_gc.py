@@ -17,6 +17,12 @@ Policy (`Config.gc_control`, default on):
   * a full collection runs only when the engine is idle (`idle()`: no request anywhere), over what was allocated since
     `settle()` - the frozen part is never walked again.
 
+The policy changes PROCESS-WIDE collector state from a library (`gc.freeze()`, `gc.disable()` inside a step): an
+application that manages the collector itself turns it off with `Config.gc_control = False` (or `MI355_GC_CONTROL=0`,
+which the TP workers honour as well).  Several engines in one process share the frozen heap: the freeze is reference-
+counted (`_FROZEN_BY`), only the last engine to leave unfreezes, and the automatic collector comes back only when no
+engine is inside a step.
+
 `stats` counts what ran where; `watch()` registers a `gc.callbacks` hook that records every collection with its
 generation, duration and whether a step was in progress (bench.py reports it, tests assert on it).
 """
@@ -24,6 +30,26 @@ from __future__ import annotations
 
 import gc
 from time import perf_counter
+
+
+_FROZEN_BY = 0   # engines (HostGc objects) that have settled and not yet released: the heap stays frozen while > 0
+_IN_STEP = 0     # engines currently inside step(): the automatic collector stays off while > 0
+MAX_EVENTS = 4096  # watch(): a serving engine runs for days - keep the tail
+
+
+def freeze_permanent_heap() -> None:
+    """One full collection, then freeze what is alive (a TP worker's start-up: ModelRunner.loop)."""
+    global _FROZEN_BY
+    gc.collect()
+    gc.freeze()
+    _FROZEN_BY += 1
+
+
+def release_permanent_heap() -> None:
+    global _FROZEN_BY
+    _FROZEN_BY = max(0, _FROZEN_BY - 1)
+    if _FROZEN_BY == 0:
+        gc.unfreeze()
 
 
 class HostGc:
@@ -45,8 +71,7 @@ class HostGc:
         if not self.enabled:
             return
         t = perf_counter()
-        gc.collect()
-        gc.freeze()
+        freeze_permanent_heap()
         self.stats["settle_ms"] = (perf_counter() - t) * 1e3
         self.stats["frozen_objects"] = gc.get_freeze_count()
         self._settled = True
@@ -58,20 +83,27 @@ class HostGc:
         if not self.enabled or not self._settled:
             return
         self._settled = False
-        gc.unfreeze()
-        if self._was_enabled:
+        if self.in_step:
+            self.leave_step()
+        release_permanent_heap()  # (another engine of this process may still rely on the frozen heap)
+        if self._was_enabled and _IN_STEP == 0:
             gc.enable()
 
     # ------------------------------------------------------------------ the step loop
     def enter_step(self) -> None:
-        self.in_step = True
-        if self.enabled:
+        global _IN_STEP
+        if self.enabled and not self.in_step:
+            _IN_STEP += 1
             gc.disable()
+        self.in_step = True
 
     def leave_step(self) -> None:
+        global _IN_STEP
+        if self.enabled and self.in_step:
+            _IN_STEP = max(0, _IN_STEP - 1)
+            if self._was_enabled and _IN_STEP == 0:
+                gc.enable()
         self.in_step = False
-        if self.enabled and self._was_enabled:
-            gc.enable()
 
     def slack(self) -> None:
         """The host is about to wait for the device with the next step already queued: the cheap collections go here."""
@@ -96,6 +128,8 @@ class HostGc:
         if phase == "start":
             self._t0 = perf_counter()
         else:
+            if len(self.events) >= MAX_EVENTS:
+                del self.events[:MAX_EVENTS // 2]
             self.events.append({"generation": info["generation"], "ms": (perf_counter() - self._t0) * 1e3,
                                 "in_step": self.in_step, "collected": info.get("collected", 0),
                                 "at": self._t0})

@@ -170,10 +170,22 @@ class LLMEngine:
             return
         self._exited = True
         self.gc.release()
-        self.model_runner.call("exit")
+        try:
+            self.model_runner.call("exit")
+        except RuntimeError as e:  # a worker that is gone never acknowledges the message: the ranks are ended below
+            import warnings
+
+            warnings.warn(f"engine exit: {e}; terminating the worker processes")
+            try:
+                self.model_runner.exit(abort=True)
+            except Exception:  # noqa: BLE001 - teardown goes on
+                pass
+            for p in self.ps:
+                if p.is_alive():
+                    p.terminate()
         del self.model_runner
         for p in self.ps:
-            p.join()
+            p.join(timeout=30)
 
     # ------------------------------------------------------------------ requests
     def add_request(self, prompt: str | list[int], sampling_params: SamplingParams, request_id: str | None = None):
@@ -233,9 +245,9 @@ class LLMEngine:
         token_ids = self.model_runner.call("run", seqs, is_prefill)
         if is_prefill:
             now = self._stamp_first_tokens(seqs)
-            self.prefill_trace.append({"tokens": sum(len(s) - s.num_prefix_tokens for s in seqs), "seqs": len(seqs),
-                                       "launch_start": t0, "launch_end": now, "host_launch_ms": (now - t0) * 1e3,
-                                       "device_ms": None, "stamp": now, "queued_behind_previous": False})
+            self._trace({"tokens": sum(len(s) - s.num_prefix_tokens for s in seqs), "seqs": len(seqs),
+                         "launch_start": t0, "launch_end": now, "host_launch_ms": (now - t0) * 1e3,
+                         "device_ms": None, "stamp": now, "queued_behind_previous": False})
         self.scheduler.postprocess(seqs, token_ids)
         outputs = [(s.seq_id, s.completion_token_ids, s.num_prompt_tokens, s.num_cached_tokens)
                    for s in seqs if s.is_finished]
@@ -254,10 +266,15 @@ class LLMEngine:
                "launch_end": t1, "host_launch_ms": (t1 - t0) * 1e3, "device_ms": None, "stamp": None,
                "queued_behind_previous": behind_previous, "graph": counters()[0] > replays,
                "captured": counters()[1] > captures}
-        if len(self.prefill_trace) >= 4096:  # a serving engine runs for days: keep the tail
+        self._trace(rec)
+        return (handle, rec)
+
+    def _trace(self, rec: dict) -> None:
+        """One record per prefill step, on every path (queued, synchronous, tensor-parallel); a serving engine runs for
+        days: keep the tail."""
+        if len(self.prefill_trace) >= 4096:
             del self.prefill_trace[:2048]
         self.prefill_trace.append(rec)
-        return (handle, rec)
 
     def _stamp_first_tokens(self, seqs) -> float:
         now = perf_counter()

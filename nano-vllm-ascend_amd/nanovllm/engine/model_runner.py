@@ -262,20 +262,31 @@ class ModelRunner:
 
     def loop(self):
         """TP worker main loop (rank > 0): execute whatever rank 0 publishes."""
-        if self.config.gc_control:
+        from nanovllm.engine import host_gc
+        from nanovllm.engine.rpc import ChannelError
+
+        frozen = self.config.gc_control and os.environ.get("MI355_GC_CONTROL", "1") != "0"
+        if frozen:
             # a full collection on ONE worker stalls every rank at the next exchange for as long as it takes (~100 ms with
             # torch + the model alive); everything alive now is permanent: out of the collector's sight (engine/host_gc.py)
-            import gc
+            host_gc.freeze_permanent_heap()
 
-            gc.collect()
-            gc.freeze()
+        def leave(abort: bool):
+            self.exit(abort=abort)
+            if frozen:
+                host_gc.release_permanent_heap()
+
         while True:
-            method, seqs, is_prefill, extra = self.channel.recv()
+            try:
+                method, seqs, is_prefill, extra = self.channel.recv()
+            except ChannelError:  # a torn message: never replay it - leave without the exit barrier, loudly
+                leave(True)
+                raise
             if method == "exit":
-                self.exit()
+                leave(False)
                 return
             if method == "abort":  # rank 0 gave up on a step (an exchange timed out): leave without the exit barrier
-                self.exit(abort=True)
+                leave(True)
                 return
             if method == "launch_decode":  # a step rank 0 queued behind the running one: queue the same step here
                 self.launch_decode(seqs, extra if extra else None)

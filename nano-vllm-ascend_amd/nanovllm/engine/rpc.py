@@ -40,6 +40,13 @@ _DEFAULT_CAPACITY = 1 << 18  # int64 words per slot (2 MiB) when the caller does
 _SLOTS = 4
 _BASE = 8            # word 0: newest generation published; word r (1 <= r < world <= 8): the newest part rank r has consumed
 ACK_TIMEOUT_S = 120.0
+TEARDOWN_ACK_TIMEOUT_S = 2.0  # "exit" / "abort": a worker that died must not hold rank 0's teardown for two minutes
+
+
+class ChannelError(RuntimeError):
+    """The control channel's framing was violated (interleaved parts, a length that contradicts its header, a slot
+    overwritten before it was read).  Raised - never asserted: `python -O` strips asserts, and a worker that went on with
+    a torn message would replay a step the other ranks are not running."""
 
 
 def slot_words(max_num_batched_tokens: int, max_num_seqs: int, max_model_len: int, block_size: int) -> int:
@@ -63,7 +70,8 @@ class StepChannel:
         self.skip_cached_prefix = False  # prefill steps ship only the tokens behind the cached prefix (set by ModelRunner)
         self.parts_sent = 0              # (statistics: parts published, messages that needed more than one)
         self.multipart_messages = 0
-        assert 1 <= world_size <= _BASE
+        if not 1 <= world_size <= _BASE:
+            raise ValueError(f"control channel: world size {world_size} (1 .. {_BASE})")
         _CAPACITY = self.capacity = max(int(capacity_words), _HEADER + 64)  # every rank derives it from the same configuration
         nbytes = (_BASE + _SLOTS * _CAPACITY) * 8
         if rank == 0:
@@ -85,7 +93,7 @@ class StepChannel:
             self.buf = np.ndarray((_BASE + _SLOTS * _CAPACITY,), dtype=np.int64, buffer=self.shm.buf)
         self.generation = 0
 
-    def _wait_for_slot(self, gen: int) -> None:
+    def _wait_for_slot(self, gen: int, timeout_s: float = ACK_TIMEOUT_S) -> None:
         """Part `gen` goes where part gen - _SLOTS lived: every worker must have copied that one out."""
         need = gen - _SLOTS
         if need <= 0 or self.world_size == 1:
@@ -97,9 +105,9 @@ class StepChannel:
             if spins > 2000:
                 time.sleep(0)
                 if deadline is None:
-                    deadline = time.monotonic() + ACK_TIMEOUT_S
+                    deadline = time.monotonic() + timeout_s
                 elif time.monotonic() > deadline:
-                    raise RuntimeError(f"control channel: a worker has not read part {need} after {ACK_TIMEOUT_S:.0f} s "
+                    raise RuntimeError(f"control channel: a worker has not read part {need} after {timeout_s:.0f} s "
                                        f"(acknowledged: {[int(a) for a in acks]})")
 
     def send(self, method: str, seqs: list[Sequence] | None = None, is_prefill: bool = False,
@@ -116,7 +124,9 @@ class StepChannel:
         for k in range(parts):
             piece = body[k * room:(k + 1) * room]
             gen = self.generation + 1
-            self._wait_for_slot(gen)
+            # (teardown messages: a worker that is gone never acknowledges - give up on it quickly, the caller goes on
+            # to terminate the ranks)
+            self._wait_for_slot(gen, TEARDOWN_ACK_TIMEOUT_S if method in ("exit", "abort") else ACK_TIMEOUT_S)
             b = self.buf[_BASE + (gen % _SLOTS) * self.capacity:]
             b[0] = 0  # the slot is being rewritten
             if len(piece):
@@ -143,7 +153,7 @@ class StepChannel:
         head = [int(v) for v in b[1:_HEADER]]
         data = b[_HEADER:_HEADER + head[5]].copy()
         if int(b[0]) != want:  # rank 0 ran more than _SLOTS - 1 parts ahead of this worker: a protocol error
-            raise RuntimeError(f"control channel: message {want} was overwritten before rank {self.rank} read it")
+            raise ChannelError(f"control channel: message {want} was overwritten before rank {self.rank} read it")
         self.generation = want
         self.buf[self.rank] = want  # acknowledged: the slot may be re-used
         return head, data
@@ -153,12 +163,16 @@ class StepChannel:
         chunks = [data]
         while head[6]:
             more, data = self._recv_part()
-            assert more[:5] == head[:5], "control channel: parts of two messages interleaved"
+            if more[:5] != head[:5]:
+                raise ChannelError(f"control channel: parts of two messages interleaved on rank {self.rank} "
+                                   f"({head[:5]} then {more[:5]})")
             head = more
             chunks.append(data)
         method, is_prefill, n_seqs, n, n_extra = _METHODS[head[0]], bool(head[1]), head[2], head[3], head[4]
         body = chunks[0] if len(chunks) == 1 else np.concatenate(chunks)
-        assert len(body) == n + n_extra, "control channel: message length does not match its header"
+        if len(body) != n + n_extra:
+            raise ChannelError(f"control channel: {len(body)} body words on rank {self.rank}, the header announces "
+                               f"{n} + {n_extra}")
         extra = [int(v) for v in body[n:n + n_extra]]
         seqs, pos = [], 0
         for _ in range(n_seqs):

@@ -1,8 +1,8 @@
 """Tile GEMM (mi_gemm_bf16) against the library GEMM behind F.linear on the prefill shapes of the bench
 (16384 tokens x the four Qwen3-0.6B projections) and a few others; every schedule variant of
 mi_gemm_bf16_ex.  Timed as hipGraph replays of REPS back-to-back launches on random data (the guide's rule 25:
-zero-filled operands clock higher).  The timing-only variants (no stores, GEMM_ABLATE=1) exist in an
-EXPERIMENTS=1 build of the library only.  Usage: python tools/gemm_bench.py [out.json]"""
+zero-filled operands clock higher).  (Round 4's timing-only variants - no stores - went with that round's EXPERIMENTS=1
+build flavour; their numbers are in profiles/r04_gemm_ablation.txt.)  Usage: python tools/gemm_bench.py [out.json]"""
 import json
 import os
 import sys
