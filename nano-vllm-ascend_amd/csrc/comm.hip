@@ -248,6 +248,105 @@ __global__ __launch_bounds__(64) void allreduce_add_rmsnorm_kernel(
   if (lane == 0) comm_finish(g, e, rows);
 }
 
+// The same seam for a few WIDE rows (decode batches of hidden 2048 ... 8192 models: a Qwen3-32B TP-8 rank's 32 x 5120):
+// WPR waves per row instead of one, so that a lane has 1 / WPR of the pushes and slot reads in flight (one wave walks a
+// 5120-column row in ten dependent-looking 16-byte steps per operand and peer).  The arithmetic after the rank-ordered sum
+// is add_rmsnorm_splitk_rows_kernel<0, WPR>'s (elementwise.hip: what mi_add_rmsnorm runs on such rows - thread t holds
+// vectors t and t + 64 WPR, the sum of squares goes lane -> wave butterfly -> the waves in order), so the launch is
+// bit-identical to mi_allreduce_sum_bf16 followed by mi_add_rmsnorm on the same rows.
+template <int WPR>
+__global__ __launch_bounds__(WPR * 64) void allreduce_add_rmsnorm_rows_kernel(
+    CommGeom g, const uint16_t* __restrict__ x, const uint16_t* __restrict__ residual,
+    const uint16_t* __restrict__ w, uint16_t* __restrict__ y, uint16_t* __restrict__ residual_out, int rows,
+    int cols, float eps) {
+  __shared__ float wave_ss[WPR];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = cols >> 3;
+  const int64_t off = (int64_t)row * cols;
+  const uint32_t e = comm_epoch(g);
+  const uint32_t par = e & 1u;
+  constexpr int MAXV = 2;  // vectors per thread: cols <= WPR * 64 * 8 * MAXV
+
+  u32x4 mine[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vec = tid + i * WPR * 64;
+    if (vec < nvec) mine[i] = *reinterpret_cast<const u32x4*>(x + off + vec * 8);
+  }
+  for (int k = 1; k <= g.world; ++k) {
+    const int q = (g.rank + k) % g.world;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(comm_slot(g, q, par, g.rank)) + off;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vec = tid + i * WPR * 64;
+      if (vec < nvec) *reinterpret_cast<u32x4*>(dst + vec * 8) = mine[i];
+    }
+  }
+  comm_publish_and_wait(g, e, row, tid, true);  // every wave's pushes are fenced, the first wave's lanes do the flags
+
+  const uint8_t* slots = comm_slot(g, g.rank, par, 0);
+  float v[MAXV][8];
+  u32x4 wr[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vec = tid + i * WPR * 64;
+    if (vec < nvec) {
+      const u32x4 rr = *reinterpret_cast<const u32x4*>(residual + off + vec * 8);
+      wr[i] = *reinterpret_cast<const u32x4*>(w + vec * 8);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < g.world; ++r) {
+        const u32x4 p = *reinterpret_cast<const u32x4*>(
+            reinterpret_cast<const uint16_t*>(slots + (size_t)r * g.slot_stride) + off + vec * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += lo_bf(p[j]);
+          acc[2 * j + 1] += hi_bf(p[j]);
+        }
+      }
+      u32x4 ro;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t sum_bf = pack_bf(acc[2 * j], acc[2 * j + 1]);  // the all-reduce's bf16 result
+        const float a = lo_bf(sum_bf) + lo_bf(rr[j]);
+        const float b = hi_bf(sum_bf) + hi_bf(rr[j]);
+        ro[j] = pack_bf(a, b);
+        v[i][2 * j] = a;
+        v[i][2 * j + 1] = b;
+        ss += a * a;
+        ss += b * b;
+      }
+      *reinterpret_cast<u32x4*>(residual_out + off + vec * 8) = ro;
+    } else {
+      wr[i] = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) wave_ss[wave] = ss;
+  __syncthreads();
+  float tot = wave_ss[0];
+#pragma unroll
+  for (int wv = 1; wv < WPR; ++wv) tot += wave_ss[wv];
+  const float rs = 1.0f / sqrtf(tot / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vec = tid + i * WPR * 64;
+    if (vec < nvec) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = rbf(v[i][2 * j] * rs) * lo_bf(wr[i][j]);
+        const float b = rbf(v[i][2 * j + 1] * rs) * hi_bf(wr[i][j]);
+        o[j] = pack_bf(a, b);
+      }
+      *reinterpret_cast<u32x4*>(y + off + vec * 8) = o;
+    }
+  }
+  if (tid == 0) comm_finish(g, e, rows);  // (every thread's slot reads are in front of the barrier above)
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -360,6 +459,16 @@ extern "C" int mi_allreduce_add_rmsnorm(mi_comm* comm, const mi_bf16* x, const m
   if (rows == 0) return MI_OK;
   const int nvec = cols / 8;
   hipStream_t st = S(stream);
+  // a few wide rows: four or eight waves per row - where mi_add_rmsnorm takes its multi-wave kernel, with its arithmetic
+  if (rows <= 64 && cols > 1024 && tuning(MI_TUNE_NORM_WPR) == 4) {
+    if (cols <= 4 * 64 * 8 * 2)
+      hipLaunchKernelGGL((allreduce_add_rmsnorm_rows_kernel<4>), dim3(rows), dim3(256), 0, st, comm->geom(), x, residual,
+                         weight, out, residual_out, rows, cols, eps);
+    else
+      hipLaunchKernelGGL((allreduce_add_rmsnorm_rows_kernel<8>), dim3(rows), dim3(512), 0, st, comm->geom(), x, residual,
+                         weight, out, residual_out, rows, cols, eps);
+    return check_launch();
+  }
 #define LAUNCH_ARN(V)                                                                                           \
   hipLaunchKernelGGL((allreduce_add_rmsnorm_kernel<V>), dim3(rows), dim3(64), 0, st, comm->geom(), x, residual, \
                      weight, out, residual_out, rows, cols, eps)

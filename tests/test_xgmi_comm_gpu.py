@@ -19,7 +19,7 @@ def _worker(rank, world, port, out):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    comm = XgmiComm(rank, world, 1 << 20, dev)
+    comm = XgmiComm(rank, world, 1 << 20, dev)  # (1 MiB per slot: 65 x 5120 bf16 rows fit)
     try:
         ok = comm.self_test()
         # random values: the kernel sums the bf16 inputs in fp32 in rank order, one rounding at the end
@@ -41,7 +41,10 @@ def _worker(rank, world, port, out):
         from nanovllm import ops
 
         fused_ok = True
-        for rows, cols in ((1, 1024), (32, 1024), (64, 1024), (7, 5120), (5, 512)):
+        # (up to 64 rows of more than 1024 columns run the seam's multi-wave kernel, as mi_add_rmsnorm runs its own: a
+        # Qwen3-32B TP-8 rank's 32 x 5120 decode rows; 65 rows of 5120 stay on one wave per row)
+        for rows, cols in ((1, 1024), (32, 1024), (64, 1024), (7, 5120), (5, 512), (32, 5120), (64, 4096), (8, 8192),
+                           (33, 2048), (65, 5120)):
             g2 = torch.Generator().manual_seed(rows * 10000 + cols)  # same residual / weight on every rank
             res = torch.randn(rows, cols, generator=g2).bfloat16().to(dev)
             w = (1 + 0.1 * torch.randn(cols, generator=g2)).bfloat16().to(dev)
@@ -56,7 +59,7 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_allreduce_ranks_sharing_one_gpu(world):
     import torch.multiprocessing as mp
 

@@ -160,5 +160,63 @@ def main():
             timeline(g5s, stamps5, names5, shapes5)
 
 
+def seam_32b():
+    """the same fusion on the unsharded Qwen3-32B layer's attention seam (hidden 5120: o_proj
+    5120 x 8192 -> add + RMSNorm -> gate_up 51200 x 5120 + SwiGLU), three launches against two.  (The layer's other seam
+    has K = 25600 = 400 wave slices of 64, which the sixteen-wave producer does not divide: not built.)"""
+    Hh, Ko, Ngu, Ls, ks = 5120, 8192, 51200, 4, 4
+    torch.manual_seed(1)
+    mk = lambda n, k: ops.pack_weight((torch.randn(n, k, device=DEV) * 0.02).bfloat16())  # noqa: E731
+    w_o = [mk(Hh, Ko) for _ in range(Ls)]
+    w_gu = [mk(Ngu, Hh) for _ in range(Ls)]
+    wn = torch.ones(Hh, device=DEV).bfloat16()
+    res = torch.randn(B, Hh, device=DEV).bfloat16()
+    o = torch.randn(B, Ko, device=DEV).bfloat16()
+
+    def three(l):
+        x, _ = ops.add_rmsnorm_splitk(ops.gemm_packed_splitk(o, w_o[l], ks), res, wn, 1e-6)
+        return ops.gemm_packed(x, w_gu[l], silu_mul=True)
+
+    def two(l):
+        s, _, stat = ops.gemm_rowstat(o, w_o[l], res, ks)
+        return ops.gemm_normed(s, stat, wn, 1e-6, w_gu[l], silu_mul=True)
+
+    def graph_time(fn, n=10):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for l in range(Ls):
+                fn(l)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for l in range(Ls):
+                fn(l)
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e3 / n / Ls
+
+    with torch.inference_mode():
+        same = torch.equal(three(0).view(torch.int16), two(0).view(torch.int16))
+        t3, t2 = [], []
+        for _ in range(4):
+            t3.append(round(graph_time(three), 1))
+            t2.append(round(graph_time(two), 1))
+    print(f"Qwen3-32B widths on one GPU, bs {B}, the attention seam of a layer (o_proj 5120 x 8192 -> norm -> gate_up 51200 x 5120 "
+          f"+ SwiGLU), us per seam, alternating rounds; outputs equal bit for bit: {same}")
+    print(f"  three launches (split-K 4 o_proj, add+RMSNorm, gate_up): min {min(t3):.1f}   {t3}")
+    print(f"  two launches (o_proj + residual + statistic, gate_up with the norm on load): min {min(t2):.1f}   {t2}")
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("SEAM") == "32b":
+        seam_32b()
+    else:
+        main()

@@ -19,7 +19,7 @@ def worker(rank, world, port):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    comm = XgmiComm(rank, world, 64 * 1024 * 2, dev)
+    comm = XgmiComm(rank, world, 64 * 5120 * 2, dev)
     rows, cols, reps = 32, 1024, 50
     x = torch.randn(rows, cols, device=dev).bfloat16()
     res = torch.randn(rows, cols, device=dev).bfloat16()
@@ -56,6 +56,17 @@ def worker(rank, world, port):
     timed(lambda: check(lib.mi_allreduce_sum_bf16(comm._comm, ptr(res), ptr(y), y.numel(), stream()), "ar"),
           "allreduce_sum_bf16 out of place [32x1024]")
     timed(lambda: ops.add_rmsnorm(x, res, w, 1e-6), "add_rmsnorm alone (no exchange)")
+    # a few wide rows (a Qwen3-32B TP-8 rank's decode step): the seam's multi-wave kernel against one wave per row
+    from nanovllm import _C
+
+    xw = torch.randn(32, 5120, device=dev).bfloat16()
+    rw = torch.randn(32, 5120, device=dev).bfloat16()
+    ww = torch.ones(5120, device=dev).bfloat16()
+    for wpr, name in ((4, "eight waves per row"), (1, "one wave per row (MI_TUNE_NORM_WPR = 1)")):
+        _C.set_tuning(_C.TUNE_NORM_WPR, wpr)
+        timed(lambda: comm.allreduce_add_rmsnorm(xw, rw, ww, 1e-6), f"allreduce_add_rmsnorm [32x5120], {name}")
+        timed(lambda: ops.add_rmsnorm(xw, rw, ww, 1e-6), f"add_rmsnorm alone [32x5120], {name}")
+    _C.set_tuning(_C.TUNE_NORM_WPR, 4)
     assert not comm.timed_out()
     dist.barrier()
     comm.close()
@@ -65,7 +76,7 @@ def worker(rank, world, port):
 if __name__ == "__main__":
     import torch.multiprocessing as mp
 
-    for world in (2, 4):
+    for world in [int(w) for w in sys.argv[1:]] or (1, 2, 4, 8):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
