@@ -239,7 +239,7 @@ class LLMEngine:
         seqs, is_prefill = self.scheduler.schedule()
         if self.lookahead and not is_prefill and seqs and self.model_runner.can_launch_decode(len(seqs)):
             return self._step_lookahead(self.model_runner.call("launch_decode", seqs), seqs, set())
-        if self.lookahead and is_prefill and seqs and self.model_runner.can_launch_prefill:
+        if self.lookahead and is_prefill and seqs and self._prefill_launchable(seqs):
             return self._step_prefill(self._launch_prefill(seqs), seqs)
         t0 = perf_counter()
         token_ids = self.model_runner.call("run", seqs, is_prefill)
@@ -253,6 +253,11 @@ class LLMEngine:
                    for s in seqs if s.is_finished]
         num_tokens = sum(len(s) for s in seqs) if is_prefill else -len(seqs)
         return outputs, num_tokens
+
+    def _prefill_launchable(self, seqs) -> bool:
+        runner = self.model_runner
+        fn = getattr(runner, "prefill_launchable", None)  # (scripted runners of the host tests: the property only)
+        return fn(seqs) if fn is not None else bool(runner.can_launch_prefill)
 
     def _launch_prefill(self, seqs, behind_previous: bool = False):
         """Queue a prefill step; the handle carries the step's trace record."""
@@ -300,7 +305,10 @@ class LLMEngine:
         num_tokens = sum(len(s) for s in seqs)
         decode_plan = None
         if not runner.prefill_done(handle):
-            nxt = sched.lookahead_prefill(seqs, self.prefill_lookahead_min_tokens)
+            # (the NEXT prefill step is admitted ahead only where any step can be queued: a tensor-parallel engine queues
+            # the steps that replay a graph, and what the next admission will be is not known before it is made)
+            nxt = (sched.lookahead_prefill(seqs, self.prefill_lookahead_min_tokens) if runner.can_launch_prefill
+                   else None)
             if nxt:
                 self._inflight_prefill = (self._launch_prefill(nxt, behind_previous=True), nxt)
                 self.prefill_lookahead_launches += 1

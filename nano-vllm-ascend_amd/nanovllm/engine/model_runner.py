@@ -54,6 +54,10 @@ PREFILL_GRAPH_SEQS = (1, 2, 4)
 # one evicted; a step that would be padded by more than 1/16 of its tokens stays eager (these steps are device-bound).
 PREFILL_LAZY_GRAPHS = 8
 PREFILL_LAZY_SEQS_CAP = 64  # rows of the static metadata buffer's block table (it is uploaded whole with every step)
+# Tensor parallelism: a captured prefill step all-reduces its activations over the xGMI exchange region (RCCL on
+# prefill-sized tensors stays outside graphs), whose slots are 2 x world x tokens x hidden x 2 bytes per rank: the table
+# stops here (Qwen3-32B at TP 8: 335 MB per rank)
+TP_PREFILL_GRAPH_TOKENS = 2048
 
 
 def graph_buckets(max_num_seqs: int) -> list[int]:
@@ -114,7 +118,12 @@ class ModelRunner:
         if self.world_size > 1:
             from nanovllm.layers import xgmi_comm
 
-            rows = max(64, min(config.max_num_seqs, 512))  # decode-sized activations; prefill goes through RCCL
+            rows = max(64, min(config.max_num_seqs, 512))  # decode-sized activations; eager prefill goes through RCCL
+            if config.use_graphs and config.prefill_graphs and os.environ.get("MI355_PREFILL_GRAPHS", "1") != "0":
+                # ... captured prefill steps (capture_prefill_graphs) through the region as well: every rank replays the
+                # same graph, whose all-reduces must be kernels of this library, not RCCL calls
+                rows = max(rows, max([t for t in PREFILL_GRAPH_TOKENS
+                                      if t <= min(config.max_num_batched_tokens, TP_PREFILL_GRAPH_TOKENS)] or [0]))
             self.xgmi = xgmi_comm.create_if_enabled(rank, self.world_size, rows * self.hf_config.hidden_size * 2,
                                                     self.device)
             parallel.set_xgmi_comm(self.xgmi)
@@ -189,17 +198,34 @@ class ModelRunner:
         self._pg_lazy_seen: dict[tuple, int] = {}   # sightings of keys without a graph (bounded, see _prefill_bucket)
         self._pg_lazy_lru: list[tuple] = []         # lazily captured keys, least recently replayed first
         self._pg_lazy_on = False
-        if (config.use_graphs and config.prefill_graphs and self.graph_samples and self.can_launch_prefill
+        # one GPU, or tensor-parallel ranks whose exchange region is up (then every collective of a step is a kernel of
+        # this library and the token choice is made among the ranks inside the graph, as in the decode graphs)
+        capturable = self.can_launch_prefill or (self.world_size > 1 and self.xgmi is not None)
+        if (config.use_graphs and config.prefill_graphs and self.graph_samples and capturable
                 and os.environ.get("MI355_PREFILL_GRAPHS", "1") != "0"):
+            ok = True
             try:
+                if self.world_size > 1:
+                    dist.barrier()  # (the capture's warm-up runs exchange with the peers: start together)
                 self.capture_prefill_graphs()
-                self._pg_lazy_on = bool(self.prefill_graphs) and os.environ.get("MI355_PREFILL_GRAPHS_LAZY", "1") != "0"
+                self._pg_lazy_on = (bool(self.prefill_graphs) and self.world_size == 1
+                                    and os.environ.get("MI355_PREFILL_GRAPHS_LAZY", "1") != "0")
             except Exception as e:
                 import warnings
 
                 warnings.warn(f"hipGraph capture of the prefill buckets failed ({e!r}); prefill steps are launched eagerly")
+                ok = False
+            if self.world_size > 1:
+                # every rank replays the same graph or none does: agree (a rank that failed mid-capture has left the
+                # exchange epochs uneven, which the status check of the next step would report - it does not hang)
+                flag = torch.tensor([int(ok)], dtype=torch.int32,
+                                    device=self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item())
+            if not ok:
                 self.prefill_graphs.clear()
                 self.prefill_graph_logits.clear()
+                self._pg_lazy_on = False
                 reset_context()
         if self.collective:
             dist.barrier()
@@ -272,6 +298,15 @@ class ModelRunner:
             host_gc.freeze_permanent_heap()
 
         def leave(abort: bool):
+            stats = os.environ.get("MI355_WORKER_STATS")  # tests / bring-up: what this worker ran, as <prefix>.<rank>.json
+            if stats:
+                import json
+
+                with open(f"{stats}.{self.rank}.json", "w") as f:
+                    json.dump({"rank": self.rank, "steps_run": self._steps_run,
+                               "prefill_graph_replays": self.prefill_graph_replays,
+                               "prefill_graphs": len(self.prefill_graphs),
+                               "lookahead_launches": getattr(self, "lookahead_launches", 0)}, f)
             self.exit(abort=abort)
             if frozen:
                 host_gc.release_permanent_heap()
@@ -290,6 +325,8 @@ class ModelRunner:
                 return
             if method == "launch_decode":  # a step rank 0 queued behind the running one: queue the same step here
                 self.launch_decode(seqs, extra if extra else None)
+            elif method == "launch_prefill":  # a captured prefill step: stage the same metadata, replay the same graph
+                self.launch_prefill(seqs)
             else:
                 self.run(seqs, is_prefill)
 
@@ -299,6 +336,8 @@ class ModelRunner:
         if self.channel is not None and self.rank == 0:
             if method_name == "launch_decode":
                 self.channel.send(method_name, args[0], False, extra=args[1] if len(args) > 1 else None)
+            elif method_name == "launch_prefill":  # (the bucket is every rank's own, equal, decision)
+                self.channel.send(method_name, args[0], True)
             else:
                 self.channel.send(method_name, *args)
         return getattr(self, method_name)(*args)
@@ -404,14 +443,17 @@ class ModelRunner:
         # gives the step's device time to the engine's prefill trace
         self.prefill_starts = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self.prefill_events = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self._prefill_events_recorded = [False, False]
         # captured prefill steps (capture_prefill_graphs) read their metadata at FIXED addresses: one static device buffer
         # [ids i64 T][pos i64 T][slots i32 T][cu_q i32 S+1][cu_k i32 S+1][kv_lens i32 S][temps f32 S][rng u64 2][tables i32 S*W]
         # for the largest bucket, of which a graph uses the leading T_b / S_b entries; two pinned mirrors, alternating
-        self._pg_tmax = max([t for t in PREFILL_GRAPH_TOKENS if t <= cfg.max_num_batched_tokens] or [0])
+        t_cap = cfg.max_num_batched_tokens if self.world_size == 1 else min(cfg.max_num_batched_tokens,
+                                                                            TP_PREFILL_GRAPH_TOKENS)
+        self._pg_tmax = max([t for t in PREFILL_GRAPH_TOKENS if t <= t_cap] or [0])
         self._pg_smax = max([n for n in PREFILL_GRAPH_SEQS if n <= cfg.max_num_seqs] or [0])
         # (the buffer itself holds the largest step there is: the lazily captured large steps read it too)
-        tmax = cfg.max_num_batched_tokens if self._pg_tmax else 0
-        smax = min(cfg.max_num_seqs, PREFILL_LAZY_SEQS_CAP) if self._pg_smax else 0
+        tmax = (cfg.max_num_batched_tokens if self.world_size == 1 else self._pg_tmax) if self._pg_tmax else 0
+        smax = (min(cfg.max_num_seqs, PREFILL_LAZY_SEQS_CAP) if self.world_size == 1 else self._pg_smax) if self._pg_smax else 0
         self._pg_tcap, self._pg_scap = tmax, smax
         if tmax and smax:
             off, sp = 0, {}
@@ -591,11 +633,20 @@ class ModelRunner:
                     max_seqlen_k=mq, slot_mapping=d["slots"][:tb], block_tables=d["tables"][:sb],
                     block_size=self.block_size, kv_lens=d["kv_lens"][:sb])
 
+        head = self.model.lm_head
+
         def body():
             hidden = self.model(d["ids"][:tb], d["pos"][:tb])
             x = ops.gather_last_tokens(hidden, d["cu_q"][:sb + 1])
-            logits, _ = ops.gemm_packed_pick(x, self.model.lm_head.weight_packed, d["temps"][:sb], d["rng"],
-                                             self.tokens_dev[:sb])
+            if self.world_size == 1:
+                logits, _ = ops.gemm_packed_pick(x, head.weight_packed, d["temps"][:sb], d["rng"], self.tokens_dev[:sb])
+                return logits
+            # tensor parallelism: every rank picks in its vocabulary shard, the ranks exchange {key, token} pairs over the
+            # region and take the same winner (ParallelLMHead.local_logits_pick, the decode graphs' last launches)
+            pairs = torch.empty((sb, 2), dtype=torch.int32, device=x.device)
+            logits, _ = ops.gemm_packed_pick(x, head.weight_packed, d["temps"][:sb], d["rng"], self.tokens_dev[:sb],
+                                             col_offset=head.vocab_start_idx, pairs_out=pairs)
+            self.xgmi.pick_exchange(pairs, self.tokens_dev[:sb])
             return logits
 
         side = torch.cuda.Stream(device=self.device)
@@ -820,6 +871,16 @@ class ModelRunner:
         synchronisation of run()."""
         return self.world_size == 1 and not self.collective
 
+    def prefill_launchable(self, seqs: list[Sequence]) -> bool:
+        """May THIS prefill step be queued without waiting for its tokens?  One GPU: any step (eagerly if it has no
+        graph).  Tensor parallelism: a step that replays a captured graph - rank 0 publishes `launch_prefill`, every
+        rank stages the same metadata at its static addresses and replays the same graph, whose collectives are exchange
+        kernels and whose last launch leaves the step's tokens on every rank (an eager TP step ends in RCCL calls and the
+        logits gather: it stays synchronous, run())."""
+        if self.can_launch_prefill:
+            return True
+        return self.world_size > 1 and bool(self.prefill_graphs) and self._prefill_bucket(seqs) is not None
+
     @torch.inference_mode()
     def launch_prefill(self, seqs: list[Sequence], bucket=False):
         """run(seqs, True) without its last step: metadata upload, the model, the sampler and the token copy are queued
@@ -831,15 +892,25 @@ class ModelRunner:
             bucket = self._prefill_bucket(seqs, note=True)
         self.prefill_starts[self._pflip ^ 1].record()  # (prepare_prefill / _stage_prefill_static flip to this buffer)
         if bucket is not None:  # a captured step: stage at the fixed addresses, replay, the tokens are picked in the graph
+            nb = self._pflip ^ 1
+            if self.rank != 0 and self._prefill_events_recorded[nb]:
+                # a worker never waits for a step's tokens: before the pinned mirror of the step before last is
+                # overwritten, make sure its upload has executed (rank 0 gets that from collect_prefill)
+                self.prefill_events[nb].synchronize()
             b = self._stage_prefill_static(seqs, bucket[0], bucket[1])
             self.prefill_graphs[bucket].replay()
             self.sampler.step += 1  # the graph sampled with this step (see _stage_prefill_static)
             self.prefill_graph_replays += 1
             self.last_logits = self.prefill_graph_logits[bucket][:real]
-            self.prefill_tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+            if self.rank == 0:
+                self.prefill_tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+                if self.xgmi is not None:  # the exchange's timeout flag travels with the tokens: no device sync here
+                    self.xgmi.status_async(self._xgmi_flag)
             self.prefill_events[b].record()
+            self._prefill_events_recorded[b] = True
             self._steps_run += 1
             return (b, real)
+        assert self.world_size == 1, "an eager prefill step of tensor-parallel ranks is run(), not launch_prefill()"
         input_ids, positions = self.prepare_prefill(seqs)
         b = self._pflip
         temps = self.prepare_sample(seqs)
@@ -859,6 +930,9 @@ class ModelRunner:
     def collect_prefill(self, handle) -> list[int]:
         b, real = handle
         self.prefill_events[b].synchronize()
+        if self._xgmi_flag is not None and int(self._xgmi_flag[0]):
+            self._abort_workers()
+            raise RuntimeError("rank 0: xGMI exchange timed out waiting for a peer; results are invalid")
         return self.prefill_tokens_hosts[b][:real].tolist()
 
     def prefill_device_ms(self, handle) -> float:

@@ -34,7 +34,7 @@ import numpy as np
 
 from nanovllm.engine.sequence import Sequence
 
-_METHODS = ("run", "exit", "launch_decode", "abort")
+_METHODS = ("run", "exit", "launch_decode", "abort", "launch_prefill")
 _HEADER = 8
 _DEFAULT_CAPACITY = 1 << 18  # int64 words per slot (2 MiB) when the caller does not size the channel
 _SLOTS = 4

@@ -439,6 +439,63 @@ def test_tp_decode_picks_tokens_in_the_graph(monkeypatch):
     assert same >= 0.8 * 60, (same, one, two)
 
 
+def test_tp_prefill_steps_replay_graphs_on_every_rank(monkeypatch, tmp_path):
+    """Round 6: under tensor parallelism a prefill step that fits the bucket table is a captured
+    hipGraph on EVERY rank - its all-reduces are exchange kernels over the (now prefill-sized) xGMI region, its last
+    launches pick the first tokens among the ranks - published by rank 0 as `launch_prefill` and replayed by the workers
+    from the RPC ring like a decode step; arrivals are prefilled behind the running decode step and the first decode
+    step is queued behind the last prefill step, as on one GPU.  Two ranks sharing cuda:0 over gloo, greedy and sampled
+    requests arriving in three waves: the streams of the one-GPU engine (up to near-ties of the differently split K
+    sums), rank 1's own counters show graph replays (it launched no prefill step eagerly), nothing timed out."""
+    import json
+    import socket
+
+    from nanovllm import LLM, SamplingParams
+
+    gen = torch.Generator().manual_seed(21)
+    lens = (9, 33, 70, 150, 5, 260, 40)
+    prompts = [torch.randint(0, 4096, (n,), generator=gen).tolist() for n in lens]
+    sps = [SamplingParams(max_tokens=8, ignore_eos=True, greedy=(i % 3 != 1), temperature=0.7) for i in range(len(lens))]
+
+    def run(tp):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        llm = LLM(make_model_dir(MID), kvcache_block_size=16, max_num_seqs=8, max_num_batched_tokens=1024,
+                  max_model_len=512, num_kvcache_blocks=128, warmup=False, synthetic_seed=3, sampling_seed=77,
+                  tensor_parallel_size=tp, hccl_port=port)
+        try:
+            mr = llm.model_runner
+            assert mr.prefill_graphs and (tp == 1 or mr.xgmi is not None)
+            done, waves = {}, [prompts[:3], prompts[3:5], prompts[5:]]
+            params = [sps[:3], sps[3:5], sps[5:]]
+            for w, (ps, pp) in enumerate(zip(waves, params)):
+                for p, sp in zip(ps, pp):
+                    llm.add_request(p, sp)
+                for _ in range(3 if w < 2 else 10 ** 6):  # a few steps, then the next wave arrives mid-decode
+                    if llm.is_finished():
+                        break
+                    for seq_id, toks, _, _ in llm.step()[0]:
+                        done[seq_id] = list(toks)
+            stats = (mr.prefill_graph_replays, getattr(llm, "prefill_behind_decode_launches", 0),
+                     getattr(llm, "decode_behind_prefill_launches", 0))
+            return [done[k] for k in sorted(done)], stats
+        finally:
+            llm.exit()
+
+    one, st1 = run(1)
+    monkeypatch.setenv("MI355_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("MI355_WORKER_STATS", str(tmp_path / "worker"))
+    two, st2 = run(2)
+    assert [len(t) for t in two] == [8] * len(lens)
+    assert st2[0] >= 3 and st2[0] == st1[0], (st1, st2)          # the same prefill steps were graph replays on rank 0 ...
+    assert st2[1] >= 1 and st2[2] >= 1, st2                       # ... queued behind decode steps / followed by queued ones
+    worker = json.load(open(str(tmp_path / "worker") + ".1.json"))
+    assert worker["prefill_graph_replays"] == st2[0] and worker["prefill_graphs"] > 0, worker   # ... and on rank 1
+    same = sum(next((i for i, (a, b) in enumerate(zip(x, y)) if a != b), len(x)) for x, y in zip(one, two))
+    assert same >= 0.8 * 8 * len(lens), (same, one, two)
+
+
 @pytest.mark.parametrize("prompt_len", [128, pytest.param(1040, marks=pytest.mark.gpu_slow)])  # (configs[0] as written: 128)
 def test_config0_bs1_128_token_prompt_greedy_full_qwen3_0p6b(prompt_len):
     """BASELINE.json configs[0]: Qwen3-0.6B (full shape, synthetic weights), bs=1, 128-token prompt,
