@@ -23,6 +23,7 @@
 
 #include "mi_common.hpp"
 #include "kv_store.hpp"
+#include "prefill_common.hpp"
 
 namespace mi {
 
@@ -134,12 +135,7 @@ __device__ __forceinline__ void attend_chunk(const u32x4 (&K0)[DB], const u32x4 
 }
 
 // element strides of the KV cache: block id, kv head, 16-token tile inside a block
-struct KvStrides {
-  int64_t block, head, tile;
-};
-__host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb, int tile_elems = MI_KV_TILE_ELEMS) {
-  return KvStrides{(int64_t)n_kv_heads * tpb * tile_elems, (int64_t)tpb * tile_elems, tile_elems};
-}
+// (KvStrides / default_strides: prefill_common.hpp)
 
 // ---------------------------------------------------------------------------
 // decode: grid (splits, n_kv_heads, batch), WAVES wavefronts per workgroup
@@ -681,9 +677,7 @@ __global__ __launch_bounds__(256) void paged_attn_merge_kernel(const float* __re
 // workgroup's softmax VALU work overlaps the other's MFMA phases.
 // The finished O tile is transposed through the (now idle) LDS stage and stored as whole rows.
 // ---------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-constexpr float kDeferMax = 8.0f;  // prefill: rescale the running softmax only when a maximum grows by more than 2^8
+// (f32x16, kDeferMax, xor32_max / xor32_sum, QPrep: prefill_common.hpp)
 
 // Probabilities in the second product.  SPLIT_P = false (the default since round 4): P is ONE bf16 per key, as in
 // the reference's own CPU statement of this operator (attention_torch_native.py:80,127,139,188-189 keeps the scale, S
@@ -691,15 +685,6 @@ constexpr float kDeferMax = 8.0f;  // prefill: rescale the running softmax only 
 // VALU instructions fewer per 32-key chunk in an issue-bound loop.  Bound: |out - fp32 oracle| <= 2^-7 |out| + 1e-4
 // (1 bf16 ulp of the output instead of 1/2; tests/test_kernels_gpu.py).  SPLIT_P = true (tuning knob
 // MI_TUNE_PREFILL_P_SPLIT, the round-1..3 form): P as bf16 hi + lo, two MFMAs per product, <= 1/2 ulp.
-// swap the upper half of `x` with the lower half of a copy: both halves then see (own, partner)
-__device__ __forceinline__ float xor32_max(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xor32_sum(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // one hand-issued ds_read_b64 at LDS byte address `addr` + OFF (see PV_READ2 below).  NOT counted by hipcc: the caller
 // waits with its own asm s_waitcnt lgkmcnt naming the destination "+v" before the first use.
@@ -708,14 +693,6 @@ __device__ __forceinline__ void lds_read64_uncounted(uint64_t& dst, uint32_t add
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
 
-// FUSE_Q: q points at the RAW q heads of the packed qkv rows; q-norm (if q_w) and RoPE are applied while the Q
-// operand is loaded (the separate mi_qknorm_rope_store then handles K and V only and never writes q)
-struct QPrep {
-  const uint16_t* q_w;
-  const int64_t* positions;
-  const float* cos_sin;
-  float eps;
-};
 
 // Variant bits VAR (mi_paged_attn_prefill_fused_ex; the product entry points use 0, or PV_SPLIT_P under the tuning knob):
 //   PV_EARLY   the first two chunks are requested ahead of the Q preparation instead of behind it (stress test)
@@ -740,7 +717,8 @@ struct QPrep {
 //              in a VGPR: ~13 VALU per chunk) and global_load_lds.  Default now: the tile's address stays on the scalar
 //              unit - a buffer descriptor whose base is the cache block, lane * 16 as the only vector offset - and the
 //              request is buffer_load_dwordx4 ... lds.
-enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16, PV_MAXTREE = 32, PV_VADDR = 64 };
+//   PV_COLS64  the 64-columns-per-wave kernel of paged_attn_prefill64.hip regardless of the launch size (alone)
+enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16, PV_MAXTREE = 32, PV_VADDR = 64, PV_COLS64 = 128 };
 
 // DB = head_dim / 32 (4, or 2 for head_dim 64: plain q rows only).  G = 7 (Qwen2-0.5B, Qwen2.5-7B) runs as a group
 // of 8 columns per query token whose eighth column is masked out: 4 tokens x 7 heads per wave.
@@ -1333,6 +1311,25 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   for (int sft = 0; sft < 12; ++sft)
     if ((1 << sft) == block_size / 16) tpb_shift = sft;
   hipStream_t st = S(stream);
+  // The 64-columns-per-wave kernel (paged_attn_prefill64.hip): 128-wide heads, a power of two of query heads per kv
+  // head, P as one bf16.  One workgroup per CU, so it needs a launch that fills the CUs (MI_TUNE_PREFILL_COLS64 = 1: at
+  // least 256 workgroups of 256 / G query tokens; variant bit 128 / knob value 2: whenever the geometry allows).
+  {
+    const int cols64 = tuning(MI_TUNE_PREFILL_COLS64);
+    const bool forced = (variant & PV_COLS64) != 0;
+    if (forced && (variant & ~PV_COLS64)) return MI_EUNSUPPORTED;
+    if (head_dim == MI_HEAD_DIM && !split_p && (variant == 0 || forced) && (cols64 != 0 || forced) && G <= 16 &&
+        (G & (G - 1)) == 0) {
+      const int tq64 = 256 / G;
+      const int64_t wgs = (int64_t)n_pairs * ((max_seqlen_q + tq64 - 1) / tq64);
+      if (forced || cols64 == 2 || wgs >= 256) {
+        rc = prefill64_launch(q, q_row_stride, prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
+                              n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, block_size, sl2, 0, st);
+        if (rc != MI_EUNSUPPORTED) return rc == MI_OK ? check_launch() : rc;
+      }
+    }
+    if (forced) return MI_EUNSUPPORTED;
+  }
   const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
 #define LAUNCH_PRE_AS(GG, FQ, VV)                                                                                  \
   hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, FQ, VV>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,   \

@@ -1,0 +1,45 @@
+// Shared by the two prefill attention kernels (paged_attn.hip: 32 query columns per wave, every geometry;
+// paged_attn_prefill64.hip: 64 query columns per wave, 128-wide heads) and their launcher.
+#pragma once
+#include "mi_common.hpp"
+
+namespace mi {
+
+struct KvStrides {
+  int64_t block, head, tile;
+};
+__host__ __device__ inline KvStrides default_strides(int n_kv_heads, int tpb, int tile_elems = MI_KV_TILE_ELEMS) {
+  return KvStrides{(int64_t)n_kv_heads * tpb * tile_elems, (int64_t)tpb * tile_elems, tile_elems};
+}
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr float kDeferMax = 8.0f;  // prefill: rescale the running softmax only when a maximum grows by more than 2^8
+
+// swap the upper half of `x` with the lower half of a copy: both halves then see (own, partner)
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// FUSE_Q: q points at the RAW q heads of the packed qkv rows; q-norm (if q_w) and RoPE are applied while the Q
+// operand is loaded (the separate mi_qknorm_rope_store then handles K and V only and never writes q)
+struct QPrep {
+  const uint16_t* q_w;
+  const int64_t* positions;
+  const float* cos_sin;
+  float eps;
+};
+
+// The 64-column form (paged_attn_prefill64.hip).  Returns MI_EUNSUPPORTED for geometries it does not cover (the caller
+// then launches the 32-column kernel), MI_OK once the launch is queued.
+int prefill64_launch(const uint16_t* q, int64_t q_stride, const QPrep* prep, const uint16_t* kc, const uint16_t* vc,
+                     const int32_t* block_table, int table_stride, const int32_t* cu_q, const int32_t* kv_lens,
+                     int n_seqs, int max_seqlen_q, uint16_t* out, int n_q_heads, int n_kv_heads, int block_size,
+                     float scale_log2e, int variant, hipStream_t st);
+
+}  // namespace mi
