@@ -81,11 +81,7 @@ enum mi_tuning_knob {
   MI_TUNE_PLAIN_SPLIT_TARGET = 4, /* mi_paged_attn_decode_plain: workgroups aimed for when contexts are split (default 512)     */
   MI_TUNE_PREFILL_P_SPLIT = 5,    /* prefill attention: probabilities as bf16 hi + lo (1) instead of one bf16 (default 0)       */
   MI_TUNE_GEMM_PIPE = 6,          /* streaming GEMMs: double-buffered K loop for K-slices of two or more blocks (default 1)     */
-  MI_TUNE_PREFILL_COLS64 = 7,     /* prefill attention, 128-wide heads, 2^n query heads per kv head: the 64-columns-per-wave
-                                     kernel (one 4-wave workgroup per CU, software-pipelined stage; same bits as the
-                                     32-column kernel, measured slower: profiles/r06_prefill64_*.txt) 0 (default) = never,
-                                     1 = when the launch has >= 256 such workgroups, 2 = whenever the geometry allows  */
-  MI_TUNE_COUNT = 8
+  MI_TUNE_COUNT = 7
 };
 int mi_set_tuning(int knob, int value);
 /* current value, or INT32_MIN for an unknown knob */

@@ -20,11 +20,10 @@ static constexpr int kTuneSpec[MI_TUNE_COUNT][3] = {
     {512, 1, 4096},  // MI_TUNE_PLAIN_SPLIT_TARGET
     {0, 0, 1},       // MI_TUNE_PREFILL_P_SPLIT
     {1, 0, 1},       // MI_TUNE_GEMM_PIPE
-    {0, 0, 2},       // MI_TUNE_PREFILL_COLS64
 };
 static std::atomic<int> g_tuning[MI_TUNE_COUNT] = {
     {kTuneSpec[0][0]}, {kTuneSpec[1][0]}, {kTuneSpec[2][0]}, {kTuneSpec[3][0]}, {kTuneSpec[4][0]}, {kTuneSpec[5][0]},
-    {kTuneSpec[6][0]}, {kTuneSpec[7][0]}};
+    {kTuneSpec[6][0]}};
 
 int tuning(int knob) { return g_tuning[knob].load(std::memory_order_relaxed); }
 

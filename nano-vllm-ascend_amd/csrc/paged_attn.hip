@@ -717,8 +717,7 @@ __device__ __forceinline__ void lds_read64_uncounted(uint64_t& dst, uint32_t add
 //              in a VGPR: ~13 VALU per chunk) and global_load_lds.  Default now: the tile's address stays on the scalar
 //              unit - a buffer descriptor whose base is the cache block, lane * 16 as the only vector offset - and the
 //              request is buffer_load_dwordx4 ... lds.
-//   PV_COLS64  the 64-columns-per-wave kernel of paged_attn_prefill64.hip regardless of the launch size (alone)
-enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16, PV_MAXTREE = 32, PV_VADDR = 64, PV_COLS64 = 128 };
+enum { PV_EARLY = 1, PV_PAIR = 2, PV_SPLIT_P = 4, PV_READ2 = 8, PV_NOPREF = 16, PV_MAXTREE = 32, PV_VADDR = 64 };
 
 // DB = head_dim / 32 (4, or 2 for head_dim 64: plain q rows only).  G = 7 (Qwen2-0.5B, Qwen2.5-7B) runs as a group
 // of 8 columns per query token whose eighth column is masked out: 4 tokens x 7 heads per wave.
@@ -1311,25 +1310,6 @@ static int prefill_impl(const mi_bf16* q, int64_t q_row_stride, const QPrep* pre
   for (int sft = 0; sft < 12; ++sft)
     if ((1 << sft) == block_size / 16) tpb_shift = sft;
   hipStream_t st = S(stream);
-  // The 64-columns-per-wave kernel (paged_attn_prefill64.hip): 128-wide heads, a power of two of query heads per kv
-  // head, P as one bf16.  One workgroup per CU, so it needs a launch that fills the CUs (MI_TUNE_PREFILL_COLS64 = 1: at
-  // least 256 workgroups of 256 / G query tokens; variant bit 128 / knob value 2: whenever the geometry allows).
-  {
-    const int cols64 = tuning(MI_TUNE_PREFILL_COLS64);
-    const bool forced = (variant & PV_COLS64) != 0;
-    if (forced && (variant & ~PV_COLS64)) return MI_EUNSUPPORTED;
-    if (head_dim == MI_HEAD_DIM && !split_p && (variant == 0 || forced) && (cols64 != 0 || forced) && G <= 16 &&
-        (G & (G - 1)) == 0) {
-      const int tq64 = 256 / G;
-      const int64_t wgs = (int64_t)n_pairs * ((max_seqlen_q + tq64 - 1) / tq64);
-      if (forced || cols64 == 2 || wgs >= 256) {
-        rc = prefill64_launch(q, q_row_stride, prep, k_cache, v_cache, block_table, table_stride, cu_seqlens_q, kv_lens,
-                              n_seqs, max_seqlen_q, out, n_q_heads, n_kv_heads, block_size, sl2, 0, st);
-        if (rc != MI_EUNSUPPORTED) return rc == MI_OK ? check_launch() : rc;
-      }
-    }
-    if (forced) return MI_EUNSUPPORTED;
-  }
   const QPrep qp = prep ? *prep : QPrep{nullptr, nullptr, nullptr, 0.f};
 #define LAUNCH_PRE_AS(GG, FQ, VV)                                                                                  \
   hipLaunchKernelGGL((paged_attn_prefill_kernel<GG, FQ, VV>), grid, dim3(256), 0, st, q, q_row_stride, k_cache,   \

@@ -1,5 +1,5 @@
-// Shared by the two prefill attention kernels (paged_attn.hip: 32 query columns per wave, every geometry;
-// paged_attn_prefill64.hip: 64 query columns per wave, 128-wide heads) and their launcher.
+// Types and helpers of the prefill attention kernel (paged_attn.hip), shared with the 64-columns-per-wave experiment
+// (tools/ubench/prefill64/, not part of the library).
 #pragma once
 #include "mi_common.hpp"
 
@@ -34,12 +34,5 @@ struct QPrep {
   const float* cos_sin;
   float eps;
 };
-
-// The 64-column form (paged_attn_prefill64.hip).  Returns MI_EUNSUPPORTED for geometries it does not cover (the caller
-// then launches the 32-column kernel), MI_OK once the launch is queued.
-int prefill64_launch(const uint16_t* q, int64_t q_stride, const QPrep* prep, const uint16_t* kc, const uint16_t* vc,
-                     const int32_t* block_table, int table_stride, const int32_t* cu_q, const int32_t* kv_lens,
-                     int n_seqs, int max_seqlen_q, uint16_t* out, int n_q_heads, int n_kv_heads, int block_size,
-                     float scale_log2e, int variant, hipStream_t st);
 
 }  // namespace mi

@@ -173,7 +173,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
 # ---- tuning knobs (include/mi355_nanovllm.h: mi_tuning_knob).  The library never reads the environment; the A/B
 # switches documented in tools/README.md are mapped onto mi_set_tuning() here, once, at import.
 (TUNE_ATTN_PIPE, TUNE_ATTN_RESOLVE, TUNE_NORM_WPR, TUNE_ROPE_BLOCK64, TUNE_PLAIN_SPLIT_TARGET, TUNE_PREFILL_P_SPLIT,
- TUNE_GEMM_PIPE, TUNE_PREFILL_COLS64) = range(8)
+ TUNE_GEMM_PIPE) = range(7)
 _ENV_KNOBS = {
     "MI355_ATTN_PIPE": TUNE_ATTN_PIPE,
     "MI355_ATTN_RESOLVE": TUNE_ATTN_RESOLVE,
@@ -182,7 +182,6 @@ _ENV_KNOBS = {
     "MI355_PLAIN_SPLIT_TARGET": TUNE_PLAIN_SPLIT_TARGET,
     "MI355_PREFILL_P_SPLIT": TUNE_PREFILL_P_SPLIT,
     "MI355_GEMM_PIPE": TUNE_GEMM_PIPE,
-    "MI355_PREFILL_COLS64": TUNE_PREFILL_COLS64,
 }
 
 

@@ -800,8 +800,6 @@ def test_prefill_attention_chunk_pipeline_stress(ops):
     assert torch.equal(late.view(torch.int16), ref.view(torch.int16))    # paging invariance
     assert torch.equal(early.view(torch.int16), late.view(torch.int16))  # request order does not matter
     assert torch.equal(paired.view(torch.int16), late.view(torch.int16))  # nor does one barrier per two chunks
-    cols64, _ = run(scrambled, 128, 30)  # the opt-in 64-columns-per-wave kernel: five-chunk ring, same function
-    assert torch.equal(cols64.view(torch.int16), late.view(torch.int16))
     # round 4's schedule changes (hand-issued un-merged V reads, block ids read a chunk ahead with the request side as
     # running state) against round 3's forms of the same arithmetic: 8 = merged V reads, 16 = table read + divisions in
     # front of every request, 24 = both
@@ -824,57 +822,6 @@ def test_prefill_attention_chunk_pipeline_stress(ops):
         assert bool((err <= _prefill_bound(want, want_absv, 2 ** -8)).all()), err.max().item()   # P as one bf16
         err = (split_new[rows].cpu().float() - want).abs()
         assert bool((err <= _prefill_bound(want, want_absv, 0.0)).all()), err.max().item()       # P as hi + lo
-
-
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 1)])
-def test_prefill_attention_64_columns_per_wave_is_the_same_function(ops, hq, hkv):
-    """The opt-in 64-columns-per-wave prefill kernel (csrc/paged_attn_prefill64.hip, MI_TUNE_PREFILL_COLS64 = 2) against
-    the product's 32-column kernel: a column's result is the same function of the same chunk sequence, so the outputs
-    are the same BITS - plain q rows and q prepared in the kernel, ragged lengths, a cached prefix, scrambled tables,
-    every supported number of query heads per kv head (1, 2, 4, 8, 16)."""
-    from nanovllm import _C
-
-    gen = torch.Generator().manual_seed(hq * 5 + hkv)
-    bs = 16
-    q_lens = [300, 7, 129, 33, 513, 80, 1]
-    prefix = [0, 0, 64, 0, 32, 16, 0]
-    kv_lens = [a + b for a, b in zip(q_lens, prefix)]
-    T, n_seqs = sum(q_lens), len(q_lens)
-    nb = [-(-n // bs) for n in kv_lens]
-    perm = torch.randperm(sum(nb) + 3, generator=gen)[: sum(nb)].to(torch.int32)
-    bt = torch.full((n_seqs, max(nb)), -1, dtype=torch.int32)
-    o = 0
-    for i, n in enumerate(nb):
-        bt[i, :n] = perm[o:o + n]
-        o += n
-    pos = torch.cat([torch.arange(p, p + n) for p, n in zip(prefix, q_lens)]).to(torch.int64).to(DEV)
-    qkv = (torch.randn(T, (hq + 2 * hkv) * 128, generator=gen) * 1.5).bfloat16().to(DEV)
-    qw = (1 + 0.2 * torch.randn(128, generator=gen)).bfloat16().to(DEV)
-    table = oracle.build_cos_sin_cache(128, 4096, 1e6).to(DEV)
-    shape = ops.kv_cache_shape(sum(nb) + 3, hkv, bs)
-    kc = torch.randn(shape, generator=gen).bfloat16().to(DEV)
-    vc = torch.randn(shape, generator=gen).bfloat16().to(DEV)
-    cu = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32).to(DEV)
-    kvl = torch.tensor(kv_lens, dtype=torch.int32).to(DEV)
-    btd = bt.to(DEV)
-    scale = 1.0 / math.sqrt(128)
-    q_plain = qkv[:, : hq * 128].contiguous()
-
-    def both():
-        a = ops.paged_attn_prefill(q_plain, kc, vc, btd, cu, kvl, max(q_lens), hq, hkv, bs, scale)
-        b = ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, table, kc, vc, btd, cu, kvl, max(q_lens), hq, hkv, bs, scale)
-        return a, b
-
-    assert _C.get_tuning(_C.TUNE_PREFILL_COLS64) == 0  # the product runs the 32-column kernel
-    want = both()
-    _C.set_tuning(_C.TUNE_PREFILL_COLS64, 2)
-    try:
-        got = both()
-    finally:
-        _C.set_tuning(_C.TUNE_PREFILL_COLS64, 0)
-    for g, w in zip(got, want):
-        assert torch.equal(g.view(torch.int16), w.view(torch.int16))
-        assert float(g.float().abs().max()) > 0.1
 
 
 @pytest.mark.parametrize("hq,hkv,with_norm", [(16, 8, True), (8, 1, True), (4, 4, False), (16, 1, True)])

@@ -83,10 +83,7 @@ def prefill_attention_order():
     cu = (torch.arange(n + 1, dtype=torch.int32) * T).to(DEV)
     kvl = torch.full((n,), T, dtype=torch.int32, device=DEV)
     # variant bits of mi_paged_attn_prefill_fused_ex (include/mi355_nanovllm.h)
-    only = os.environ.get("VARIANTS")
-    variants = (("default", 0),
-                ("64 columns per wave, one workgroup per CU, pipelined stage (128)", 128),
-                ("32 columns per wave: round 6's sum-checked softmax, scalar request addressing (256)", 256),
+    variants = (("default (round 6: sum-checked softmax, scalar request addressing)", 0),
                 ("round-5 softmax: chunk maximum before the exponentials (32)", 32),
                 ("round-5 request addressing: 64-bit VALU pointers + global_load_lds (64)", 64),
                 ("the round-5 kernel as a whole (96)", 96),
@@ -97,33 +94,11 @@ def prefill_attention_order():
                 ("the round-3 kernel as a whole: P hi + lo (28)", 28),
                 ("requests ahead of the Q preparation (1)", 1),
                 ("one barrier per two chunks, ring of four (2)", 2))
-    if only:
-        variants = tuple(x for x in variants if str(x[1]) in only.split(","))
     res = {name: [] for name, _ in variants}
-    # 32 columns per wave = the default with the 64-column kernel switched off (tuning knob, not a variant bit)
-    from nanovllm import _C
-
-    def run32(fn):
-        prev64 = _C.get_tuning(_C.TUNE_PREFILL_COLS64)
-        _C.set_tuning(_C.TUNE_PREFILL_COLS64, 0)
-        try:
-            return fn()
-        finally:
-            _C.set_tuning(_C.TUNE_PREFILL_COLS64, prev64)
-
-    ref = run32(lambda: ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[0], vc[0], tables, cu, kvl, T, hq, hkv, bs,
-                                                     128 ** -0.5, variant=0).float())
-    got = ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[0], vc[0], tables, cu, kvl, T, hq, hkv, bs, 128 ** -0.5,
-                                       variant=128).float()
-    d = (got - ref).abs()
-    print(f"64-column kernel vs 32-column kernel: max |diff| {d.max().item():.3e}, mean {d.mean().item():.3e}, "
-          f"equal elements {(d == 0).float().mean().item():.4f}, nan {torch.isnan(got).any().item()}")
     for rnd in range(int(os.environ.get("ROUNDS", 4))):
         for name, v in variants:
-            fn = lambda: timeit(lambda l: ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[l], vc[l], tables, cu, kvl,
-                                                                       T, hq, hkv, bs, 128 ** -0.5, out=out,
-                                                                       variant=v & 255), L)
-            t = run32(fn) if v == 256 else fn()
+            t = timeit(lambda l: ops.paged_attn_prefill_fused(qkv, qw, 1e-6, pos, cos_sin, kc[l], vc[l], tables, cu, kvl, T,
+                                                              hq, hkv, bs, 128 ** -0.5, out=out, variant=v), L)
             res[name].append(round(t * 1e6, 1))
     flops = n * hq * (T * (T + 1) / 2) * 128 * 2 * 2
     print(f"fused-Q prefill attention 16x{T}, us per launch, alternating rounds ({flops / 1e9:.1f} GFLOP useful per launch):")

@@ -135,36 +135,31 @@ __global__ __launch_bounds__(256) void paged_attn_prefill64_kernel(
   // road on which the compiler keeps it there - through this lane's 256 bytes of LDS (behind the ring) and back by a
   // ds_read_b128 whose destination is declared "=a".  (An "a" INPUT built from an arch-VGPR value is copied in front of
   // every use: 64 v_accvgpr_write per stage and 64 arch VGPRs lost, measured on the first build.)
-  // Both column blocks' rows, positions and table rows are requested before any arithmetic (one wave per SIMD: nothing
-  // else hides a dependent HBM round trip - with the blocks one after the other this prologue took 24 k cycles).
+  // One column block after the other: only ONE block's eight fragments (and rope registers) are alive at a time.  (Both
+  // blocks' loads ahead of any arithmetic - 64 more live registers across the prologue - saved ~10 k cycles of the
+  // prologue's dependent round trips and made the register allocator SPILL pinned accumulators inside the stage, i.e.
+  // read them right behind the inline-asm MFMA that writes them: wrong results.  tests/test_build_artifacts.py holds
+  // every instantiation of this kernel to zero scratch.)
   bf16x8 Q[2][8];
   const uint32_t lds_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)stage;
   const uint32_t qslot = lds_base + P64_RING_BYTES + threadIdx.x * 256;
-  {
-    u32x4 qv[2][8];
-    const uint16_t* qrow[2];
-    int row[2];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      row[cb] = valid[cb] ? my_qt[cb] : wg_qt0;  // invalid columns read a valid row and are zeroed
-      qrow[cb] = q + (int64_t)(q_start + row[cb]) * q_stride + (int64_t)(h * G + hn) * D + 8 * hi;
+  for (int cb = 0; cb < 2; ++cb) {
+    u32x4 qv[8];
+    const int row = valid[cb] ? my_qt[cb] : wg_qt0;  // invalid columns read a valid row and are zeroed
+    const uint16_t* qrow = q + (int64_t)(q_start + row) * q_stride + (int64_t)(h * G + hn) * D + 8 * hi;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) qv[cb][kk] = *reinterpret_cast<const u32x4*>(qrow[cb] + 16 * kk);
-    }
+    for (int kk = 0; kk < 8; ++kk) qv[kk] = *reinterpret_cast<const u32x4*>(qrow + 16 * kk);
     if constexpr (FUSE_Q) {
-      RopeRegs32 rr[2];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) rope_regs_q32_load(rr[cb], qp.cos_sin + qp.positions[q_start + row[cb]] * 128, hi);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) head_rmsnorm_rope_q32_packed(qv[cb], qp.q_w, rr[cb], hi, qp.eps);
+      RopeRegs32 rr;
+      rope_regs_q32_load(rr, qp.cos_sin + qp.positions[q_start + row] * 128, hi);
+      head_rmsnorm_rope_q32_packed(qv, qp.q_w, rr, hi, qp.eps);
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        if (!valid[cb]) qv[cb][kk] = u32x4{0, 0, 0, 0};
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(qslot), "v"(qv[cb][kk]), "i"((cb * 8 + kk) * 16) : "memory");
-      }
+    for (int kk = 0; kk < 8; ++kk) {
+      if (!valid[cb]) qv[kk] = u32x4{0, 0, 0, 0};
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(qslot), "v"(qv[kk]), "i"((cb * 8 + kk) * 16) : "memory");
+    }
   }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)

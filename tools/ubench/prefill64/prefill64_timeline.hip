@@ -2,7 +2,7 @@
 // STAMP = true): 16 sequences x T tokens of Qwen3-0.6B heads (16 q / 8 kv heads, head_dim 128), block size 16, random
 // cache, fused Q preparation.  Prints the mean over waves of the cycles per stage in each segment and of the per-workgroup
 // prologue / epilogue segments.  Build: tools/ubench/build.sh; run on the GPU box: tools/ubench/prefill64_timeline [T]
-#include "../../nano-vllm-ascend_amd/csrc/paged_attn_prefill64.hip"
+#include "paged_attn_prefill64.hip"
 
 #include <stdio.h>
 #include <stdlib.h>
