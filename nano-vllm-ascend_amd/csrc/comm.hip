@@ -460,7 +460,7 @@ extern "C" int mi_allreduce_add_rmsnorm(mi_comm* comm, const mi_bf16* x, const m
   const int nvec = cols / 8;
   hipStream_t st = S(stream);
   // a few wide rows: four or eight waves per row - where mi_add_rmsnorm takes its multi-wave kernel, with its arithmetic
-  if (rows <= 64 && cols > 1024 && tuning(MI_TUNE_NORM_WPR) == 4) {
+  if (rows <= 64 && cols >= 4096 && tuning(MI_TUNE_NORM_WPR) == 4) {
     if (cols <= 4 * 64 * 8 * 2)
       hipLaunchKernelGGL((allreduce_add_rmsnorm_rows_kernel<4>), dim3(rows), dim3(256), 0, st, comm->geom(), x, residual,
                          weight, out, residual_out, rows, cols, eps);
