@@ -62,7 +62,10 @@ __device__ __forceinline__ void comm_publish_and_wait(const CommGeom& g, uint32_
     __hip_atomic_store(theirs, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t* arrive = reinterpret_cast<const uint32_t*>(g.peers.region[g.rank] + g.flags_off) +
                              ((size_t)par * g.world + tid) * MAX_SLICES + s;
-    const uint32_t limit = reinterpret_cast<const volatile uint32_t*>(g.peers.region[g.rank])[3];
+    // (once an exchange has timed out the step's results are void - the host raises when it reads the sticky flag: the
+    // launches still queued behind it do not each wait their full patience for the same missing peer)
+    const volatile uint32_t* ctrl = reinterpret_cast<const volatile uint32_t*>(g.peers.region[g.rank]);
+    const uint32_t limit = ctrl[2] ? 64u : ctrl[3];
     uint32_t spins = 0;
     while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
       if (++spins > limit) {
