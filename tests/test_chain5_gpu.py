@@ -91,8 +91,7 @@ def test_rowstat_and_normed_are_the_seven_launch_chain_bit_for_bit(ops, M, K, ks
     _assert_seam_close(res5, xn5, x, w, res, nw)
 
 
-@pytest.mark.parametrize("M,H,K", [(32, 2048, 8192), (5, 2048, 2048), (32, 4096, 4096), (24, 5120, 3200), (16, 1024, 768),
-                                   (32, 3072, 1024)])
+@pytest.mark.parametrize("M,H,K", [(32, 2048, 8192), (5, 2048, 2048), (32, 4096, 4096), (16, 1024, 768), (32, 3072, 1024)])
 def test_chain5_other_widths_against_the_oracle(ops, M, H, K):
     """Widths whose seven-launch norm kernel sums in another order (hidden 2048 ... 5120, K-slices of 12 / 10 waves): the
     five-launch pieces against the oracle, in the bounds of their seven-launch counterparts."""
@@ -102,8 +101,9 @@ def test_chain5_other_widths_against_the_oracle(ops, M, H, K):
     res = torch.randn(M, H, generator=g).bfloat16()
     nw = (1.0 + 0.1 * torch.randn(H, generator=g)).bfloat16()
     w2 = (torch.randn(512, H, generator=g) * 0.03).bfloat16()
-    if not ops.chain5_takes(M, H, (K,)):
-        pytest.skip("not a five-launch shape (the model takes the seven-launch chain)")
+    assert ops.chain5_takes(M, H, (K,))
+    # (a Qwen3-32B TP-8 rank's down_proj, K = 3200 = 50 wave slices, is not a five-launch shape: the model takes seven)
+    assert not ops.chain5_takes(24, 5120, (3200,)) and not ops.chain5_takes(33, 1024, (2048,))
     s, res5, stat = ops.gemm_rowstat(x.to(DEV), ops.pack_weight(w.to(DEV)), res.to(DEV), 1)
     xn = ops.norm_from_stat(s, stat, nw.to(DEV), EPS)
     _assert_seam_close(res5, xn, x, w, res, nw)

@@ -1190,3 +1190,25 @@ def test_generate_checks_every_prompt_before_queueing_any():
     assert eng.is_finished() and not eng.scheduler.waiting
     out = eng.generate([[1, 2, 3], [4, 5]], sp, use_tqdm=False)
     assert [o["prompt_len"] for o in out] == [3, 2]
+
+
+def test_lazily_captured_prefill_graphs_are_keyed_by_buckets_that_pad_by_at_most_a_sixteenth():
+    """ModelRunner._lazy_prefill_key (round 6: full-house prefill steps replay graphs): tokens round up to 256, sequences
+    and the longest query to powers of two (queries from 256); a step that would be padded by more than 1/16 of its
+    tokens stays eager - and the bench's full house of 16 x 1024 tokens is its own bucket."""
+    from nanovllm.engine.model_runner import ModelRunner
+
+    key = ModelRunner._lazy_prefill_key
+    assert key(16384, 16, 1024) == (16384, 16, 1024)
+    assert key(16000, 13, 1000) == (16128, 16, 1024)
+    assert key(4100, 5, 900) == (4352, 8, 1024)
+    assert key(2049, 2, 2049) is None            # 255 pad tokens on 2049: more than a sixteenth
+    assert key(300, 1, 300) is None
+    assert key(256, 1, 17) == (256, 1, 256)
+    for tokens in range(1, 20000, 37):
+        k = key(tokens, 1 + tokens % 40, 1 + tokens % 1500)
+        if k is not None:
+            tb, sb, mq = k
+            assert tb >= tokens and tb % 256 == 0 and (tb - tokens) * 16 <= tokens
+            assert sb >= 1 + tokens % 40 and sb & (sb - 1) == 0
+            assert mq >= max(256, 1 + tokens % 1500) and mq & (mq - 1) == 0

@@ -574,14 +574,13 @@ def test_decode_attention_golden(ops, golden_attention, attn_geometry):
 
 
 # --------------------------------------------------------------------------- fp8 weights
-@pytest.mark.parametrize("M", [1, 32, 64])
-@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (256, 128), (65536, 1024)])
+# (the lm_head-sized case - many row tiles per launch - is checked at one batch size)
+@pytest.mark.parametrize("N,K,M", [(n, k, m) for n, k in ((4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (256, 128))
+                                   for m in (1, 32, 64)] + [(65536, 1024, 32)])
 def test_gemm_fp8_weights(ops, M, N, K):
     """e4m3 weights + per-row fp32 scale, bf16 activations: y = x @ (w_q * scale)^T, one rounding.
     The oracle multiplies the dequantised weights in fp32; the kernel multiplies exact bf16 copies of
     w_q and scales the fp32 sums - equal up to fp32 rounding, i.e. <= 1 bf16 ulp on a few outputs."""
-    if N >= 65536 and M != 32:
-        pytest.skip("the lm_head-sized case (many row tiles per launch) is checked at one batch size")
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.02).bfloat16()
