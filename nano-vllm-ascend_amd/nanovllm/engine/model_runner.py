@@ -683,6 +683,8 @@ class ModelRunner:
         return True
 
     def _capture_lazy(self, key: tuple):
+        if len(self._pg_lazy_lru) >= PREFILL_LAZY_GRAPHS:
+            torch.cuda.synchronize()  # (a queued step may still be replaying the graph that is about to be destroyed)
         while len(self._pg_lazy_lru) >= PREFILL_LAZY_GRAPHS:
             old = self._pg_lazy_lru.pop(0)
             self.prefill_graphs.pop(old, None)
