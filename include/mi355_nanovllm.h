@@ -473,6 +473,13 @@ int mi_embedding_from_prev(const int64_t* ids, const int32_t* src_rows,
                            int n_tokens, int hidden, int64_t vocab_start,
                            int64_t vocab_local, mi_stream stream);
 
+/* A step's metadata (or its sampled tokens) between PINNED host memory and device memory as a kernel on the step's
+ * stream: dst[0, nbytes) = src[0, nbytes), 16-byte pieces, both pointers 16-byte aligned, nbytes % 16 == 0, at most
+ * 256 MiB.  Either side may be device-accessible pinned host memory (hipHostMalloc / torch pin_memory).  Replaces the
+ * H2D copies of model_runner.py:344-366 (prepare_decode: five per step; here one buffer per step) without the copy
+ * engine's cross-queue signals between two decode graphs. */
+int mi_stage_copy(void* dst, const void* src, int64_t nbytes, mi_stream stream);
+
 /* ParallelLMHead last-token select in prefill (embed_head.py:58-60):
  * out[s] = x[cu_seqlens_q[s+1]-1]. */
 int mi_gather_last_tokens(const mi_bf16* x, const int32_t* cu_seqlens_q,

@@ -1051,6 +1051,27 @@ extern "C" int mi_embedding_from_prev(const int64_t* ids, const int32_t* src_row
   return check_launch();
 }
 
+// Step metadata between pinned host memory and the device, as a KERNEL on the step's own stream (one 16-byte load and
+// store per thread, every load of the launch in flight at once): an async memcpy of these few tens of KB goes through the
+// copy engine and its cross-queue signals, which leaves the device idle for ~25 us between two decode graphs.
+namespace mi {
+__global__ __launch_bounds__(256) void stage_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t nvec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nvec) dst[i] = src[i];
+}
+}  // namespace mi
+
+extern "C" int mi_stage_copy(void* dst, const void* src, int64_t nbytes, mi_stream stream) {
+  if (!dst || !src || nbytes < 0) return MI_EINVAL;
+  if (nbytes % 16 || !aligned16(dst) || !aligned16(src)) return MI_EUNSUPPORTED;
+  if (nbytes == 0) return MI_OK;
+  const int64_t nvec = nbytes / 16;
+  if (nvec > ((int64_t)1 << 24)) return MI_EUNSUPPORTED;  // staging buffers, not bulk data
+  hipLaunchKernelGGL(mi::stage_copy_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, S(stream),
+                     static_cast<const mi::u32x4*>(src), static_cast<mi::u32x4*>(dst), nvec);
+  return check_launch();
+}
+
 extern "C" int mi_gather_last_tokens(const mi_bf16* x, const int32_t* cu_seqlens_q, mi_bf16* out, int n_seqs,
                                      int hidden, mi_stream stream) {
   if (!x || !cu_seqlens_q || !out || n_seqs < 0 || hidden <= 0) return MI_EINVAL;

@@ -129,6 +129,7 @@ _SIGNATURES = {
                                             c_int, c_int, c_float, _p]),
     "mi_embedding": (c_int, [_p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
     "mi_embedding_from_prev": (c_int, [_p, _p, _p, _p, _p, c_int, c_int, c_int64, c_int64, _p]),
+    "mi_stage_copy": (c_int, [_p, _p, c_int64, _p]),
     "mi_gather_last_tokens": (c_int, [_p, _p, _p, c_int, c_int, _p]),
     "mi_argmax": (c_int, [_p, c_int64, _p, c_int, c_int, _p]),
     "mi_sample": (c_int, [_p, c_int64, _p, _p, c_int, c_int, c_uint64, c_uint64, _p]),

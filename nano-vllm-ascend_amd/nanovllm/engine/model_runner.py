@@ -402,6 +402,7 @@ class ModelRunner:
             spans[name] = (off, nbytes)
             off += (nbytes + 15) // 16 * 16
         self._stage_bytes = off
+        self._stage_kernel = os.environ.get("MI355_STAGE_KERNEL", "1") != "0"
         self.dev_stage = torch.zeros(off, dtype=torch.uint8, device=self.device)
 
         def views(buf):
@@ -478,6 +479,23 @@ class ModelRunner:
             self.pg_host_bufs = [torch.zeros(off, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
             self.pg_hosts = [{k: t.numpy() for k, t in pviews(b).items()} for b in self.pg_host_bufs]
 
+    def _upload(self, dev: torch.Tensor, pinned: torch.Tensor) -> None:
+        """A step's staged metadata: pinned host buffer -> its device buffer, queued on the step's stream.  As a kernel
+        (ops.stage_copy) where the sizes allow: torch's async copy of a few tens of KB goes through the copy engine and
+        leaves ~25 us of idle device between two decode graphs (MI355_STAGE_KERNEL=0: the async copy)."""
+        if self._stage_kernel and dev.numel() % 16 == 0 and dev.numel() == pinned.numel():
+            ops.stage_copy(dev, pinned)
+        else:
+            dev.copy_(pinned, non_blocking=True)
+
+    def _download_tokens(self, landing: torch.Tensor, real: int) -> None:
+        """The step's sampled tokens -> a pinned landing buffer, queued behind the step (the same kernel: the whole
+        token buffer, a few hundred bytes; rows beyond `real` are padding)."""
+        if self._stage_kernel and landing.numel() == self.tokens_dev.numel() and landing.numel() % 2 == 0:
+            ops.stage_copy(landing, self.tokens_dev)
+        else:
+            landing[:real].copy_(self.tokens_dev[:real], non_blocking=True)
+
     def _fill_decode_stage(self, seqs: list[Sequence], bucket: int, src_rows=None) -> int:
         """decode_meta(seqs, pad_to=bucket, dummy slot in the reserved last block) into the next pinned
         staging buffer (incremental block-table rows), then ONE async copy to the device.  src_rows[i] >= 0:
@@ -497,7 +515,7 @@ class ModelRunner:
         elif self._src_dirty[b]:
             h["src"][:] = -1
             self._src_dirty[b] = False
-        self.dev_stage.copy_(self.host_stages[b], non_blocking=True)
+        self._upload(self.dev_stage, self.host_stages[b])
         return b
 
     # ------------------------------------------------------------------ metadata -> context
@@ -772,7 +790,7 @@ class ModelRunner:
         rng = h["rng"].view(np.uint64)
         rng[0] = self.sampler.seed & 0xFFFFFFFFFFFFFFFF
         rng[1] = (self.sampler.step + 1) & 0xFFFFFFFFFFFFFFFF
-        self.pg_dev_buf.copy_(self.pg_host_bufs[self._pflip], non_blocking=True)
+        self._upload(self.pg_dev_buf, self.pg_host_bufs[self._pflip])
         return self._pflip
 
     def _bucket_for(self, n: int) -> int | None:
@@ -855,7 +873,7 @@ class ModelRunner:
         self.graphs[bucket].replay()
         self.sampler.step += 1  # the graph sampled with this step (see _fill_decode_stage)
         if self.rank == 0:
-            self.tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+            self._download_tokens(self.tokens_hosts[b], real)
             if self.xgmi is not None:  # the exchange's timeout flag travels with the tokens: no device sync here
                 self.xgmi.status_async(self._xgmi_flag)
         self.step_events[b].record()
@@ -905,7 +923,7 @@ class ModelRunner:
             self.prefill_graph_replays += 1
             self.last_logits = self.prefill_graph_logits[bucket][:real]
             if self.rank == 0:
-                self.prefill_tokens_hosts[b][:real].copy_(self.tokens_dev[:real], non_blocking=True)
+                self._download_tokens(self.prefill_tokens_hosts[b], real)
                 if self.xgmi is not None:  # the exchange's timeout flag travels with the tokens: no device sync here
                     self.xgmi.status_async(self._xgmi_flag)
             self.prefill_events[b].record()

@@ -755,6 +755,17 @@ def embedding_from_prev(ids, src_rows, prev_tokens, w, vocab_start: int = 0, out
     return out
 
 
+def stage_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """dst[:] = src[:] between a PINNED host buffer and a device buffer (either direction), as a kernel on the current
+    stream (mi_stage_copy): a step's metadata upload / token download without the copy engine between two graphs.
+    Both contiguous, the same number of bytes (a multiple of 16)."""
+    for t in (dst, src):
+        assert t.is_contiguous() and (t.is_cuda or t.is_pinned()), "stage_copy: device or pinned host memory only"
+    n = dst.numel() * dst.element_size()
+    assert n == src.numel() * src.element_size() and (dst.is_cuda or src.is_cuda)
+    check(lib.mi_stage_copy(dst.data_ptr(), src.data_ptr(), n, stream()), "mi_stage_copy")
+
+
 def gather_last_tokens(x, cu_seqlens_q) -> torch.Tensor:
     require_gpu(x, cu_seqlens_q)
     _bf16(x)

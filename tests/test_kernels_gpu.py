@@ -869,6 +869,30 @@ def test_prefill_attention_with_q_prepared_in_the_kernel(ops, hq, hkv, with_norm
     assert float(got.float().abs().max()) > 0.1
 
 
+def test_stage_copy_between_pinned_host_and_device(ops):
+    """mi_stage_copy: a step's metadata upload / token download as a kernel - bytes in, bytes out, both directions,
+    sizes from one 16-byte piece to a full-house prefill step's staging buffer; refuses pageable memory and odd sizes."""
+    g = torch.Generator().manual_seed(3)
+    for n in (16, 256, 33008, 1 << 20):
+        host = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).pin_memory()
+        dev = torch.zeros(n, dtype=torch.uint8, device=DEV)
+        ops.stage_copy(dev, host)
+        assert torch.equal(dev.cpu(), host)
+        back = torch.zeros(n, dtype=torch.uint8).pin_memory()
+        ops.stage_copy(back, dev)
+        torch.cuda.synchronize()
+        assert torch.equal(back, host)
+    toks = torch.arange(32, dtype=torch.int64, device=DEV) * 7
+    landing = torch.zeros(32, dtype=torch.int64).pin_memory()
+    ops.stage_copy(landing, toks)
+    torch.cuda.synchronize()
+    assert torch.equal(landing, toks.cpu())
+    with pytest.raises(AssertionError):
+        ops.stage_copy(torch.zeros(16, dtype=torch.uint8, device=DEV), torch.zeros(16, dtype=torch.uint8))  # pageable
+    with pytest.raises(RuntimeError):
+        ops.stage_copy(torch.zeros(24, dtype=torch.uint8, device=DEV), torch.zeros(24, dtype=torch.uint8).pin_memory())
+
+
 # --------------------------------------------------------------------------- gathers / sampling
 def test_embedding_and_last_token(ops):
     g = torch.Generator().manual_seed(2)
