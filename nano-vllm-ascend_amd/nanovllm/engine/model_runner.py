@@ -124,8 +124,11 @@ class ModelRunner:
                 # same graph, whose all-reduces must be kernels of this library, not RCCL calls
                 rows = max(rows, max([t for t in PREFILL_GRAPH_TOKENS
                                       if t <= min(config.max_num_batched_tokens, TP_PREFILL_GRAPH_TOKENS)] or [0]))
+            eager_rows = max(64, min(config.max_num_seqs, 512))
             self.xgmi = xgmi_comm.create_if_enabled(rank, self.world_size, rows * self.hf_config.hidden_size * 2,
                                                     self.device)
+            if self.xgmi is not None:  # eager launches: decode-sized rows only (XgmiComm.eager_max_bytes)
+                self.xgmi.eager_max_bytes = eager_rows * self.hf_config.hidden_size * 2
             parallel.set_xgmi_comm(self.xgmi)
             self.xgmi_selftest = xgmi_comm.LAST_STATUS
 
@@ -667,14 +670,19 @@ class ModelRunner:
             self.xgmi.pick_exchange(pairs, self.tokens_dev[:sb])
             return logits
 
+        import contextlib
+
+        # (a captured step's ranks replay together: its prefill-sized all-reduces are exchange kernels, XgmiComm.large)
+        whole_region = self.xgmi.large() if self.xgmi is not None else contextlib.nullcontext()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with whole_region, torch.cuda.stream(side):
             body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self._pg_pool):
+        whole_region = self.xgmi.large() if self.xgmi is not None else contextlib.nullcontext()
+        with whole_region, torch.cuda.graph(graph, pool=self._pg_pool):
             logits = body()
         self._pg_pool = self._pg_pool or graph.pool()
         self.prefill_graphs[key] = graph

@@ -21,6 +21,12 @@ from nanovllm._C import check, lib, ptr, stream
 class XgmiComm:
     def __init__(self, rank: int, world: int, max_bytes: int, device: torch.device):
         self.rank, self.world, self.max_bytes, self.device = rank, world, int(max_bytes), device
+        # What an EAGER launch may put through the region (ModelRunner sets it to the decode-sized rows): the region is
+        # also sized for captured prefill steps, whose ranks replay the same graph together; an eager prefill step's ranks
+        # arrive at their collectives host-skewed by whole launch sequences, and its prefill-sized all-reduces stay on the
+        # process group (RCCL) as in rounds 1-5.  `large()` lifts the cap while a prefill graph is captured.
+        self.eager_max_bytes = int(max_bytes)
+        self._large = 0
         self._peers: list[int] = []
         self._own = ctypes.c_void_p()
         self._comm = ctypes.c_void_p()
@@ -42,16 +48,32 @@ class XgmiComm:
         check(lib.mi_comm_create(rank, world, arr, self.max_bytes, ctypes.byref(self._comm)), "mi_comm_create")
         dist.barrier()  # every rank has mapped every region before the first push
 
+    def _cap(self) -> int:
+        return self.max_bytes if self._large else min(self.max_bytes, self.eager_max_bytes)
+
+    def large(self):
+        """context: launches inside may use the whole region (capture of a prefill step's graph and its warm-up run)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self._large += 1
+            try:
+                yield self
+            finally:
+                self._large -= 1
+        return scope()
+
     def fits(self, t: torch.Tensor) -> bool:
         return (t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous() and t.numel() % 8 == 0
-                and 0 < t.numel() * 2 <= self.max_bytes)
+                and 0 < t.numel() * 2 <= self._cap())
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         check(lib.mi_allreduce_sum_bf16(self._comm, ptr(t), ptr(t), t.numel(), stream()), "mi_allreduce_sum_bf16")
         return t
 
     def fits_rows(self, rows: int, cols: int) -> bool:
-        return 0 < rows <= 512 and 512 <= cols <= 8192 and cols % 8 == 0 and rows * cols * 2 <= self.max_bytes
+        return 0 < rows <= 512 and 512 <= cols <= 8192 and cols % 8 == 0 and rows * cols * 2 <= self._cap()
 
     def allreduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, w: torch.Tensor, eps: float):
         """sum over ranks of x, + residual, RMSNorm: one launch (mi_allreduce_add_rmsnorm)."""
