@@ -173,7 +173,7 @@ def _attention_roofline(llm, seqs, iters):
         launch_all()
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):  # graph replay: no host launch gaps between the launches
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # graph replay: no host launch gaps between the launches
         launch_all()
     graph.replay()
     torch.cuda.synchronize()
@@ -248,7 +248,7 @@ def chain_roofline(llm, batch: int, iters: int = 20):
             run()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             run()
         graph.replay()
         torch.cuda.synchronize()

@@ -58,6 +58,11 @@ PREFILL_LAZY_SEQS_CAP = 64  # rows of the static metadata buffer's block table (
 # prefill-sized tensors stays outside graphs), whose slots are 2 x world x tokens x hidden x 2 bytes per rank: the table
 # stops here (Qwen3-32B at TP 8: 335 MB per rank)
 TP_PREFILL_GRAPH_TOKENS = 2048
+# Stream capture in THREAD-LOCAL error mode: with a process group alive, ProcessGroupNCCL's watchdog thread polls the
+# events of enqueued collectives (hipEventQuery); under the default global mode such a call from ANOTHER thread while
+# this one captures is "operation not permitted when stream is capturing" - raised inside the watchdog, which terminates
+# the process.  Only this thread's own calls need policing during a capture.
+CAPTURE_MODE = "thread_local"
 
 
 def graph_buckets(max_num_seqs: int) -> list[int]:
@@ -610,7 +615,7 @@ class ModelRunner:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=pool):  # kernels only: the logits gather of TP stays outside
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode=CAPTURE_MODE):  # kernels only: the logits gather of TP stays outside
                 logits = body()
             pool = pool or graph.pool()
             self.graphs[bs] = graph
@@ -682,7 +687,7 @@ class ModelRunner:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         whole_region = self.xgmi.large() if self.xgmi is not None else contextlib.nullcontext()
-        with whole_region, torch.cuda.graph(graph, pool=self._pg_pool):
+        with whole_region, torch.cuda.graph(graph, pool=self._pg_pool, capture_error_mode=CAPTURE_MODE):
             logits = body()
         self._pg_pool = self._pg_pool or graph.pool()
         self.prefill_graphs[key] = graph

@@ -136,7 +136,7 @@ class XgmiComm:
                 self.all_reduce(buf)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # (the process group's watchdog thread polls events)
                 for _ in range(3):  # three dependent launches per replay
                     buf.copy_(src)
                     self.all_reduce(buf)
