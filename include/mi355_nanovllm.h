@@ -631,6 +631,10 @@ int mi_comm_status_async(mi_comm* comm, int* timed_out_host, mi_stream stream);
 int mi_comm_set_spin_limit(mi_comm* comm, uint32_t polls);
 /* Copies the sticky timeout flag to *timed_out (synchronises the device). */
 int mi_comm_status(mi_comm* comm, int* timed_out);
+/* What this rank's FIRST timed-out exchange was waiting for: info = {epoch, slice (row / slice index of the launch), peer
+ * rank whose flag never arrived, the flag value seen instead (an older epoch: the peer never got there; a newer one:
+ * the peer is ahead)}.  Synchronous; meaningful once mi_comm_status reports a time-out.  Bring-up aid. */
+int mi_comm_timeout_info(mi_comm* comm, uint32_t info[4]);
 
 /* ---- host-side hashing (reference: engine/block_manager.py:38-44) --------- */
 /* xxh64 of `len` bytes with seed 0, optionally prefixed by the 8 little-endian

@@ -2,8 +2,11 @@
 //
 // Region of one rank (uncached device memory, mapped by every peer through HIP IPC):
 //   [0, 4096)            control: epoch u32, finished-workgroup counter u32, sticky timeout flag u32,
-//                        spin limit u32 (polls before a peer is declared missing)
-//   [4096, +flag bytes)  flags[parity 2][source rank world][MAX_SLICES] u32  (epoch of the last arrival)
+//                        spin limit u32 (polls before a peer is declared missing), then what the first give-up was
+//                        waiting for: epoch, slice, peer, flag value seen
+//   [4096, +flag bytes)  flags[parity 2][source rank world][MAX_SLICES], ONE 128-byte line per flag (u32 epoch of the
+//                        last arrival in its first word: flags of neighbouring slices are written by waves on different
+//                        XCDs, i.e. through different L2s - they do not share a line)
 //   [..., +slot bytes)   slots[parity 2][source rank world][max_bytes]
 // A launch cuts the vector into slices (up to 64 element ranges for the plain all-reduce, one row each
 // for the fused add+RMSNorm), one single-wave workgroup per slice; workgroup s owns slice s in every phase, so the only cross-GPU dependency
@@ -18,6 +21,7 @@
 namespace mi {
 
 constexpr int MAX_SLICES = 512;  // flag slots per (parity, source): rows of the fused kernel (= the largest decode batch)
+constexpr int FLAG_STRIDE = 32;   // u32 words between two flags: a 128-byte line each
 constexpr size_t CTRL_BYTES = 4096;
 constexpr uint32_t DEFAULT_SPIN_LIMIT = 1u << 26;  // polls of ~1 us each: about a minute
 
@@ -31,7 +35,7 @@ struct Layout {
 static Layout layout(int world, size_t max_bytes) {
   Layout l;
   l.flags_off = CTRL_BYTES;
-  const size_t flag_bytes = ((size_t)2 * world * MAX_SLICES * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t flag_bytes = ((size_t)2 * world * MAX_SLICES * FLAG_STRIDE * sizeof(uint32_t) + 255) / 256 * 256;
   l.slots_off = l.flags_off + flag_bytes;
   l.slot_stride = (max_bytes + 255) / 256 * 256;
   l.total = l.slots_off + (size_t)2 * world * l.slot_stride;
@@ -58,10 +62,10 @@ __device__ __forceinline__ void comm_publish_and_wait(const CommGeom& g, uint32_
   if (tid < g.world) {
     const uint32_t par = e & 1u;
     uint32_t* theirs = reinterpret_cast<uint32_t*>(g.peers.region[tid] + g.flags_off) +
-                       ((size_t)par * g.world + g.rank) * MAX_SLICES + s;
+                       (((size_t)par * g.world + g.rank) * MAX_SLICES + s) * FLAG_STRIDE;
     __hip_atomic_store(theirs, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t* arrive = reinterpret_cast<const uint32_t*>(g.peers.region[g.rank] + g.flags_off) +
-                             ((size_t)par * g.world + tid) * MAX_SLICES + s;
+                             (((size_t)par * g.world + tid) * MAX_SLICES + s) * FLAG_STRIDE;
     // (once an exchange has timed out the step's results are void - the host raises when it reads the sticky flag: the
     // launches still queued behind it do not each wait their full patience for the same missing peer)
     const volatile uint32_t* ctrl = reinterpret_cast<const volatile uint32_t*>(g.peers.region[g.rank]);
@@ -69,8 +73,15 @@ __device__ __forceinline__ void comm_publish_and_wait(const CommGeom& g, uint32_
     uint32_t spins = 0;
     while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
       if (++spins > limit) {
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(g.peers.region[g.rank]) + 2, 1u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t* own = reinterpret_cast<uint32_t*>(g.peers.region[g.rank]);
+        // the FIRST give-up of this rank says what it was waiting for (mi_comm_timeout_info): words 4..7 =
+        // {epoch, slice, peer, the flag value seen instead}
+        if (__hip_atomic_exchange(own + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+          own[4] = e;
+          own[5] = (uint32_t)s;
+          own[6] = (uint32_t)tid;
+          own[7] = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -507,6 +518,14 @@ extern "C" int mi_comm_set_spin_limit(mi_comm* comm, uint32_t polls) {
   if (!comm || polls == 0) return MI_EINVAL;
   if (hipMemcpy(comm->ptrs.region[comm->rank] + 3 * sizeof(uint32_t), &polls, sizeof(polls), hipMemcpyHostToDevice) !=
       hipSuccess)
+    return MI_ERUNTIME;
+  return MI_OK;
+}
+
+extern "C" int mi_comm_timeout_info(mi_comm* comm, uint32_t info[4]) {
+  if (!comm || !info) return MI_EINVAL;
+  if (hipMemcpy(info, comm->ptrs.region[comm->rank] + 4 * sizeof(uint32_t), 4 * sizeof(uint32_t),
+                hipMemcpyDeviceToHost) != hipSuccess)
     return MI_ERUNTIME;
   return MI_OK;
 }

@@ -162,6 +162,7 @@ _SIGNATURES = {
     "mi_allreduce_add_rmsnorm": (c_int, [_p, _p, _p, _p, _p, _p, c_int, c_int, c_float, _p]),
     "mi_comm_set_spin_limit": (c_int, [_p, ctypes.c_uint32]),
     "mi_comm_status": (c_int, [_p, ctypes.POINTER(c_int)]),
+    "mi_comm_timeout_info": (c_int, [_p, _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

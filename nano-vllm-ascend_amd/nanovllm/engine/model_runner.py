@@ -132,7 +132,8 @@ class ModelRunner:
             eager_rows = max(64, min(config.max_num_seqs, 512))
             self.xgmi = xgmi_comm.create_if_enabled(rank, self.world_size, rows * self.hf_config.hidden_size * 2,
                                                     self.device)
-            if self.xgmi is not None:  # eager launches: decode-sized rows only (XgmiComm.eager_max_bytes)
+            if self.xgmi is not None and os.environ.get("MI355_XGMI_EAGER_LARGE", "0") != "1":
+                # eager launches: decode-sized rows only (XgmiComm.eager_max_bytes; the switch: bring-up / repro)
                 self.xgmi.eager_max_bytes = eager_rows * self.hf_config.hidden_size * 2
             parallel.set_xgmi_comm(self.xgmi)
             self.xgmi_selftest = xgmi_comm.LAST_STATUS
@@ -965,7 +966,7 @@ class ModelRunner:
         self.prefill_events[b].synchronize()
         if self._xgmi_flag is not None and int(self._xgmi_flag[0]):
             self._abort_workers()
-            raise RuntimeError("rank 0: xGMI exchange timed out waiting for a peer; results are invalid")
+            raise RuntimeError(f"rank 0: xGMI exchange timed out waiting for a peer; results are invalid - {self.xgmi.timeout_info()}")
         return self.prefill_tokens_hosts[b][:real].tolist()
 
     def prefill_device_ms(self, handle) -> float:
@@ -978,7 +979,7 @@ class ModelRunner:
         self.step_events[b].synchronize()
         if self._xgmi_flag is not None and int(self._xgmi_flag[0]):
             self._abort_workers()
-            raise RuntimeError("rank 0: xGMI exchange timed out waiting for a peer; results are invalid")
+            raise RuntimeError(f"rank 0: xGMI exchange timed out waiting for a peer; results are invalid - {self.xgmi.timeout_info()}")
         return self.tokens_hosts[b][:real].tolist()
 
     def _check_xgmi(self):
@@ -987,7 +988,8 @@ class ModelRunner:
         been synchronised for the token copy - and at exit)."""
         if self.xgmi is not None and self.xgmi.timed_out():
             self._abort_workers()
-            raise RuntimeError(f"rank {self.rank}: xGMI all-reduce timed out waiting for a peer; results are invalid")
+            raise RuntimeError(f"rank {self.rank}: xGMI all-reduce timed out waiting for a peer; results are invalid - "
+                               f"{self.xgmi.timeout_info()}")
 
     def _abort_workers(self):
         """Rank 0 is about to raise: tell the workers to leave their receive loops (they kept spinning)."""

@@ -102,6 +102,17 @@ class XgmiComm:
         check(lib.mi_comm_status(self._comm, ctypes.byref(flag)), "mi_comm_status")
         return bool(flag.value)
 
+    def timeout_info(self) -> str:
+        """what this rank's first timed-out exchange was waiting for (mi_comm_timeout_info), for the error message"""
+        info = (ctypes.c_uint32 * 4)()
+        try:
+            check(lib.mi_comm_timeout_info(self._comm, info), "mi_comm_timeout_info")
+        except Exception as e:  # noqa: BLE001 - diagnostics must not mask the time-out itself
+            return f"(no details: {e!r})"
+        epoch, slice_, peer, seen = (int(v) for v in info)
+        return (f"exchange {epoch}, slice {slice_}: no flag from rank {peer} (saw {seen}: "
+                f"{'that rank is behind' if seen < epoch else 'that rank is AHEAD'})")
+
     def self_test(self) -> bool:
         """Integer-valued inputs: the fp32 sum and its bf16 rounding are exact, so the expected
         result is known without a second collective.  Covers the smallest and the largest vector,
@@ -158,7 +169,9 @@ class XgmiComm:
             # fault injection for tests: "the self-test failed on rank k" must end with EVERY rank on the RCCL path
             if os.environ.get("MI355_XGMI_SELFTEST_FAIL_RANK") == str(self.rank):
                 ok = False
-            check(lib.mi_comm_set_spin_limit(self._comm, 1 << 26), "mi_comm_set_spin_limit")
+            # patience in production: ~a minute and more per exchange (MI355_XGMI_SPIN_LIMIT: bring-up / repro runs)
+            check(lib.mi_comm_set_spin_limit(self._comm, int(os.environ.get("MI355_XGMI_SPIN_LIMIT", 1 << 26))),
+                  "mi_comm_set_spin_limit")
         except Exception as e:  # noqa: BLE001 - any failure means "do not use this path"
             warnings.warn(f"xGMI all-reduce self-test raised {e!r}")
             ok = False

@@ -85,3 +85,68 @@ def test_allreduce_ranks_sharing_one_gpu(world):
         assert ok, f"rank {rank}: self-test failed"
         assert exact, f"rank {rank}: sum differs from the rank-ordered fp32 sum"
         assert not timed_out, f"rank {rank}: a peer timed out"
+
+
+def _worker_missing_peer(rank, world, port, out):
+    import ctypes
+
+    import torch.distributed as dist
+
+    from nanovllm._C import check, lib
+    from nanovllm.layers.xgmi_comm import XgmiComm
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = XgmiComm(rank, world, 1 << 16, dev)
+    try:
+        x = torch.full((64,), float(rank + 1), dtype=torch.bfloat16, device=dev)
+        comm.all_reduce(x)  # a complete exchange first (epoch 1)
+        torch.cuda.synchronize()
+        first_ok = bool((x == 3).all()) and not comm.timed_out()
+        dist.barrier()
+        info = ""
+        if rank == 0:  # rank 1 never launches the second exchange
+            check(lib.mi_comm_set_spin_limit(comm._comm, 1 << 12), "mi_comm_set_spin_limit")
+            comm.all_reduce(torch.ones(64, dtype=torch.bfloat16, device=dev))
+            comm.all_reduce(torch.ones(64, dtype=torch.bfloat16, device=dev))  # (behind a time-out: gives up at once)
+            torch.cuda.synchronize()
+            info = comm.timeout_info()
+            raw = (ctypes.c_uint32 * 4)()
+            check(lib.mi_comm_timeout_info(comm._comm, raw), "mi_comm_timeout_info")
+            info = (info, [int(v) for v in raw])
+        out.put((rank, first_ok, comm.timed_out(), info))
+    finally:
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
+
+
+def test_a_missing_peer_raises_the_sticky_flag_and_says_who_was_missing():
+    """A peer that never launches its side of an exchange: the waiting rank gives up after its spin limit instead of
+    hanging the GPU, the sticky flag is set, mi_comm_timeout_info names the exchange (epoch 2), the slice and the missing
+    rank with the stale flag value it saw (epoch 0 or 1: that rank is behind) - and the exchange queued behind the
+    time-out does not wait its patience again."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker_missing_peer, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        results = sorted(out.get(timeout=180) for _ in range(2))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    (r0, ok0, timed0, info0), (r1, ok1, timed1, _) = results
+    assert ok0 and ok1 and not timed1
+    assert timed0, "rank 0 waited for a peer that never came and did not report it"
+    text, (epoch, slice_, peer, seen) = info0
+    assert epoch == 2 and slice_ == 0 and peer == 1 and seen < epoch, info0
+    assert "rank 1" in text and "behind" in text
