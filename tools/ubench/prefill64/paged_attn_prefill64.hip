@@ -1,3 +1,4 @@
+// EXPERIMENT, NOT PART OF THE LIBRARY (README.md next to this file: slower than the 32-column kernel, and not robust).
 // Prefill attention with SIXTY-FOUR query columns per wave (round 6), 128-wide heads.
 // Reference operator: /root/reference/nanovllm/layers/attention.py:46-59 (the prefill branch: causal attention of the
 // new tokens over the paged cache, block tables and cu_seqlens as given).
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill64_kernel(
   // One column block after the other: only ONE block's eight fragments (and rope registers) are alive at a time.  (Both
   // blocks' loads ahead of any arithmetic - 64 more live registers across the prologue - saved ~10 k cycles of the
   // prologue's dependent round trips and made the register allocator SPILL pinned accumulators inside the stage, i.e.
-  // read them right behind the inline-asm MFMA that writes them: wrong results.  tests/test_build_artifacts.py holds
-  // every instantiation of this kernel to zero scratch.)
+  // read them right behind the inline-asm MFMA that writes them: wrong results.  This order did not remove the spills
+  // either - see README.md next to this file: the kernel is an experiment, not part of the library.)
   bf16x8 Q[2][8];
   const uint32_t lds_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)stage;
   const uint32_t qslot = lds_base + P64_RING_BYTES + threadIdx.x * 256;
