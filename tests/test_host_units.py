@@ -1212,3 +1212,26 @@ def test_lazily_captured_prefill_graphs_are_keyed_by_buckets_that_pad_by_at_most
             assert tb >= tokens and tb % 256 == 0 and (tb - tokens) * 16 <= tokens
             assert sb >= 1 + tokens % 40 and sb & (sb - 1) == 0
             assert mq >= max(256, 1 + tokens % 1500) and mq & (mq - 1) == 0
+
+
+def test_exchange_region_cap_for_eager_launches_and_the_scope_that_lifts_it():
+    """XgmiComm.fits / fits_rows (round 6): an eager launch may put decode-sized rows through the exchange region only,
+    however large the region is (it is also sized for captured prefill steps); `large()` lifts the cap for the capture of
+    such a step, nests, and restores it when the capture raises."""
+    from nanovllm.layers.xgmi_comm import XgmiComm
+
+    comm = object.__new__(XgmiComm)  # (no device, no process group: the arithmetic only)
+    comm.max_bytes, comm.eager_max_bytes, comm._large = 1024 * 2048 * 2, 64 * 2048 * 2, 0
+    assert comm.fits_rows(64, 2048) and not comm.fits_rows(65, 2048) and not comm.fits_rows(112, 2048)
+    with comm.large():
+        assert comm.fits_rows(112, 2048) and comm.fits_rows(512, 2048) and not comm.fits_rows(513, 2048)
+        with comm.large():
+            assert comm.fits_rows(512, 2048)
+        assert comm.fits_rows(512, 2048)
+    assert not comm.fits_rows(112, 2048)
+    with pytest.raises(RuntimeError):
+        with comm.large():
+            raise RuntimeError("capture failed")
+    assert comm._large == 0 and not comm.fits_rows(112, 2048)
+    comm.eager_max_bytes = comm.max_bytes  # (MI355_XGMI_EAGER_LARGE=1: the bring-up switch)
+    assert comm.fits_rows(512, 2048)
